@@ -1,0 +1,155 @@
+"""Deterministic synthetic inputs shared by tests and bench (no files, no network).
+
+The shapes follow SURVEY.md §8(d): the reference's own self-test generator grid (tool/zultra.c:425-463:
+alphabet sizes x match probabilities, literal runs 0..127, match lengths 3..1026, offsets uniform in
+history), text-like data standing in for enwik8, JSON-like 4 KiB records, plus the degenerate cases the
+hot path special-cases (all-equal bytes, short periods, incompressible noise).
+All generators are seeded numpy MT19937 streams, stable across numpy versions and machines.
+"""
+import numpy as np
+
+SELFTEST_ALPHABETS = [1, 2, 3, 15, 30, 56, 96, 137, 178, 191, 255, 256]   # tool/zultra.c:534
+
+
+def selftest_data(size, seed, n_literal_values, match_probability):
+    """Same construction as the reference's generate_compressible_data, with our own PRNG."""
+    rs = np.random.RandomState(seed)
+    buf = np.zeros(size, dtype=np.uint8)
+    if size == 0:
+        return buf
+    thresh = int(match_probability * 1023.0)
+    buf[0] = rs.randint(0, n_literal_values)
+    i = 1
+    while i < size:
+        if rs.randint(0, 1024) >= thresh:
+            cnt = min(int(rs.randint(0, 128)), size - i)
+            if cnt:
+                buf[i:i + cnt] = rs.randint(0, n_literal_values, size=cnt)
+                i += cnt
+        else:
+            ln = 3 + int(rs.randint(0, 1024))
+            ln = min(ln, size - i, i)
+            off = int(rs.randint(0, i - ln)) if ln < i else 0
+            # overlapping copy semantics: byte by byte from i-off (off may be 0 => repeats itself)
+            if off >= ln:
+                buf[i:i + ln] = buf[i - off:i - off + ln]
+            else:
+                for k in range(ln):
+                    buf[i + k] = buf[i + k - off]
+            i += ln
+    return buf
+
+
+_WORDS = None
+
+
+def _vocab(rs, n=4096):
+    letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
+    weights = np.array([12.7, 9.1, 8.2, 7.5, 7.0, 6.7, 6.3, 6.1, 6.0, 4.3, 4.0, 2.8, 2.8, 2.4, 2.4, 2.2, 2.0, 2.0, 1.9,
+                        1.5, 1.0, 0.8, 0.15, 0.15, 0.1, 0.07])
+    weights = weights / weights.sum()
+    words = []
+    for _ in range(n):
+        ln = 1 + min(int(rs.geometric(0.25)), 14)
+        words.append(bytes(rs.choice(letters, size=ln, p=weights)))
+    return words
+
+
+def text_like(size, seed=1):
+    """Zipf-distributed words, sentences, paragraphs and wiki-ish markup: an enwik8 stand-in."""
+    rs = np.random.RandomState(seed)
+    words = _vocab(np.random.RandomState(12345))
+    ranks = rs.zipf(1.25, size=size // 3 + 64)
+    ranks = np.minimum(ranks - 1, len(words) - 1)
+    out = bytearray()
+    k = 0
+    sent = 0
+    while len(out) < size:
+        w = words[int(ranks[k])]
+        k += 1
+        if sent == 0:
+            w = w.capitalize()
+        r = rs.randint(0, 100)
+        if r < 3:
+            out += b"[[" + w + b"]]"
+        elif r < 5:
+            out += b"'''" + w + b"'''"
+        elif r < 6:
+            out += b"&quot;" + w + b"&quot;"
+        elif r < 7:
+            out += str(int(rs.randint(0, 2100))).encode()
+        else:
+            out += w
+        sent += 1
+        if sent > 4 and rs.randint(0, 12) == 0:
+            out += b". "
+            sent = 0
+            if rs.randint(0, 8) == 0:
+                out += b"\n\n" if rs.randint(0, 4) else b"\n== " + words[int(ranks[k])] + b" ==\n"
+        elif rs.randint(0, 15) == 0:
+            out += b", "
+        else:
+            out += b" "
+    return np.frombuffer(bytes(out[:size]), dtype=np.uint8).copy()
+
+
+def json_like(size, seed=1):
+    """JSON-ish records (config 5 of BASELINE.json), truncated/padded to ``size`` bytes."""
+    rs = np.random.RandomState(seed)
+    names = [w.decode() for w in _vocab(np.random.RandomState(777), 64)]
+    out = bytearray()
+    rid = int(rs.randint(0, 1 << 30))
+    while len(out) < size:
+        tags = ",".join('"%s"' % names[int(t)] for t in rs.randint(0, 64, size=int(rs.randint(0, 5))))
+        out += ('{"id":%d,"user":"%s","ts":%d,"tags":[%s],"v":%.4f}\n' % (
+            rid, names[int(rs.randint(0, 64))], 1700000000 + int(rs.randint(0, 1 << 24)), tags, rs.rand() * 1000)).encode()
+        rid += 1 + int(rs.randint(0, 3))
+    return np.frombuffer(bytes(out[:size]), dtype=np.uint8).copy()
+
+
+def noise(size, seed=1):
+    return np.random.RandomState(seed).randint(0, 256, size=size).astype(np.uint8)
+
+
+def constant(size, value=0):
+    return np.full(size, value, dtype=np.uint8)
+
+
+def periodic(size, period=3, seed=1):
+    pat = np.random.RandomState(seed).randint(0, 256, size=period).astype(np.uint8)
+    return np.resize(pat, size)
+
+
+def sparse_ones(size, seed=1, gap=200):
+    """Zeros with a 1 at irregular gaps: long-but-not-maximal matches everywhere (matchfinder stress)."""
+    rs = np.random.RandomState(seed)
+    buf = np.zeros(size, dtype=np.uint8)
+    i = 0
+    while i < size:
+        i += int(rs.randint(gap // 2, gap * 2))
+        if i < size:
+            buf[i] = 1
+    return buf
+
+
+def mixed(size, seed=1):
+    """Segments cycling through the self-test grid plus noise and constant runs (config 4 shape)."""
+    rs = np.random.RandomState(seed)
+    probs = [0.0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.995]
+    parts = []
+    total = 0
+    k = 0
+    while total < size:
+        seg = min(int(rs.randint(4096, 49152)), size - total)
+        sel = k % 16
+        if sel == 14:
+            parts.append(noise(seg, seed + k))
+        elif sel == 15:
+            parts.append(constant(seg, int(rs.randint(0, 256))))
+        elif sel % 3 == 2:
+            parts.append(text_like(seg, seed + k))
+        else:
+            parts.append(selftest_data(seg, seed + k, SELFTEST_ALPHABETS[k % 12], probs[(k * 7) % 11]))
+        total += seg
+        k += 1
+    return np.concatenate(parts)[:size]
