@@ -90,7 +90,7 @@ class Oracle:
     def deflate(self, win, match, prev, start, size, is_dynamic):
         """-> (rc, nbits, bytes, best[size,2], lit_len[288], dist_len[32])"""
         win = as_u8(win)
-        cap = size + 64
+        cap = 2 * size + 1024
         out = np.zeros(cap, dtype=np.uint8)
         nbits = C.c_uint64()
         best = np.zeros((size, 2), dtype=np.uint16)
@@ -217,7 +217,7 @@ class Ref:
             return dyn, s.value, d.value
 
         def deflate(self, start, size, is_dynamic):
-            cap = size + 1024
+            cap = 2 * size + 1024
             out = np.zeros(cap, dtype=np.uint8)
             nbits = C.c_longlong()
             best = np.zeros((size, 2), dtype=np.uint16)
