@@ -1,0 +1,118 @@
+/*
+ * zultra_hip.h — C ABI of the MI355X (gfx950) device layer: batches of independent max-blocks in, per-sub-block
+ * deflate bit strings out. Plain pointers and sizes only.
+ *
+ * This is the inner boundary of the reference: the five calls that zultra_stream_compress makes per max-block
+ * (reference src/libzultra.c:287-343)
+ *      zultra_build_suffix_array(win, prev+n)            :287   \
+ *      zultra_skip_matches(0, prev)                      :291    >  stage 1  (zultra_hip: match rows)
+ *      zultra_find_all_matches(prev, prev+n)             :293   /
+ *      zultra_block_split(win, prev, n, 64, splits)      :303      stage 2  (zultra_hip: sub-block boundaries)
+ *      zultra_block_prepare_cost_evaluation / _evaluate_static_cost / 2x _estimate_dynamic_codelens /
+ *      _evaluate_dynamic_cost                            :317-321  stage 3a (static vs dynamic)
+ *      zultra_block_deflate(win, start, size, isDynamic) :343      stage 3b (bits of the sub-block body)
+ * are replaced by ONE batched call, zultra_hip_compress_blocks(), which runs them for many max-blocks at once
+ * (max-blocks are independent given their 32 KiB of raw history). What stays on the caller's side
+ * is exactly what depends on the running bit phase of the output stream: BFINAL/BTYPE bits, the stored-block
+ * fallback and the bit carry between max-blocks (libzultra.c:327-398, 414-436) — done by zultra_hip_stitch().
+ *
+ * There is no CPU fallback: every entry point fails (NULL / negative) when no HIP device is usable.
+ */
+#ifndef ZULTRA_HIP_H
+#define ZULTRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zultra_hip_ctx_s zultra_hip_ctx_t;
+
+/* One max-block: window = data + win_off, `prev` bytes of history (0..32768) followed by `n` block bytes
+ * (1..max_block_size). Mirrors the (pInWindow, nPreviousBlockSize, nInDataSize) triple of libzultra.c:287-303. */
+typedef struct zultra_hip_block_s {
+   uint64_t win_off;
+   uint32_t prev;
+   uint32_t n;
+} zultra_hip_block_t;
+
+/* One sub-block result, in stream order. Mirrors what libzultra.c:314-347 needs to frame it. */
+typedef struct zultra_hip_subblock_s {
+   uint32_t block;          /* index of the max-block in the batch */
+   uint32_t start;          /* offset of the sub-block inside the max-block (nInStart, libzultra.c:297) */
+   uint32_t size;           /* nBlockSize, libzultra.c:314 */
+   uint32_t is_dynamic;     /* nIsDynamic, libzultra.c:323-324 */
+   int32_t static_cost;     /* nStaticCost  (blockdeflate.c:538) */
+   int32_t dynamic_cost;    /* nDynamicCost (blockdeflate.c:577) */
+   uint32_t failed;         /* non-zero: zultra_block_deflate would have failed / outgrown its buffer -> store it */
+   uint32_t reserved;
+   uint64_t nbits;          /* exact bit length of the body (after the 3 header bits) */
+   uint64_t bits_off;       /* byte offset of the body's bit string (bit phase 0) in the payload */
+} zultra_hip_subblock_t;
+
+/* Timings of the last batch, milliseconds, measured with HIP events on the context's stream. */
+typedef struct zultra_hip_timing_s {
+   float h2d_ms, matchfinder_ms, tokenize_split_ms, encode_ms, d2h_ms, total_ms;
+   float group_ms, frontier_ms;
+} zultra_hip_timing_t;
+
+/* Number of usable HIP devices (0 if none). */
+int zultra_hip_device_count(void);
+
+/* Create a context on `device` able to take batches of up to max_blocks max-blocks of up to max_block_size bytes
+ * (clamped like libzultra.c:87-92). All device memory is allocated here and released by zultra_hip_destroy
+ * (the reference allocates in zultra_stream_init and frees in zultra_stream_end, libzultra.c:82-166,521-565).
+ * Returns NULL on failure (no device, out of memory). */
+zultra_hip_ctx_t *zultra_hip_create(int device, uint32_t max_block_size, uint32_t max_blocks);
+void zultra_hip_destroy(zultra_hip_ctx_t *ctx);
+const char *zultra_hip_last_error(const zultra_hip_ctx_t *ctx);
+
+/* Bytes of input the context can hold per batch (max_blocks * max_block_size + 32768 of leading history). */
+size_t zultra_hip_data_capacity(const zultra_hip_ctx_t *ctx);
+
+/* Run stages 1-3 for a batch. `data` holds every window of the batch (host memory if data_on_device == 0, else a
+ * device pointer valid on the context's device; it is then read in place, nothing is copied). Returns the number of
+ * sub-blocks (>0) or a negative error. Results stay in the context until the next batch. */
+int zultra_hip_compress_blocks(zultra_hip_ctx_t *ctx, const void *data, size_t data_size, int data_on_device,
+                               const zultra_hip_block_t *blocks, uint32_t nblocks);
+
+/* Results of the last batch as host pointers owned by the context (valid until the next batch / destroy). */
+const zultra_hip_subblock_t *zultra_hip_subblocks(const zultra_hip_ctx_t *ctx, uint32_t *count);
+const uint8_t *zultra_hip_payload(const zultra_hip_ctx_t *ctx, size_t *size);
+void zultra_hip_last_timing(const zultra_hip_ctx_t *ctx, zultra_hip_timing_t *t);
+
+/* Stage outputs of the last batch, for parity tests (copied device -> host on request).
+ *   matches: n*8 entries {u16 length, u16 offset} of max-block `block`          (match[], private.h:59-62,97)
+ *   splits : absolute window offsets of the sub-block ends, last = prev+n; returns the count (nSplitOffset, libzultra.c:299)
+ *   parse  : n entries {u16 length, u16 offset}, the final parse                (best_match[], private.h:98) */
+int zultra_hip_get_matches(zultra_hip_ctx_t *ctx, uint32_t block, uint16_t *out);
+int zultra_hip_get_splits(zultra_hip_ctx_t *ctx, uint32_t block, int *out /* [64] */);
+int zultra_hip_get_parse(zultra_hip_ctx_t *ctx, uint32_t block, uint16_t *out);
+
+/*
+ * Stitcher (host): appends the framed sub-blocks of a batch to a deflate stream, reproducing libzultra.c:327-398
+ * (3 header bits, compressed-or-stored decision from the running bit phase, stored pieces of <= 65535 bytes) and
+ * the bit carry across max-blocks (:427-434).
+ *   state        : running bit writer (zero-initialise before the first batch of a stream)
+ *   raw          : the raw bytes of the batch's max-blocks, max-block b at raw + raw_off[b] (for stored sub-blocks)
+ *   final_block  : index of the max-block that ends the stream (ZULTRA_FINALIZE and no more input), or -1
+ * Writes whole bytes to out (capacity out_cap) and returns the number written, or (size_t)-1 on overflow / error
+ * (the reference's ZULTRA_ERROR_DST). Call zultra_hip_stitch_finish() after the last batch to pad to a byte
+ * (libzultra.c:414-417).
+ */
+typedef struct zultra_hip_bitstate_s {
+   uint32_t acc;     /* pending bits, LSB first (zultra_bitwriter_t.nEncBitsData, bitwriter.h:27-33) */
+   uint32_t nacc;    /* 0..7             (nEncBitCount) */
+} zultra_hip_bitstate_t;
+
+size_t zultra_hip_stitch(zultra_hip_bitstate_t *state, const zultra_hip_subblock_t *subs, uint32_t nsubs,
+                         const uint8_t *payload, const uint8_t *raw, const uint64_t *raw_off, uint32_t max_block_size,
+                         int final_block, uint8_t *out, size_t out_cap);
+size_t zultra_hip_stitch_finish(zultra_hip_bitstate_t *state, uint8_t *out, size_t out_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZULTRA_HIP_H */

@@ -1,0 +1,311 @@
+// tests/emu/zh_platform.h — TEST INFRASTRUCTURE ONLY.
+//
+// Lock-step CPU emulator of the small slice of HIP that zultra_amd/csrc uses, so that the *product's own
+// kernel sources* can be executed (slowly) on a machine without a GPU and diffed against the oracle in the
+// `-m "not gpu"` test-suite. It shadows csrc/zh_platform.h purely through include-path order
+// (tests/emu/build_emu.py); the product library is never built against it and no product code path can
+// reach it.
+//
+// Model: one OS thread; every GPU thread of the running workgroup is a ucontext fiber; workgroups run one
+// after another. A fiber runs until it reaches a collective (wave primitive or __syncthreads), where it
+// parks until all live fibers of its wave / workgroup have arrived — i.e. collectives must be reached by
+// all lanes of the group (the same discipline the real kernels keep on the GPU).
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <algorithm>
+#include <functional>
+#include <vector>
+
+#define ZH_EMU 1
+#define ZH_WAVE 64
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+using std::max;
+using std::min;
+
+struct dim3 {
+   unsigned x, y, z;
+   dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+
+namespace zh_emu {
+struct Fiber {
+   ucontext_t ctx;
+   char *stack = nullptr;
+   bool done = false;
+   int waiting = 0;   // 0 = runnable, 1 = wave collective, 2 = workgroup barrier
+};
+inline std::vector<Fiber> g_fibers;
+inline ucontext_t g_sched;
+inline int g_cur = -1;
+inline std::function<void()> g_body;
+inline uint64_t g_slot[1024];
+inline const size_t kStack = 256 * 1024;
+}   // namespace zh_emu
+
+inline dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace zh_emu {
+
+inline void park(int kind) {
+   Fiber &f = g_fibers[g_cur];
+   f.waiting = kind;
+   swapcontext(&f.ctx, &g_sched);
+}
+
+inline void trampoline() {
+   g_body();
+   g_fibers[g_cur].done = true;
+   swapcontext(&g_fibers[g_cur].ctx, &g_sched);
+}
+
+// release a group if every live member is parked on the same kind
+inline bool try_release(int lo, int hi, int kind) {
+   bool any = false;
+   for (int i = lo; i < hi; i++) {
+      if (g_fibers[i].done) continue;
+      if (g_fibers[i].waiting != kind) return false;
+      any = true;
+   }
+   if (!any) return false;
+   for (int i = lo; i < hi; i++) g_fibers[i].waiting = 0;
+   return true;
+}
+
+inline void run_block(unsigned nthreads) {
+   if (g_fibers.size() < nthreads) g_fibers.resize(nthreads);
+   for (unsigned t = 0; t < nthreads; t++) {
+      Fiber &f = g_fibers[t];
+      if (!f.stack) f.stack = (char *)malloc(kStack);
+      f.done = false;
+      f.waiting = 0;
+      getcontext(&f.ctx);
+      f.ctx.uc_stack.ss_sp = f.stack;
+      f.ctx.uc_stack.ss_size = kStack;
+      f.ctx.uc_link = &g_sched;
+      makecontext(&f.ctx, (void (*)())trampoline, 0);
+   }
+   for (;;) {
+      bool progressed = false, alive = false;
+      for (unsigned t = 0; t < nthreads; t++) {
+         Fiber &f = g_fibers[t];
+         if (f.done) continue;
+         alive = true;
+         if (f.waiting) continue;
+         g_cur = (int)t;
+         threadIdx = dim3(t, 0, 0);
+         swapcontext(&g_sched, &f.ctx);
+         progressed = true;
+      }
+      if (!alive) break;
+      bool released = false;
+      for (unsigned w = 0; w * 64 < nthreads; w++)
+         released |= try_release((int)(w * 64), (int)std::min(nthreads, (w + 1) * 64), 1);
+      released |= try_release(0, (int)nthreads, 2);
+      if (!progressed && !released) {
+         fprintf(stderr, "zh_emu: deadlock (divergent collective?) in block %u\n", blockIdx.x);
+         abort();
+      }
+   }
+}
+
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, Args... args) {
+   gridDim = grid;
+   blockDim = block;
+   for (unsigned b = 0; b < grid.x; b++) {
+      blockIdx = dim3(b, 0, 0);
+      g_body = [=]() { kernel(args...); };
+      run_block(block.x);
+   }
+}
+
+inline int wave_base() { return g_cur & ~63; }
+inline int wave_end() { return std::min((int)blockDim.x, wave_base() + 64); }
+
+template <typename F>
+inline uint64_t collect(uint64_t mine, F combine) {
+   g_slot[g_cur] = mine;
+   park(1);
+   uint64_t r = combine();
+   park(1);
+   return r;
+}
+}   // namespace zh_emu
+
+#define ZH_LAUNCH(kernel, grid, block, stream, ...) zh_emu::launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)
+
+inline void __syncthreads() { zh_emu::park(2); }
+inline void zh_sync() { zh_emu::park(2); }
+
+inline unsigned zh_lane() { return (unsigned)zh_emu::g_cur & 63u; }
+inline uint64_t zh_ballot(bool p) {
+   using namespace zh_emu;
+   return collect(p ? 1 : 0, [] {
+      uint64_t m = 0;
+      for (int i = wave_base(); i < wave_end(); i++)
+         if (!g_fibers[i].done && g_slot[i]) m |= 1ull << (i & 63);
+      return m;
+   });
+}
+inline uint32_t zh_shfl(uint32_t v, int src) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [src] { return g_slot[wave_base() + (src & 63)]; });
+}
+inline uint32_t zh_readlane(uint32_t v, int lane) { return zh_shfl(v, lane); }
+inline uint32_t zh_readfirstlane(uint32_t v) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [] {
+      for (int i = wave_base(); i < wave_end(); i++)
+         if (!g_fibers[i].done) return g_slot[i];
+      return (uint64_t)0;
+   });
+}
+inline int zh_popc64(uint64_t m) { return __builtin_popcountll(m); }
+inline int zh_ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
+inline int zh_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+
+inline uint32_t zh_row_min(uint32_t v) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [] {
+      int lo = g_cur & ~15;
+      uint64_t m = ~0ull;
+      for (int i = lo; i < lo + 16 && i < (int)blockDim.x; i++) m = std::min(m, g_slot[i]);
+      return m;
+   });
+}
+inline uint32_t zh_wave_min(uint32_t v) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [] {
+      uint64_t m = ~0ull;
+      for (int i = wave_base(); i < wave_end(); i++) m = std::min(m, g_slot[i]);
+      return m;
+   });
+}
+inline uint32_t zh_wave_sum(uint32_t v) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [] {
+      uint64_t s = 0;
+      for (int i = wave_base(); i < wave_end(); i++) s += g_slot[i];
+      return s;
+   });
+}
+inline uint32_t zh_wave_excl_sum(uint32_t v) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [] {
+      uint64_t s = 0;
+      for (int i = wave_base(); i < g_cur; i++) s += g_slot[i];
+      return s;
+   });
+}
+
+inline uint32_t atomicAdd(uint32_t *p, uint32_t v) {
+   uint32_t o = *p;
+   *p = o + v;
+   return o;
+}
+inline int atomicAdd(int *p, int v) {
+   int o = *p;
+   *p = o + v;
+   return o;
+}
+inline uint32_t atomicMax(uint32_t *p, uint32_t v) {
+   uint32_t o = *p;
+   if (v > o) *p = v;
+   return o;
+}
+inline uint32_t atomicOr(uint32_t *p, uint32_t v) {
+   uint32_t o = *p;
+   *p = o | v;
+   return o;
+}
+inline void __threadfence_block() {}
+inline void __threadfence() {}
+struct uint2 {
+   uint32_t x, y;
+};
+struct uint4 {
+   uint32_t x, y, z, w;
+};
+inline uint32_t zh_atomic_add_lds(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+inline uint32_t zh_atomic_add_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+inline int __popc(uint32_t v) { return __builtin_popcount(v); }
+inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
+
+// ---- the sliver of the HIP runtime API the host layer uses ---------------------------------------------
+typedef int hipError_t;
+typedef void *hipStream_t;
+typedef struct zh_emu_event {
+   double t;
+} *hipEvent_t;
+#define hipSuccess 0
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+#define hipMemcpyDeviceToDevice 3
+#define hipMemcpyDefault 4
+inline hipError_t hipGetDeviceCount(int *n) {
+   *n = 1;
+   return 0;
+}
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipMalloc(void **p, size_t n) {
+   *p = malloc(n ? n : 1);
+   return *p ? 0 : 2;
+}
+inline hipError_t hipFree(void *p) {
+   free(p);
+   return 0;
+}
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+inline hipError_t hipHostFree(void *p) { return hipFree(p); }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) {
+   memmove(d, s, n);
+   return 0;
+}
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) {
+   memmove(d, s, n);
+   return 0;
+}
+inline hipError_t hipMemset(void *d, int v, size_t n) {
+   memset(d, v, n);
+   return 0;
+}
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
+   memset(d, v, n);
+   return 0;
+}
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipStreamCreate(hipStream_t *s) {
+   *s = nullptr;
+   return 0;
+}
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipEventCreate(hipEvent_t *e) {
+   *e = new zh_emu_event{0};
+   return 0;
+}
+inline hipError_t hipEventDestroy(hipEvent_t e) {
+   delete e;
+   return 0;
+}
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) {
+   *ms = 0.f;
+   return 0;
+}

@@ -1,0 +1,316 @@
+"""ctypes bindings for the C ABI of libzultra_amd.so (include/libzultra.h + include/zultra_hip.h).
+
+Python here is plumbing for tests and benchmarks; the product is the shared library. The names mirror the
+reference's API (src/libzultra.h:104-157): ``memory_bound``, ``memory_compress``, a ``Stream`` object for
+``zultra_stream_init / set_dictionary / compress / end``, plus ``HipContext`` for the batched device layer.
+"""
+import ctypes as C
+
+import numpy as np
+
+ZULTRA_OK = 0
+ZULTRA_STREAM_END = 1
+ZULTRA_ERROR_SRC = -1
+ZULTRA_ERROR_DST = -2
+ZULTRA_ERROR_DICTIONARY = -3
+ZULTRA_ERROR_MEMORY = -4
+ZULTRA_ERROR_COMPRESSION = -5
+
+FLAG_DEFLATE = 0
+FLAG_ZLIB = 1
+FLAG_GZIP = 2
+
+CONTINUE = 0
+FINALIZE = 1
+
+_u8p = C.POINTER(C.c_uint8)
+_SIZE_MAX = C.c_size_t(-1).value
+
+
+class ZultraError(RuntimeError):
+    pass
+
+
+class _Stream(C.Structure):
+    # layout of zultra_stream_t, reference src/libzultra.h:78-93
+    _fields_ = [("next_in", C.c_void_p), ("avail_in", C.c_size_t), ("total_in", C.c_ulonglong),
+                ("next_out", C.c_void_p), ("avail_out", C.c_size_t), ("total_out", C.c_ulonglong),
+                ("zalloc", C.c_void_p), ("zfree", C.c_void_p), ("opaque", C.c_void_p),
+                ("state", C.c_void_p), ("adler", C.c_uint)]
+
+
+class Block(C.Structure):
+    _fields_ = [("win_off", C.c_uint64), ("prev", C.c_uint32), ("n", C.c_uint32)]
+
+
+class SubBlock(C.Structure):
+    _fields_ = [("block", C.c_uint32), ("start", C.c_uint32), ("size", C.c_uint32), ("is_dynamic", C.c_uint32),
+                ("static_cost", C.c_int32), ("dynamic_cost", C.c_int32), ("failed", C.c_uint32), ("reserved", C.c_uint32),
+                ("nbits", C.c_uint64), ("bits_off", C.c_uint64)]
+
+
+class Timing(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("h2d_ms", "matchfinder_ms", "tokenize_split_ms", "encode_ms", "d2h_ms", "total_ms",
+                                         "group_ms", "frontier_ms")]
+
+
+class BitState(C.Structure):
+    _fields_ = [("acc", C.c_uint32), ("nacc", C.c_uint32)]
+
+
+EXPORTS = [
+    # include/libzultra.h
+    "zultra_stream_init", "zultra_stream_set_dictionary", "zultra_stream_compress", "zultra_stream_end",
+    "zultra_memory_bound", "zultra_memory_compress", "zultra_memory_compress_dict", "zultra_set_device",
+    "zultra_frame_get_header_size", "zultra_frame_encode_header", "zultra_frame_init_checksum",
+    "zultra_frame_update_checksum", "zultra_frame_get_footer_size", "zultra_frame_encode_footer",
+    "zultra_dictionary_load", "zultra_dictionary_free",
+    # include/zultra_hip.h
+    "zultra_hip_device_count", "zultra_hip_create", "zultra_hip_destroy", "zultra_hip_last_error",
+    "zultra_hip_data_capacity", "zultra_hip_compress_blocks", "zultra_hip_subblocks", "zultra_hip_payload",
+    "zultra_hip_last_timing", "zultra_hip_get_matches", "zultra_hip_get_splits", "zultra_hip_get_parse",
+    "zultra_hip_stitch", "zultra_hip_stitch_finish",
+]
+
+
+def _as_u8(data):
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+class Lib:
+    def __init__(self, path):
+        self.path = path
+        L = self.L = C.CDLL(path)
+        missing = [n for n in EXPORTS if not hasattr(L, n)]
+        if missing:
+            raise ZultraError("%s does not export %s" % (path, missing))
+        L.zultra_stream_init.argtypes = [C.POINTER(_Stream), C.c_uint, C.c_uint]
+        L.zultra_stream_init.restype = C.c_int
+        L.zultra_stream_set_dictionary.argtypes = [C.POINTER(_Stream), C.c_void_p, C.c_int]
+        L.zultra_stream_set_dictionary.restype = C.c_int
+        L.zultra_stream_compress.argtypes = [C.POINTER(_Stream), C.c_int]
+        L.zultra_stream_compress.restype = C.c_int
+        L.zultra_stream_end.argtypes = [C.POINTER(_Stream)]
+        L.zultra_stream_end.restype = None
+        L.zultra_memory_bound.argtypes = [C.c_size_t, C.c_uint, C.c_uint]
+        L.zultra_memory_bound.restype = C.c_size_t
+        L.zultra_memory_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint]
+        L.zultra_memory_compress.restype = C.c_size_t
+        L.zultra_memory_compress_dict.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_void_p, C.c_int]
+        L.zultra_memory_compress_dict.restype = C.c_size_t
+        L.zultra_set_device.argtypes = [C.c_int]
+        L.zultra_frame_update_checksum.argtypes = [C.c_uint, C.c_void_p, C.c_size_t, C.c_uint]
+        L.zultra_frame_update_checksum.restype = C.c_uint
+        L.zultra_frame_init_checksum.argtypes = [C.c_uint]
+        L.zultra_frame_init_checksum.restype = C.c_uint
+        L.zultra_frame_encode_header.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.c_int]
+        L.zultra_frame_encode_footer.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_longlong, C.c_uint]
+        L.zultra_frame_get_header_size.argtypes = [C.c_uint, C.c_void_p, C.c_int]
+        L.zultra_frame_get_footer_size.argtypes = [C.c_uint]
+        L.zultra_hip_device_count.restype = C.c_int
+        L.zultra_hip_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+        L.zultra_hip_create.restype = C.c_void_p
+        L.zultra_hip_destroy.argtypes = [C.c_void_p]
+        L.zultra_hip_last_error.argtypes = [C.c_void_p]
+        L.zultra_hip_last_error.restype = C.c_char_p
+        L.zultra_hip_data_capacity.argtypes = [C.c_void_p]
+        L.zultra_hip_data_capacity.restype = C.c_size_t
+        L.zultra_hip_compress_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(Block), C.c_uint32]
+        L.zultra_hip_compress_blocks.restype = C.c_int
+        L.zultra_hip_subblocks.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.zultra_hip_subblocks.restype = C.POINTER(SubBlock)
+        L.zultra_hip_payload.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.zultra_hip_payload.restype = _u8p
+        L.zultra_hip_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+        L.zultra_hip_get_matches.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.zultra_hip_get_splits.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int)]
+        L.zultra_hip_get_parse.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.zultra_hip_stitch.argtypes = [C.POINTER(BitState), C.POINTER(SubBlock), C.c_uint32, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_uint64), C.c_uint32, C.c_int, C.c_void_p, C.c_size_t]
+        L.zultra_hip_stitch.restype = C.c_size_t
+        L.zultra_hip_stitch_finish.argtypes = [C.POINTER(BitState), C.c_void_p, C.c_size_t]
+        L.zultra_hip_stitch_finish.restype = C.c_size_t
+
+    # ---- libzultra.h -------------------------------------------------------------------------------------
+    def device_count(self):
+        return self.L.zultra_hip_device_count()
+
+    def memory_bound(self, n, flags, max_block=0):
+        return self.L.zultra_memory_bound(n, flags, max_block)
+
+    def memory_compress(self, data, flags, max_block=0, dictionary=None, cap=None):
+        """-> compressed bytes, or None where the reference returns (size_t)-1."""
+        data = _as_u8(data)
+        if cap is None:
+            cap = self.memory_bound(len(data), flags, max_block) + 16
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        if dictionary is not None and len(dictionary):
+            d = _as_u8(dictionary)
+            r = self.L.zultra_memory_compress_dict(data.ctypes.data, len(data), out.ctypes.data, cap, flags, max_block, d.ctypes.data, len(d))
+        else:
+            r = self.L.zultra_memory_compress(data.ctypes.data, len(data), out.ctypes.data, cap, flags, max_block)
+        if r == _SIZE_MAX:
+            return None
+        return out[:r].tobytes()
+
+    def checksum(self, data, flags, start=None):
+        data = _as_u8(data)
+        if start is None:
+            start = self.L.zultra_frame_init_checksum(flags)
+        return self.L.zultra_frame_update_checksum(start, data.ctypes.data, len(data), flags)
+
+    def stream(self, flags, max_block=0):
+        return Stream(self, flags, max_block)
+
+    def context(self, max_block, max_blocks, device=0):
+        return HipContext(self, device, max_block, max_blocks)
+
+
+class Stream:
+    """zultra_stream_t driven the way tool/zultra.c:151-186 drives it."""
+
+    def __init__(self, lib, flags, max_block=0):
+        self.lib = lib
+        self.s = _Stream()
+        rc = lib.L.zultra_stream_init(C.byref(self.s), flags, max_block)
+        if rc != ZULTRA_OK:
+            raise ZultraError("zultra_stream_init failed: %d (no HIP device? the library has no CPU path)" % rc)
+        self._keep = []
+        self.ended = False
+
+    def set_dictionary(self, d):
+        d = _as_u8(d)
+        self._keep.append(d)
+        return self.lib.L.zultra_stream_set_dictionary(C.byref(self.s), d.ctypes.data, len(d))
+
+    def compress(self, chunk, finalize, out_chunk=1 << 16):
+        """Feed one chunk; returns (status, bytes produced)."""
+        chunk = _as_u8(chunk)
+        self._keep = self._keep[-2:] + [chunk]
+        self.s.next_in = chunk.ctypes.data if len(chunk) else None
+        self.s.avail_in = len(chunk)
+        out = bytearray()
+        buf = np.empty(out_chunk, dtype=np.uint8)
+        while True:
+            self.s.next_out = buf.ctypes.data
+            self.s.avail_out = out_chunk
+            st = self.lib.L.zultra_stream_compress(C.byref(self.s), FINALIZE if finalize else CONTINUE)
+            out += buf[: out_chunk - self.s.avail_out].tobytes()
+            if st != ZULTRA_OK:
+                return st, bytes(out)
+            if self.s.avail_in == 0 and self.s.avail_out != 0:
+                return st, bytes(out)
+
+    @property
+    def total_in(self):
+        return self.s.total_in
+
+    @property
+    def total_out(self):
+        return self.s.total_out
+
+    def end(self):
+        if not self.ended:
+            self.lib.L.zultra_stream_end(C.byref(self.s))
+            self.ended = True
+
+    def __del__(self):
+        try:
+            self.end()
+        except Exception:
+            pass
+
+
+class HipContext:
+    """zultra_hip_ctx_t: batches of independent max-blocks (include/zultra_hip.h)."""
+
+    def __init__(self, lib, device, max_block, max_blocks):
+        self.lib = lib
+        self.h = lib.L.zultra_hip_create(device, max_block, max_blocks)
+        if not self.h:
+            raise ZultraError("zultra_hip_create failed: no usable HIP device (there is no CPU fallback)")
+        self.max_block = max_block
+        self._data = None
+        self._blocks = None
+
+    def close(self):
+        if self.h:
+            self.lib.L.zultra_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def compress_blocks(self, data, blocks, data_on_device=False, data_size=None):
+        """data: uint8 array (host) or an integer device pointer; blocks: list of (win_off, prev, n)."""
+        arr = (Block * len(blocks))(*[Block(int(o), int(p), int(n)) for (o, p, n) in blocks])
+        self._blocks = list(blocks)
+        if data_on_device:
+            ptr, size = int(data), int(data_size)
+        else:
+            self._data = _as_u8(data)
+            ptr, size = self._data.ctypes.data, len(self._data)
+        n = self.lib.L.zultra_hip_compress_blocks(self.h, ptr, size, 1 if data_on_device else 0, arr, len(blocks))
+        if n <= 0:
+            raise ZultraError("zultra_hip_compress_blocks: " + self.lib.L.zultra_hip_last_error(self.h).decode())
+        return n
+
+    def subblocks(self):
+        cnt = C.c_uint32()
+        p = self.lib.L.zultra_hip_subblocks(self.h, C.byref(cnt))
+        return [p[i] for i in range(cnt.value)], p, cnt.value
+
+    def subblock_bits(self, sb):
+        size = C.c_size_t()
+        p = self.lib.L.zultra_hip_payload(self.h, C.byref(size))
+        nbytes = (sb.nbits + 7) // 8
+        return bytes(bytearray(p[sb.bits_off: sb.bits_off + nbytes]))
+
+    def timing(self):
+        t = Timing()
+        self.lib.L.zultra_hip_last_timing(self.h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def matches(self, block):
+        n = self._blocks[block][2]
+        m = np.zeros((n, 8, 2), dtype=np.uint16)
+        if self.lib.L.zultra_hip_get_matches(self.h, block, m.ctypes.data) != 0:
+            raise ZultraError("get_matches")
+        return m
+
+    def splits(self, block):
+        out = (C.c_int * 64)()
+        k = self.lib.L.zultra_hip_get_splits(self.h, block, out)
+        if k < 0:
+            raise ZultraError("get_splits")
+        return list(out[:k])
+
+    def parse(self, block):
+        n = self._blocks[block][2]
+        m = np.zeros((n, 2), dtype=np.uint16)
+        if self.lib.L.zultra_hip_get_parse(self.h, block, m.ctypes.data) != 0:
+            raise ZultraError("get_parse")
+        return m
+
+    def stitch(self, raw, raw_offs, max_block, final_block, state=None, finish=True):
+        """Host stitcher over the last batch -> (bytes, BitState)."""
+        subs, p, cnt = self.subblocks()
+        size = C.c_size_t()
+        payload = self.lib.L.zultra_hip_payload(self.h, C.byref(size))
+        raw = _as_u8(raw)
+        offs = (C.c_uint64 * len(raw_offs))(*raw_offs)
+        st = state or BitState(0, 0)
+        cap = len(raw) + 64 * 6 * len(raw_offs) + 1024
+        out = np.empty(cap, dtype=np.uint8)
+        w = self.lib.L.zultra_hip_stitch(C.byref(st), p, cnt, payload, raw.ctypes.data, offs, max_block, final_block, out.ctypes.data, cap)
+        if w == _SIZE_MAX:
+            return None, st
+        if finish:
+            f = self.lib.L.zultra_hip_stitch_finish(C.byref(st), out.ctypes.data + w, cap - w)
+            w += f
+        return out[:w].tobytes(), st

@@ -1,0 +1,683 @@
+// libzultra.cpp — the drop-in libzultra API (include/libzultra.h) on top of the MI355X device layer.
+//
+// Host C++ mirror of reference src/libzultra.c (stream state machine, :200-514; in-memory entry, :576-619),
+// src/frame.c (gzip / zlib / raw framing and checksums) and src/dictionary.c. The per-max-block section of the
+// reference's loop (:287-403) is replaced by batched calls into include/zultra_hip.h; what depends on the running
+// bit phase (3 header bits, stored fallback, bit carry, :327-398 and :414-436) is zultra_hip_stitch below.
+// There is no CPU implementation of the hot path in this library: without a HIP device, stream init fails.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/libzultra.h"
+#include "../../include/zultra_hip.h"
+
+// ================================================================================================================
+// Framing and checksums (reference src/frame.c)
+// ================================================================================================================
+
+static uint32_t g_crc_tab[8][256];
+static std::once_flag g_crc_once;
+
+static void crc_init() {
+   for (uint32_t i = 0; i < 256; i++) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1) ? 0xEDB88320u : 0);
+      g_crc_tab[0][i] = c;
+   }
+   for (uint32_t i = 0; i < 256; i++)
+      for (int t = 1; t < 8; t++) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xff];
+}
+
+// CRC-32 (reflected 0xEDB88320), slicing-by-8; same function of the data as frame.c:324-354.
+static uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n) {
+   std::call_once(g_crc_once, crc_init);
+   crc = ~crc;
+   while (n && ((uintptr_t)p & 7)) {
+      crc = (crc >> 8) ^ g_crc_tab[0][(crc ^ *p++) & 0xff];
+      n--;
+   }
+   while (n >= 8) {
+      uint64_t v;
+      memcpy(&v, p, 8);
+      v ^= crc;
+      crc = g_crc_tab[7][v & 0xff] ^ g_crc_tab[6][(v >> 8) & 0xff] ^ g_crc_tab[5][(v >> 16) & 0xff] ^ g_crc_tab[4][(v >> 24) & 0xff] ^
+            g_crc_tab[3][(v >> 32) & 0xff] ^ g_crc_tab[2][(v >> 40) & 0xff] ^ g_crc_tab[1][(v >> 48) & 0xff] ^ g_crc_tab[0][v >> 56];
+      p += 8;
+      n -= 8;
+   }
+   while (n--) crc = (crc >> 8) ^ g_crc_tab[0][(crc ^ *p++) & 0xff];
+   return ~crc;
+}
+
+// Adler-32 (frame.c:74-138): sums modulo 65521, reduced every 5552 bytes.
+static uint32_t adler32_update(uint32_t adler, const uint8_t *p, size_t n) {
+   uint32_t a = adler & 0xffff, b = (adler >> 16) & 0xffff;
+   while (n) {
+      size_t chunk = n > 5552 ? 5552 : n;
+      for (size_t k = 0; k < chunk; k++) {
+         a += p[k];
+         b += a;
+      }
+      a %= 65521u;
+      b %= 65521u;
+      p += chunk;
+      n -= chunk;
+   }
+   return a | (b << 16);
+}
+
+extern "C" int zultra_frame_get_header_size(const unsigned int nFlags, const void *pDict, const int nDictSize) {
+   if (nFlags & ZULTRA_FLAG_GZIP_FRAMING) return 10;
+   if (nFlags & ZULTRA_FLAG_ZLIB_FRAMING) return (pDict && nDictSize) ? 6 : 2;
+   return 0;
+}
+
+extern "C" int zultra_frame_encode_header(unsigned char *p, const int nMax, const unsigned int nFlags, const void *pDict,
+                                          const int nDictSize) {
+   if (nFlags & ZULTRA_FLAG_GZIP_FRAMING) {
+      // RFC 1952: magic, CM=8, FLG=0, MTIME=0, XFL=2 (max compression), OS=255 (frame.c:390-401)
+      static const unsigned char gz[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 2, 255};
+      if (nMax < 10) return ZULTRA_ENCODE_ERR;
+      memcpy(p, gz, 10);
+      return 10;
+   }
+   if (nFlags & ZULTRA_FLAG_ZLIB_FRAMING) {
+      // RFC 1950: CMF=0x78, FLG: level 3, FDICT if a dictionary is set, FCHECK (frame.c:412-433)
+      const bool has_dict = pDict && nDictSize;
+      if (nMax < (has_dict ? 6 : 2)) return ZULTRA_ENCODE_ERR;
+      unsigned cmf = 0x78, flg = 0xc0 | (has_dict ? 0x20 : 0);
+      flg |= (31 - ((cmf << 8 | flg) % 31)) & 0x1f;
+      p[0] = (unsigned char)cmf;
+      p[1] = (unsigned char)flg;
+      if (!has_dict) return 2;
+      uint32_t a = adler32_update(1, (const uint8_t *)pDict, (size_t)nDictSize);
+      p[2] = (unsigned char)(a >> 24);
+      p[3] = (unsigned char)(a >> 16);
+      p[4] = (unsigned char)(a >> 8);
+      p[5] = (unsigned char)a;
+      return 6;
+   }
+   return 0;
+}
+
+extern "C" zultra_frame_checksum_t zultra_frame_init_checksum(const unsigned int nFlags) {
+   if (nFlags & ZULTRA_FLAG_GZIP_FRAMING) return 0;
+   if (nFlags & ZULTRA_FLAG_ZLIB_FRAMING) return 1;
+   return 0;
+}
+
+extern "C" zultra_frame_checksum_t zultra_frame_update_checksum(zultra_frame_checksum_t sum, const void *pData, size_t n,
+                                                                const unsigned int nFlags) {
+   if (nFlags & ZULTRA_FLAG_GZIP_FRAMING) return crc32_update(sum, (const uint8_t *)pData, n);
+   if (nFlags & ZULTRA_FLAG_ZLIB_FRAMING) return adler32_update(sum, (const uint8_t *)pData, n);
+   return 0;
+}
+
+extern "C" int zultra_frame_get_footer_size(const unsigned int nFlags) {
+   if (nFlags & ZULTRA_FLAG_GZIP_FRAMING) return 8;
+   if (nFlags & ZULTRA_FLAG_ZLIB_FRAMING) return 4;
+   return 0;
+}
+
+extern "C" int zultra_frame_encode_footer(unsigned char *p, const int nMax, const zultra_frame_checksum_t sum, long long nOriginalSize,
+                                          const unsigned int nFlags) {
+   if (nFlags & ZULTRA_FLAG_GZIP_FRAMING) {
+      if (nMax < 8) return ZULTRA_ENCODE_ERR;
+      for (int k = 0; k < 4; k++) p[k] = (unsigned char)(sum >> (8 * k));                                       // CRC32, LE
+      for (int k = 0; k < 4; k++) p[4 + k] = (unsigned char)((unsigned long long)nOriginalSize >> (8 * k));   // ISIZE mod 2^32
+      return 8;
+   }
+   if (nFlags & ZULTRA_FLAG_ZLIB_FRAMING) {
+      if (nMax < 4) return ZULTRA_ENCODE_ERR;
+      for (int k = 0; k < 4; k++) p[k] = (unsigned char)(sum >> (8 * (3 - k)));   // Adler-32, BE
+      return 4;
+   }
+   return 0;
+}
+
+// ================================================================================================================
+// Dictionary file helper (reference src/dictionary.c:49-104)
+// ================================================================================================================
+
+extern "C" zultra_status_t zultra_dictionary_load(const char *name, void **ppData, int *pSize) {
+   unsigned char *buf = NULL;
+   int n = 0;
+   if (name) {
+      FILE *f = fopen(name, "rb");
+      if (!f) return ZULTRA_ERROR_DICTIONARY;
+      buf = (unsigned char *)malloc(HISTORY_SIZE);
+      if (!buf) {
+         fclose(f);
+         return ZULTRA_ERROR_MEMORY;
+      }
+      fseek(f, 0, SEEK_END);
+      long long sz = ftello(f);
+      if (sz > HISTORY_SIZE)
+         fseek(f, -HISTORY_SIZE, SEEK_END);   // last 32 KiB of the file
+      else
+         fseek(f, 0, SEEK_SET);
+      n = (int)fread(buf, 1, HISTORY_SIZE, f);
+      if (n < 0) n = 0;
+      fclose(f);
+   }
+   *ppData = buf;
+   *pSize = n;
+   return ZULTRA_OK;
+}
+
+extern "C" void zultra_dictionary_free(void **ppData) {
+   if (ppData && *ppData) {
+      free(*ppData);
+      *ppData = NULL;
+   }
+}
+
+// ================================================================================================================
+// Stitcher (reference src/libzultra.c:327-398, 414-436; bit writer src/huffman/bitwriter.c:63-98)
+// ================================================================================================================
+
+namespace {
+struct Sink {
+   uint8_t *out;
+   size_t cap, pos;
+   uint32_t acc, nacc;
+   bool overflow;
+   inline void byte(uint8_t b) {
+      if (pos < cap)
+         out[pos] = b;
+      else
+         overflow = true;
+      pos++;
+   }
+   inline void bits(uint32_t v, uint32_t n) {   // n <= 16
+      acc |= v << nacc;
+      nacc += n;
+      while (nacc >= 8) {
+         byte((uint8_t)acc);
+         acc >>= 8;
+         nacc -= 8;
+      }
+   }
+   inline void pad() {
+      if (nacc) {
+         byte((uint8_t)(acc & ((1u << nacc) - 1)));
+         acc = 0;
+         nacc = 0;
+      }
+   }
+   // append nbits of a phase-0 bit string
+   void append(const uint8_t *src, uint64_t nbits) {
+      const uint64_t full = nbits >> 3;
+      if (nacc == 0) {
+         size_t room = pos < cap ? cap - pos : 0;
+         size_t k = full < room ? (size_t)full : room;
+         memcpy(out + pos, src, k);
+         if (k < full) overflow = true;
+         pos += full;
+      }
+      else {
+         // shift-merge, 8 source bytes per step
+         uint64_t i = 0;
+         const uint32_t sh = nacc;
+         uint64_t carry = acc;
+         if (pos + full + 8 <= cap) {
+            for (; i + 8 <= full; i += 8) {
+               uint64_t v;
+               memcpy(&v, src + i, 8);
+               uint64_t o = carry | (v << sh);
+               memcpy(out + pos, &o, 8);
+               pos += 8;
+               carry = v >> (64 - sh);
+            }
+         }
+         acc = (uint32_t)carry;
+         for (; i < full; i++) bits(src[i], 8);
+      }
+      if (nbits & 7) bits(src[full] & ((1u << (nbits & 7)) - 1), (uint32_t)(nbits & 7));
+   }
+};
+}   // namespace
+
+extern "C" size_t zultra_hip_stitch(zultra_hip_bitstate_t *state, const zultra_hip_subblock_t *subs, uint32_t nsubs,
+                                    const uint8_t *payload, const uint8_t *raw, const uint64_t *raw_off, uint32_t max_block_size,
+                                    int final_block, uint8_t *out, size_t out_cap) {
+   Sink s{out, out_cap, 0, state->acc, state->nacc, false};
+   // capacity of the reference's per-max-block output buffer (libzultra.c:115): exceeding it is ZULTRA_ERROR_DST
+   const size_t blockbuf_cap = 1 + (size_t)max_block_size + 5 * ((size_t)max_block_size / 65535 + 1);
+   size_t block_base = 0;
+   uint32_t cur_block = 0xFFFFFFFFu;
+
+   for (uint32_t k = 0; k < nsubs; k++) {
+      const zultra_hip_subblock_t &sb = subs[k];
+      if (sb.block != cur_block) {
+         cur_block = sb.block;
+         block_base = s.pos;   // bitwriter offset restarts at 0 for every max-block, pending bits carry (:427-434)
+      }
+      const bool last_of_block = (k + 1 == nsubs) || (subs[k + 1].block != sb.block);
+      const uint32_t is_final = ((int)sb.block == final_block && last_of_block) ? 1u : 0u;   // :328
+
+      // where the three header bits leave the reference's writer (:329-337)
+      const uint32_t c0 = (s.nacc + 3) & 7;
+      const size_t o0 = (s.pos - block_base) + ((s.nacc + 3) >> 3);
+      if (o0 > blockbuf_cap) return (size_t)-1;
+      const uint64_t body_bytes = ((uint64_t)c0 + sb.nbits) >> 3;
+
+      if (!sb.failed && body_bytes <= sb.size && o0 + body_bytes <= blockbuf_cap) {   // :345-347
+         s.bits(is_final, 1);
+         s.bits(1 + sb.is_dynamic, 2);
+         s.append(payload + sb.bits_off, sb.nbits);
+      }
+      else {
+         // stored, pieces of at most 65535 bytes (:350-397)
+         const uint8_t *src = raw + raw_off[sb.block] + sb.start;
+         uint32_t rem = sb.size;
+         while (rem) {
+            const uint32_t piece = rem > 65535 ? 65535 : rem;
+            s.bits((rem > 65535) ? 0 : is_final, 1);
+            s.bits(0, 2);
+            s.pad();
+            if ((s.pos - block_base) + 4 + piece > blockbuf_cap) return (size_t)-1;   // :382
+            s.byte((uint8_t)(piece & 0xff));
+            s.byte((uint8_t)(piece >> 8));
+            s.byte((uint8_t)((piece & 0xff) ^ 0xff));
+            s.byte((uint8_t)((piece >> 8) ^ 0xff));
+            if (s.pos + piece <= s.cap)
+               memcpy(s.out + s.pos, src, piece);
+            else
+               s.overflow = true;
+            s.pos += piece;
+            src += piece;
+            rem -= piece;
+         }
+      }
+   }
+   state->acc = s.acc;
+   state->nacc = s.nacc;
+   return s.overflow ? (size_t)-1 : s.pos;
+}
+
+extern "C" size_t zultra_hip_stitch_finish(zultra_hip_bitstate_t *state, uint8_t *out, size_t out_cap) {
+   if (!state->nacc) return 0;
+   if (out_cap < 1) return (size_t)-1;
+   out[0] = (uint8_t)(state->acc & ((1u << state->nacc) - 1));   // libzultra.c:414-417
+   state->acc = 0;
+   state->nacc = 0;
+   return 1;
+}
+
+// ================================================================================================================
+// Streaming API (reference src/libzultra.c:82-565)
+// ================================================================================================================
+
+enum {
+   ST_HAS_DICTIONARY = 1,
+   ST_HEADER_EMITTED = 2,
+   ST_FINALIZED = 4,
+   ST_FOOTER_EMITTED = 8,
+   ST_STREAM_ENDED = 16,
+};
+
+static int g_device = -1;
+static std::mutex g_ctx_mutex;
+struct CachedCtx {
+   zultra_hip_ctx_t *ctx;
+   int device;
+   uint32_t max_block, max_blocks;
+};
+static std::vector<CachedCtx> g_ctx_pool;   // contexts released by finished streams, reused by later ones
+
+static int zh_pick_device() {
+   if (g_device >= 0) return g_device;
+   const char *e = getenv("ZULTRA_HIP_DEVICE");
+   return e ? atoi(e) : 0;
+}
+
+extern "C" void zultra_set_device(int nDevice) { g_device = nDevice; }
+
+static uint32_t clamp_block(uint32_t n) {
+   if (!n) n = ZULTRA_DEFAULT_MAX_BLOCK_SIZE;
+   if (n < 32768) n = 32768;
+   if (n > 2097152) n = 2097152;
+   return n;
+}
+
+// device bytes one max-block of a batch costs (see the layout comment in zh_device.hip)
+static uint64_t per_block_device_bytes(uint32_t bs) { return (uint64_t)bs * 56 + 400000; }
+
+static zultra_hip_ctx_t *ctx_acquire(uint32_t bs, uint32_t want_blocks) {
+   const int dev = zh_pick_device();
+   std::lock_guard<std::mutex> lk(g_ctx_mutex);
+   for (size_t i = 0; i < g_ctx_pool.size(); i++) {
+      if (g_ctx_pool[i].device == dev && g_ctx_pool[i].max_block == bs && g_ctx_pool[i].max_blocks >= want_blocks) {
+         zultra_hip_ctx_t *c = g_ctx_pool[i].ctx;
+         g_ctx_pool.erase(g_ctx_pool.begin() + (long)i);
+         return c;
+      }
+   }
+   // a smaller cached context of the same geometry would only waste memory next to the new one
+   for (size_t i = 0; i < g_ctx_pool.size();) {
+      if (g_ctx_pool[i].device == dev && g_ctx_pool[i].max_block == bs) {
+         zultra_hip_destroy(g_ctx_pool[i].ctx);
+         g_ctx_pool.erase(g_ctx_pool.begin() + (long)i);
+      }
+      else
+         i++;
+   }
+   return zultra_hip_create(dev, bs, want_blocks);
+}
+
+static void ctx_release(zultra_hip_ctx_t *c, uint32_t bs, uint32_t blocks) {
+   if (!c) return;
+   std::lock_guard<std::mutex> lk(g_ctx_mutex);
+   if (g_ctx_pool.size() >= 2) {
+      zultra_hip_destroy(g_ctx_pool[0].ctx);
+      g_ctx_pool.erase(g_ctx_pool.begin());
+   }
+   g_ctx_pool.push_back(CachedCtx{c, zh_pick_device(), bs, blocks});
+}
+
+struct _zultra_compressor_s {
+   unsigned flags;
+   uint32_t max_block;
+   uint32_t batch_blocks;       // max-blocks per device batch
+   const void *dict;
+   int dict_size;
+   unsigned state;
+
+   zultra_hip_ctx_t *hip;
+   zultra_hip_bitstate_t bitstate;
+
+   uint8_t *in;                 // [32 KiB history][batch_blocks * max_block]
+   size_t in_bytes;             // input bytes staged after the history area
+   int prev;                    // valid history bytes (end-aligned in the history area)
+
+   uint8_t *out;                // stitched bytes of the last batch
+   size_t out_cap, out_pos, out_pending;
+
+   unsigned char frame[16];
+   size_t frame_pos, frame_pending;
+
+   std::vector<zultra_hip_block_t> blocks;
+   std::vector<uint64_t> raw_off;
+};
+
+static void *default_zalloc(void *, unsigned int items, unsigned int size) { return malloc((size_t)items * size); }
+static void default_zfree(void *, void *p) { free(p); }
+
+static zultra_status_t stream_init_sized(zultra_stream_t *s, unsigned flags, unsigned bs_in, uint32_t batch_blocks) {
+   const uint32_t bs = clamp_block(bs_in);
+   if (!s->zalloc) s->zalloc = default_zalloc;
+   if (!s->zfree) s->zfree = default_zfree;
+   s->adler = 0;
+   s->state = NULL;
+
+   zultra_compressor_t *c = (zultra_compressor_t *)s->zalloc(s->opaque, 1, (unsigned)sizeof(zultra_compressor_t));
+   if (!c) return ZULTRA_ERROR_MEMORY;
+   new (c) zultra_compressor_t();
+   s->state = c;
+   c->flags = flags;
+   c->max_block = bs;
+   c->dict = NULL;
+   c->dict_size = 0;
+   c->state = 0;
+   c->bitstate.acc = c->bitstate.nacc = 0;
+   c->in_bytes = 0;
+   c->prev = 0;
+   c->out_pos = c->out_pending = 0;
+   c->frame_pos = c->frame_pending = 0;
+   c->in = c->out = NULL;
+
+   if (!batch_blocks) {
+      const char *e = getenv("ZULTRA_HIP_BATCH_BLOCKS");
+      batch_blocks = e ? (uint32_t)atoi(e) : (uint32_t)((64u << 20) / bs);
+      if (batch_blocks < 2) batch_blocks = 2;
+   }
+   const uint64_t budget = 24ull << 30;   // device bytes per context; MI355X has 288 GB
+   if ((uint64_t)batch_blocks * per_block_device_bytes(bs) > budget) batch_blocks = (uint32_t)(budget / per_block_device_bytes(bs));
+   if (batch_blocks < 1) batch_blocks = 1;
+   c->batch_blocks = batch_blocks;
+
+   c->hip = ctx_acquire(bs, batch_blocks);
+   if (!c->hip) {
+      zultra_stream_end(s);
+      return ZULTRA_ERROR_MEMORY;   // no usable HIP device / device memory: there is no CPU path
+   }
+   const size_t in_size = (size_t)HISTORY_SIZE + (size_t)batch_blocks * bs;
+   // worst case per max-block: all sub-blocks stored (libzultra.c:576-587)
+   c->out_cap = (size_t)batch_blocks * ((size_t)bs + 6 * 64 + 16) + 16;
+   c->in = (uint8_t *)malloc(in_size);
+   c->out = (uint8_t *)malloc(c->out_cap);
+   if (!c->in || !c->out) {
+      zultra_stream_end(s);
+      return ZULTRA_ERROR_MEMORY;
+   }
+   return ZULTRA_OK;
+}
+
+extern "C" zultra_status_t zultra_stream_init(zultra_stream_t *s, const unsigned int nFlags, unsigned int nMaxBlockSize) {
+   return stream_init_sized(s, nFlags, nMaxBlockSize, 0);
+}
+
+extern "C" zultra_status_t zultra_stream_set_dictionary(zultra_stream_t *s, const void *pDict, const int nDictSize) {
+   zultra_compressor_t *c = s->state;
+   if (c && c->state == 0) {   // only before the first compress call (libzultra.c:180)
+      c->dict = pDict;
+      c->dict_size = nDictSize;
+      c->state |= ST_HAS_DICTIONARY;
+      return ZULTRA_OK;
+   }
+   return ZULTRA_ERROR_COMPRESSION;
+}
+
+extern "C" void zultra_stream_end(zultra_stream_t *s) {
+   if (s->state && s->zfree) {
+      zultra_compressor_t *c = s->state;
+      ctx_release(c->hip, c->max_block, c->batch_blocks);
+      free(c->in);
+      free(c->out);
+      c->~zultra_compressor_t();
+      s->zfree(s->opaque, c);
+      s->state = NULL;
+   }
+}
+
+static void drain_frame(zultra_stream_t *s, zultra_compressor_t *c) {
+   if (c->frame_pending && s->avail_out) {
+      size_t k = s->avail_out < c->frame_pending ? s->avail_out : c->frame_pending;
+      memcpy(s->next_out, c->frame + c->frame_pos, k);
+      c->frame_pos += k;
+      c->frame_pending -= k;
+      s->next_out += k;
+      s->avail_out -= k;
+      s->total_out += k;
+   }
+}
+
+// Compress `count` max-blocks staged at c->in + HISTORY (the last one `last_n` bytes long).
+static zultra_status_t compress_staged(zultra_stream_t *s, zultra_compressor_t *c, uint32_t count, uint32_t last_n, bool final_last) {
+   const uint32_t bs = c->max_block;
+   c->blocks.resize(count);
+   c->raw_off.resize(count);
+   const uint64_t base = (uint64_t)HISTORY_SIZE - (uint64_t)c->prev;   // window of block 0 starts here
+   size_t consumed = 0;
+   for (uint32_t b = 0; b < count; b++) {
+      const uint32_t n = (b + 1 == count) ? last_n : bs;
+      const uint32_t prev = (b == 0) ? (uint32_t)c->prev : (uint32_t)HISTORY_SIZE;   // blocks are >= 32 KiB unless last
+      c->blocks[b].win_off = (uint64_t)HISTORY_SIZE + (uint64_t)b * bs - prev - base;
+      c->blocks[b].prev = prev;
+      c->blocks[b].n = n;
+      c->raw_off[b] = (uint64_t)b * bs;
+      // checksum once per max-block over its bytes (libzultra.c:279)
+      s->adler = zultra_frame_update_checksum(s->adler, c->in + HISTORY_SIZE + (size_t)b * bs, n, c->flags);
+      consumed += n;
+   }
+   const size_t data_size = (size_t)c->prev + consumed;
+   int nsubs = zultra_hip_compress_blocks(c->hip, c->in + base, data_size, 0, c->blocks.data(), count);
+   if (nsubs <= 0) return ZULTRA_ERROR_COMPRESSION;
+
+   uint32_t cnt = 0;
+   const zultra_hip_subblock_t *subs = zultra_hip_subblocks(c->hip, &cnt);
+   size_t psize = 0;
+   const uint8_t *payload = zultra_hip_payload(c->hip, &psize);
+   size_t w = zultra_hip_stitch(&c->bitstate, subs, cnt, payload, c->in + HISTORY_SIZE, c->raw_off.data(), bs,
+                                final_last ? (int)count - 1 : -1, c->out, c->out_cap);
+   if (w == (size_t)-1) return ZULTRA_ERROR_DST;
+   if (final_last) {
+      size_t f = zultra_hip_stitch_finish(&c->bitstate, c->out + w, c->out_cap - w);
+      if (f == (size_t)-1) return ZULTRA_ERROR_DST;
+      w += f;
+      c->state |= ST_FINALIZED;
+   }
+   c->out_pos = 0;
+   c->out_pending = w;
+
+   // slide: the last <= 32 KiB just compressed become the history of what follows (libzultra.c:406-412)
+   size_t keep = consumed < (size_t)HISTORY_SIZE ? consumed : (size_t)HISTORY_SIZE;
+   if (consumed < (size_t)HISTORY_SIZE) {
+      // (only possible for a last, short block; kept for symmetry) old history stays in front
+      size_t old = (size_t)c->prev;
+      if (old + consumed > (size_t)HISTORY_SIZE) old = (size_t)HISTORY_SIZE - consumed;
+      memmove(c->in + HISTORY_SIZE - keep - old, c->in + HISTORY_SIZE - old, old);
+      memmove(c->in + HISTORY_SIZE - keep, c->in + HISTORY_SIZE, keep);
+      c->prev = (int)(old + keep);
+   }
+   else {
+      memmove(c->in, c->in + HISTORY_SIZE + consumed - HISTORY_SIZE, HISTORY_SIZE);
+      c->prev = HISTORY_SIZE;
+   }
+   const size_t left = c->in_bytes - consumed;
+   if (left) memmove(c->in + HISTORY_SIZE, c->in + HISTORY_SIZE + consumed, left);
+   c->in_bytes = left;
+   c->dict_size = 0;
+   return ZULTRA_OK;
+}
+
+extern "C" zultra_status_t zultra_stream_compress(zultra_stream_t *s, const int nDoFinalize) {
+   zultra_compressor_t *c = s->state;
+   zultra_status_t err = ZULTRA_OK;
+   if (!c) return ZULTRA_ERROR_COMPRESSION;
+   if (c->state & ST_STREAM_ENDED) return ZULTRA_ERROR_COMPRESSION;
+   const uint32_t bs = c->max_block;
+
+   do {
+      if (!(c->state & ST_HEADER_EMITTED)) {
+         c->state |= ST_HEADER_EMITTED;
+         int h = zultra_frame_encode_header(c->frame, 16, c->flags, c->dict, c->dict_size);
+         if (h < 0)
+            err = ZULTRA_ERROR_COMPRESSION;
+         else {
+            c->frame_pos = 0;
+            c->frame_pending = (size_t)h;
+         }
+         s->adler = zultra_frame_init_checksum(c->flags);
+      }
+      if (!err) drain_frame(s, c);
+
+      if (!err && !c->prev && c->dict_size && c->dict && c->in_bytes == 0) {
+         // preset dictionary = pre-filled history of the first max-block (libzultra.c:250-253)
+         int d = c->dict_size > HISTORY_SIZE ? HISTORY_SIZE : c->dict_size;
+         memcpy(c->in + HISTORY_SIZE - d, (const uint8_t *)c->dict + (c->dict_size - d), (size_t)d);
+         c->prev = d;
+      }
+
+      if (!err && !c->frame_pending && !c->out_pending) {
+         const size_t cap = (size_t)c->batch_blocks * bs;
+         size_t take = s->avail_in;
+         if (take > cap - c->in_bytes) take = cap - c->in_bytes;
+         memcpy(c->in + HISTORY_SIZE + c->in_bytes, s->next_in, take);
+         s->next_in += take;
+         s->avail_in -= take;
+         s->total_in += take;
+         c->in_bytes += take;
+
+         // which staged max-blocks may be compressed now (libzultra.c:269): a full block needs more input behind
+         // it, or ZULTRA_FINALIZE; a partial block needs ZULTRA_FINALIZE
+         const uint32_t full = (uint32_t)(c->in_bytes / bs);
+         const uint32_t rem = (uint32_t)(c->in_bytes % bs);
+         uint32_t count = 0, last_n = bs;
+         bool final_last = false;
+         if (nDoFinalize) {
+            count = full + (rem ? 1 : 0);
+            if (rem) last_n = rem;
+            final_last = (s->avail_in == 0);
+         }
+         else if (full) {
+            count = (rem || s->avail_in) ? full : full - 1;
+         }
+         if (count) err = compress_staged(s, c, count, last_n, final_last && count > 0);
+      }
+
+      if (!err && !c->frame_pending && c->out_pending && s->avail_out) {
+         size_t k = s->avail_out < c->out_pending ? s->avail_out : c->out_pending;
+         memcpy(s->next_out, c->out + c->out_pos, k);
+         c->out_pos += k;
+         c->out_pending -= k;
+         s->next_out += k;
+         s->avail_out -= k;
+         s->total_out += k;
+      }
+
+      if (!err && !c->frame_pending && !c->out_pending && (c->state & ST_FINALIZED) && !(c->state & ST_FOOTER_EMITTED)) {
+         int f = zultra_frame_encode_footer(c->frame, 16, s->adler, (long long)s->total_in, c->flags);
+         if (f < 0)
+            err = ZULTRA_ERROR_COMPRESSION;
+         else {
+            c->state = (c->state | ST_FOOTER_EMITTED) & ~(unsigned)ST_FINALIZED;
+            c->frame_pos = 0;
+            c->frame_pending = (size_t)f;
+         }
+      }
+      if (!err) drain_frame(s, c);
+   } while (!err && s->avail_in && s->avail_out);
+
+   if (err) return err;
+   if ((c->state & ST_FOOTER_EMITTED) && !(c->state & ST_STREAM_ENDED) && !c->frame_pending) {
+      c->state |= ST_STREAM_ENDED;
+      return ZULTRA_STREAM_END;
+   }
+   return ZULTRA_OK;
+}
+
+// ================================================================================================================
+// In-memory API (reference src/libzultra.c:576-619)
+// ================================================================================================================
+
+extern "C" size_t zultra_memory_bound(size_t nInputSize, const unsigned int nFlags, unsigned int nMaxBlockSize) {
+   const size_t bs = clamp_block(nMaxBlockSize);
+   return (size_t)zultra_frame_get_header_size(nFlags, NULL, 0) + ((nInputSize + (bs - 1)) / bs) * (1 + 4 + 1) * 64 + nInputSize + 1 +
+          (size_t)zultra_frame_get_footer_size(nFlags);
+}
+
+extern "C" size_t zultra_memory_compress_dict(const unsigned char *pIn, size_t nIn, unsigned char *pOut, size_t nOutCap,
+                                              const unsigned int nFlags, unsigned int nMaxBlockSize, const void *pDict, int nDictSize) {
+   zultra_stream_t strm;
+   memset(&strm, 0, sizeof(strm));
+   const uint32_t bs = clamp_block(nMaxBlockSize);
+   // the whole input is at hand: size the device batch to it
+   uint64_t want = (nIn + bs - 1) / bs;
+   if (want < 1) want = 1;
+   if (want > 8192) want = 8192;
+   if (stream_init_sized(&strm, nFlags, nMaxBlockSize, (uint32_t)want) != ZULTRA_OK) return (size_t)-1;
+   if (pDict && nDictSize > 0 && zultra_stream_set_dictionary(&strm, pDict, nDictSize) != ZULTRA_OK) {
+      zultra_stream_end(&strm);
+      return (size_t)-1;
+   }
+   strm.next_in = pIn;
+   strm.avail_in = nIn;
+   strm.next_out = pOut;
+   strm.avail_out = nOutCap;
+   zultra_status_t st = zultra_stream_compress(&strm, ZULTRA_FINALIZE);
+   zultra_stream_end(&strm);
+   if (st != ZULTRA_STREAM_END) return (size_t)-1;
+   return nOutCap - strm.avail_out;
+}
+
+extern "C" size_t zultra_memory_compress(const unsigned char *pIn, size_t nIn, unsigned char *pOut, size_t nOutCap,
+                                         const unsigned int nFlags, unsigned int nMaxBlockSize) {
+   return zultra_memory_compress_dict(pIn, nIn, pOut, nOutCap, nFlags, nMaxBlockSize, NULL, 0);
+}

@@ -1,0 +1,291 @@
+// zh_device.hip — host side of the device layer: context, HBM layout, launches (C ABI of include/zultra_hip.h).
+//
+// HBM layout of one context (B = max_blocks, N = max_block_size, W = N + 32768):
+//   d_data     W + (B-1)*N      input bytes when the caller hands over host memory (read in place otherwise)
+//   d_blocks   B * 16           max-block descriptors
+//   d_sort_a/b B * W * 4  each  trigram-sorted window positions (ping-pong of the 3-pass radix sort)
+//   d_match    B * N * 32       match rows, 8 x {u16 length, u16 offset} per block position
+//   d_tok_pos  B * N * 4        greedy token chain: position / packed symbols
+//   d_tok_info B * N * 2
+//   d_best     B * N * 4        final parse per position
+//   d_payload  B * (N + 4224)   per-sub-block bit strings (slot of sub-block k of a block starts at its offset + 64k)
+//   small: ntok, split boundaries, counts, work items, results
+#include <zh_platform.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/zultra_hip.h"
+#include "zh_common.h"
+#include "zh_encode.h"
+#include "zh_huffman.h"
+#include "zh_matchfinder.h"
+#include "zh_split.h"
+
+static_assert(sizeof(zultra_hip_block_t) == sizeof(zh_block_t), "ABI");
+static_assert(sizeof(zultra_hip_subblock_t) == sizeof(zh_subblock_t), "ABI");
+
+struct zultra_hip_ctx_s {
+   int device;
+   uint32_t max_block, max_blocks;
+   uint64_t W, sort_stride, match_stride, tok_stride, best_stride, slot_stride;
+   size_t data_cap;
+   hipStream_t stream;
+   hipEvent_t ev[8];
+
+   uint8_t *d_data;
+   zh_block_t *d_blocks;
+   uint32_t *d_sort_a, *d_sort_b;
+   zh_match_t *d_match;
+   uint32_t *d_tok_pos;
+   uint16_t *d_tok_info;
+   uint32_t *d_ntok, *d_split_tok, *d_split_cnt, *d_sub_base;
+   uint32_t *d_best;
+   zh_work_t *d_work;
+   zh_subblock_t *d_results;
+   uint8_t *d_payload;
+
+   // host mirrors of the last batch
+   std::vector<zh_block_t> blocks;
+   std::vector<uint32_t> split_cnt, sub_base;
+   std::vector<zh_subblock_t> results;
+   uint8_t *h_payload;   // pinned
+   size_t payload_size;
+   const uint8_t *cur_data;   // device pointer the kernels read
+   uint32_t nblocks, nsubs;
+   zultra_hip_timing_t timing;
+   char err[256];
+};
+
+#define ZH_CHECK(ctx, call)                                                                              \
+   do {                                                                                                  \
+      hipError_t e_ = (call);                                                                            \
+      if (e_ != hipSuccess) {                                                                            \
+         snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                                   \
+         return -1;                                                                                      \
+      }                                                                                                  \
+   } while (0)
+
+static uint32_t zh_clamp_block(uint32_t n) {
+   if (!n) n = 1048576;   // libzultra.c:87-92
+   if (n < ZH_MIN_BLOCK) n = ZH_MIN_BLOCK;
+   if (n > ZH_MAX_BLOCK) n = ZH_MAX_BLOCK;
+   return n;
+}
+
+extern "C" int zultra_hip_device_count(void) {
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+   return n;
+}
+
+template <typename T>
+static int zh_alloc(zultra_hip_ctx_t *c, T **p, size_t count) {
+   ZH_CHECK(c, hipMalloc((void **)p, count * sizeof(T)));
+   return 0;
+}
+
+extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
+   if (!c) return;
+   hipSetDevice(c->device);
+   hipFree(c->d_data);
+   hipFree(c->d_blocks);
+   hipFree(c->d_sort_a);
+   hipFree(c->d_sort_b);
+   hipFree(c->d_match);
+   hipFree(c->d_tok_pos);
+   hipFree(c->d_tok_info);
+   hipFree(c->d_ntok);
+   hipFree(c->d_split_tok);
+   hipFree(c->d_split_cnt);
+   hipFree(c->d_sub_base);
+   hipFree(c->d_best);
+   hipFree(c->d_work);
+   hipFree(c->d_results);
+   hipFree(c->d_payload);
+   if (c->h_payload) hipHostFree(c->h_payload);
+   for (int i = 0; i < 8; i++)
+      if (c->ev[i]) hipEventDestroy(c->ev[i]);
+   if (c->stream) hipStreamDestroy(c->stream);
+   delete c;
+}
+
+static int zh_create_buffers(zultra_hip_ctx_t *c) {
+   const uint64_t B = c->max_blocks, N = c->max_block;
+   ZH_CHECK(c, hipSetDevice(c->device));
+   ZH_CHECK(c, hipStreamCreate(&c->stream));
+   for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->ev[i]));
+   if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->sort_stride) ||
+       zh_alloc(c, &c->d_sort_b, B * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
+       zh_alloc(c, &c->d_tok_pos, B * c->tok_stride) || zh_alloc(c, &c->d_tok_info, B * c->tok_stride) ||
+       zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_split_tok, B * (ZH_MAX_SPLITS + 1)) || zh_alloc(c, &c->d_split_cnt, B) ||
+       zh_alloc(c, &c->d_sub_base, B) || zh_alloc(c, &c->d_best, B * c->best_stride) || zh_alloc(c, &c->d_work, B * ZH_MAX_SPLITS) ||
+       zh_alloc(c, &c->d_results, B * ZH_MAX_SPLITS) || zh_alloc(c, &c->d_payload, B * c->slot_stride))
+      return -1;
+   ZH_CHECK(c, hipHostMalloc((void **)&c->h_payload, B * c->slot_stride, 0));
+   (void)N;
+   return 0;
+}
+
+extern "C" zultra_hip_ctx_t *zultra_hip_create(int device, uint32_t max_block_size, uint32_t max_blocks) {
+   int ndev = zultra_hip_device_count();
+   if (ndev <= 0 || device < 0 || device >= ndev || max_blocks == 0) return NULL;
+   zultra_hip_ctx_t *c = new zultra_hip_ctx_s();
+   memset((void *)&c->timing, 0, sizeof(c->timing));
+   c->device = device;
+   c->max_block = zh_clamp_block(max_block_size);
+   c->max_blocks = max_blocks;
+   c->W = (uint64_t)c->max_block + ZH_HISTORY;
+   c->sort_stride = (c->W + 63) & ~63ull;
+   c->match_stride = (uint64_t)c->max_block * ZH_NMATCH;
+   c->tok_stride = ((uint64_t)c->max_block + 63) & ~63ull;
+   c->best_stride = c->tok_stride;
+   c->slot_stride = (((uint64_t)c->max_block + 64 * ZH_MAX_SPLITS + 64) + 63) & ~63ull;
+   c->data_cap = (size_t)c->W + (size_t)(max_blocks - 1) * c->max_block;
+   c->err[0] = 0;
+   if (zh_create_buffers(c) != 0) {
+      fprintf(stderr, "zultra_hip_create: %s\n", c->err);
+      zultra_hip_destroy(c);
+      return NULL;
+   }
+   return c;
+}
+
+extern "C" const char *zultra_hip_last_error(const zultra_hip_ctx_t *c) { return c ? c->err : "no context"; }
+extern "C" size_t zultra_hip_data_capacity(const zultra_hip_ctx_t *c) { return c ? c->data_cap : 0; }
+
+extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data, size_t data_size, int data_on_device,
+                                          const zultra_hip_block_t *blocks, uint32_t nblocks) {
+   if (!c || !data || !blocks || nblocks == 0 || nblocks > c->max_blocks) {
+      if (c) snprintf(c->err, sizeof(c->err), "bad arguments");
+      return -1;
+   }
+   for (uint32_t b = 0; b < nblocks; b++) {
+      if (blocks[b].n == 0 || blocks[b].n > c->max_block || blocks[b].prev > ZH_HISTORY ||
+          blocks[b].win_off + blocks[b].prev + blocks[b].n > data_size) {
+         snprintf(c->err, sizeof(c->err), "block %u out of range", b);
+         return -1;
+      }
+   }
+   if (!data_on_device && data_size > c->data_cap) {
+      snprintf(c->err, sizeof(c->err), "batch of %zu bytes exceeds the context's staging capacity %zu", data_size, c->data_cap);
+      return -1;
+   }
+   ZH_CHECK(c, hipSetDevice(c->device));
+   hipStream_t st = c->stream;
+   c->nblocks = nblocks;
+   c->nsubs = 0;
+   c->blocks.assign((const zh_block_t *)blocks, (const zh_block_t *)blocks + nblocks);
+
+   ZH_CHECK(c, hipEventRecord(c->ev[0], st));
+   if (data_on_device)
+      c->cur_data = (const uint8_t *)data;
+   else {
+      ZH_CHECK(c, hipMemcpyAsync(c->d_data, data, data_size, hipMemcpyHostToDevice, st));
+      c->cur_data = c->d_data;
+   }
+   ZH_CHECK(c, hipMemcpyAsync(c->d_blocks, blocks, nblocks * sizeof(zh_block_t), hipMemcpyHostToDevice, st));
+   ZH_CHECK(c, hipEventRecord(c->ev[1], st));
+
+   // stage 1: match rows
+   ZH_LAUNCH(zh_mf_group, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, c->d_sort_a, c->d_sort_b,
+             c->sort_stride);
+   ZH_CHECK(c, hipEventRecord(c->ev[6], st));
+   ZH_LAUNCH(zh_mf_frontier, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const uint32_t *)c->d_sort_a,
+             c->sort_stride, c->d_match, c->match_stride);
+   ZH_CHECK(c, hipEventRecord(c->ev[2], st));
+
+   // stage 2: greedy token chain + splitter
+   ZH_LAUNCH(zh_tokenize, nblocks, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const zh_match_t *)c->d_match, c->match_stride,
+             c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok);
+   ZH_LAUNCH(zh_split, nblocks, 64, st, (const zh_block_t *)c->d_blocks, (const uint32_t *)c->d_tok_pos, (const uint16_t *)c->d_tok_info,
+             c->tok_stride, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt);
+   c->split_cnt.resize(nblocks);
+   c->sub_base.resize(nblocks);
+   ZH_CHECK(c, hipMemcpyAsync(c->split_cnt.data(), c->d_split_cnt, nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+   ZH_CHECK(c, hipEventRecord(c->ev[3], st));
+   ZH_CHECK(c, hipStreamSynchronize(st));
+   uint32_t nsubs = 0;
+   for (uint32_t b = 0; b < nblocks; b++) {
+      c->sub_base[b] = nsubs;
+      nsubs += c->split_cnt[b];
+   }
+   ZH_CHECK(c, hipMemcpyAsync(c->d_sub_base, c->sub_base.data(), nblocks * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+
+   // stage 3: one wave per sub-block
+   ZH_LAUNCH(zh_plan_subblocks, (nblocks + 63) / 64, 64, st, (const zh_block_t *)c->d_blocks, nblocks, (const uint32_t *)c->d_tok_pos,
+             c->tok_stride, (const uint32_t *)c->d_ntok, (const uint32_t *)c->d_split_tok, (const uint32_t *)c->d_split_cnt,
+             (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work);
+   ZH_LAUNCH(zh_encode, nsubs, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const zh_match_t *)c->d_match, c->match_stride,
+             (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_best, c->best_stride, c->d_payload,
+             c->d_results);
+   ZH_CHECK(c, hipEventRecord(c->ev[4], st));
+
+   c->results.resize(nsubs);
+   c->payload_size = (size_t)nblocks * c->slot_stride;
+   ZH_CHECK(c, hipMemcpyAsync(c->results.data(), c->d_results, nsubs * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
+   ZH_CHECK(c, hipMemcpyAsync(c->h_payload, c->d_payload, c->payload_size, hipMemcpyDeviceToHost, st));
+   ZH_CHECK(c, hipEventRecord(c->ev[5], st));
+   ZH_CHECK(c, hipStreamSynchronize(st));
+   ZH_CHECK(c, hipGetLastError());
+   c->nsubs = nsubs;
+
+   hipEventElapsedTime(&c->timing.h2d_ms, c->ev[0], c->ev[1]);
+   hipEventElapsedTime(&c->timing.matchfinder_ms, c->ev[1], c->ev[2]);
+   hipEventElapsedTime(&c->timing.group_ms, c->ev[1], c->ev[6]);
+   hipEventElapsedTime(&c->timing.frontier_ms, c->ev[6], c->ev[2]);
+   hipEventElapsedTime(&c->timing.tokenize_split_ms, c->ev[2], c->ev[3]);
+   hipEventElapsedTime(&c->timing.encode_ms, c->ev[3], c->ev[4]);
+   hipEventElapsedTime(&c->timing.d2h_ms, c->ev[4], c->ev[5]);
+   hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[5]);
+   return (int)nsubs;
+}
+
+extern "C" const zultra_hip_subblock_t *zultra_hip_subblocks(const zultra_hip_ctx_t *c, uint32_t *count) {
+   if (!c) return NULL;
+   if (count) *count = c->nsubs;
+   return (const zultra_hip_subblock_t *)c->results.data();
+}
+extern "C" const uint8_t *zultra_hip_payload(const zultra_hip_ctx_t *c, size_t *size) {
+   if (!c) return NULL;
+   if (size) *size = c->payload_size;
+   return c->h_payload;
+}
+extern "C" void zultra_hip_last_timing(const zultra_hip_ctx_t *c, zultra_hip_timing_t *t) {
+   if (c && t) *t = c->timing;
+}
+
+extern "C" int zultra_hip_get_matches(zultra_hip_ctx_t *c, uint32_t block, uint16_t *out) {
+   if (!c || block >= c->nblocks) return -1;
+   ZH_CHECK(c, hipSetDevice(c->device));
+   ZH_CHECK(c, hipMemcpy(out, c->d_match + (uint64_t)block * c->match_stride, (size_t)c->blocks[block].n * ZH_NMATCH * sizeof(zh_match_t),
+                         hipMemcpyDeviceToHost));
+   return 0;
+}
+
+extern "C" int zultra_hip_get_splits(zultra_hip_ctx_t *c, uint32_t block, int *out) {
+   if (!c || block >= c->nblocks) return -1;
+   ZH_CHECK(c, hipSetDevice(c->device));
+   uint32_t st[ZH_MAX_SPLITS + 1], nt = 0;
+   const uint32_t cnt = c->split_cnt[block];
+   ZH_CHECK(c, hipMemcpy(st, c->d_split_tok + (uint64_t)block * (ZH_MAX_SPLITS + 1), sizeof(st), hipMemcpyDeviceToHost));
+   ZH_CHECK(c, hipMemcpy(&nt, c->d_ntok + block, sizeof(nt), hipMemcpyDeviceToHost));
+   for (uint32_t k = 0; k < cnt; k++) {
+      uint32_t t1 = st[k + 1], pos = c->blocks[block].prev + c->blocks[block].n;
+      if (t1 < nt) ZH_CHECK(c, hipMemcpy(&pos, c->d_tok_pos + (uint64_t)block * c->tok_stride + t1, sizeof(pos), hipMemcpyDeviceToHost));
+      out[k] = (int)pos;
+   }
+   return (int)cnt;
+}
+
+extern "C" int zultra_hip_get_parse(zultra_hip_ctx_t *c, uint32_t block, uint16_t *out) {
+   if (!c || block >= c->nblocks) return -1;
+   ZH_CHECK(c, hipSetDevice(c->device));
+   ZH_CHECK(c, hipMemcpy(out, c->d_best + (uint64_t)block * c->best_stride, (size_t)c->blocks[block].n * sizeof(uint32_t),
+                         hipMemcpyDeviceToHost));
+   return 0;
+}

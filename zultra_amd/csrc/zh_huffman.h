@@ -1,0 +1,406 @@
+// zh_huffman.h — entropy-coding primitives of the hot path as device code (one wave = one alphabet owner).
+//
+// Replaces reference src/huffman/huffencoder.c (code lengths :157-270, length limit + canonical codes
+// :279-375, code-length RLE :446-735, table trimming :400-406,:532-538) and src/huffman/huffutils.c:34-114.
+// The arrays live in LDS. Two calling conventions:
+//   *_wave   : called by all 64 lanes; sorting is lane-parallel (rank sort), the inherently serial
+//              two-queue merge runs on lane 0;
+//   *_lane   : plain single-lane code on a private LDS slice, for small alphabets (the 19-symbol code-length
+//              alphabet) where several independent instances run in different lanes at once.
+#pragma once
+#include <zh_platform.h>
+#include "zh_common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// Moffat-Katajainen in-place minimum-redundancy code lengths on an ascending weight array
+// (huffencoder.c:198-255). Tie rule: an internal node is preferred only when strictly lighter than the
+// next leaf. Single lane.
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline void zh_mk_depths(int32_t *A, int n) {
+   int leaf = 0, node = 0, t;
+   for (t = 0; t < n - 1; t++) {
+      int w = 0;
+      for (int pick = 0; pick < 2; pick++) {
+         if (leaf >= n || (node < t && A[node] < A[leaf])) {
+            w += A[node];
+            A[node] = t;
+            node++;
+         }
+         else {
+            w += A[leaf];
+            leaf++;
+         }
+      }
+      A[t] = w;
+   }
+   A[n - 2] = 0;
+   for (t = n - 3; t >= 0; t--) A[t] = A[A[t]] + 1;
+   int avail = 1, used = 0, depth = 0, next = n - 1;
+   t = n - 2;
+   while (avail > 0) {
+      while (t >= 0 && A[t] == depth) {
+         used++;
+         t--;
+      }
+      while (avail > used) {
+         A[next--] = depth;
+         avail--;
+      }
+      avail = used << 1;
+      depth++;
+      used = 0;
+   }
+}
+
+// Scratch for the wave-cooperative builders (per wave, LDS)
+struct zh_huff_scratch_t {
+   uint32_t keys[ZH_NLIT];
+   uint32_t sorted[ZH_NLIT];
+   int32_t A[ZH_NLIT];
+   uint32_t count;
+};
+
+// Lane-parallel rank sort of unique 32-bit keys: sorted[rank(k)] = k. All lanes call.
+__device__ inline void zh_rank_sort_wave(const uint32_t *keys, uint32_t *sorted, int n) {
+   const int lane = (int)zh_lane();
+   for (int base = 0; base < n; base += 64) {
+      int e = base + lane;
+      if (e < n) {
+         uint32_t k = keys[e];
+         int rank = 0;
+         for (int j = 0; j < n; j++) rank += (keys[j] < k) ? 1 : 0;
+         sorted[rank] = k;
+      }
+   }
+   zh_sync();
+}
+
+// Collect (value<<9 | symbol) keys of the symbols with value != 0, in symbol order. Returns the count.
+template <typename T>
+__device__ inline int zh_collect_keys_wave(const T *value, int nsym, zh_huff_scratch_t *sc) {
+   const int lane = (int)zh_lane();
+   int n = 0;
+   for (int base = 0; base < nsym; base += 64) {
+      int s = base + lane;
+      uint32_t v = (s < nsym) ? (uint32_t)value[s] : 0;
+      uint64_t m = zh_ballot(v != 0);
+      if (v != 0) sc->keys[n + zh_popc64(m & ((1ull << lane) - 1))] = (v << 9) | (uint32_t)s;
+      n += zh_popc64(m);
+   }
+   zh_sync();
+   return n;
+}
+
+// huffencoder.c:157-270: code lengths without limit. `len` receives nsym entries. All lanes call.
+__device__ inline void zh_huff_lengths_wave(const int32_t *freq, uint8_t *len, int nsym, zh_huff_scratch_t *sc) {
+   const int lane = (int)zh_lane();
+   int n = zh_collect_keys_wave(freq, nsym, sc);
+   for (int s = lane; s < nsym; s += 64) len[s] = 0;
+   zh_sync();
+   if (n <= 1) {
+      if (lane == 0) len[0] = 1;   // huffencoder.c:263-267: symbol 0, whichever symbol was used
+      zh_sync();
+      return;
+   }
+   zh_rank_sort_wave(sc->keys, sc->sorted, n);
+   for (int e = lane; e < n; e += 64) sc->A[e] = (int32_t)(sc->sorted[e] >> 9);
+   zh_sync();
+   if (lane == 0) zh_mk_depths(sc->A, n);
+   zh_sync();
+   for (int e = lane; e < n; e += 64) len[sc->sorted[e] & 511u] = (uint8_t)sc->A[e];
+   zh_sync();
+}
+
+__device__ __forceinline__ uint32_t zh_bitrev16(uint32_t v, int nbits) {
+   v = ((v & 0x5555u) << 1) | ((v & 0xaaaau) >> 1);
+   v = ((v & 0x3333u) << 2) | ((v & 0xccccu) >> 2);
+   v = ((v & 0x0f0fu) << 4) | ((v & 0xf0f0u) >> 4);
+   v = ((v & 0x00ffu) << 8) | ((v & 0xff00u) >> 8);
+   return v >> (16 - nbits);
+}
+
+// huffencoder.c:310-344 on a list of symbols ordered by (length, symbol). Single lane. Returns 0, or -1
+// where the reference would walk past its array (:334; believed unreachable).
+__device__ inline int zh_limit_lengths(uint8_t *len, const uint32_t *order, int n, int maxbits) {
+   const int full = 1 << maxbits;
+   int kraft = 0, i;
+   for (i = n - 1; i >= 0; i--) {
+      int s = (int)(order[i] & 511u);
+      if (len[s] > maxbits) len[s] = (uint8_t)maxbits;
+      kraft += full >> len[s];
+   }
+   for (i = n - 1; kraft > full && i >= 0; i--) {
+      int s = (int)(order[i] & 511u);
+      while (len[s] < maxbits && kraft > full) {
+         len[s]++;
+         kraft -= full >> len[s];
+      }
+   }
+   for (i = 0; kraft < full; i++) {
+      if (i >= n) return -1;
+      int s = (int)(order[i] & 511u);
+      while (kraft + (full >> len[s]) <= full) {
+         kraft += full >> len[s];
+         len[s]--;
+      }
+   }
+   return 0;
+}
+
+// huffencoder.c:348-372: canonical codes along a (length, symbol)-ordered list, stored bit-reversed.
+__device__ inline void zh_assign_codes(const uint8_t *len, uint16_t *code, const uint32_t *order, int n) {
+   uint32_t c = 0;
+   for (int i = 0; i < n; i++) {
+      int s = (int)(order[i] & 511u);
+      code[s] = (uint16_t)zh_bitrev16(c, len[s]);
+      if (i + 1 < n) c = (c + 1) << (len[order[i + 1] & 511u] - len[s]);
+   }
+}
+
+// huffencoder.c:279-375: lengths, limit to maxbits, canonical codes. All lanes call. Returns 0 / -1 (uniform).
+__device__ inline int zh_huff_build_wave(const int32_t *freq, uint8_t *len, uint16_t *code, int nsym, int maxbits,
+                                         zh_huff_scratch_t *sc) {
+   const int lane = (int)zh_lane();
+   zh_huff_lengths_wave(freq, len, nsym, sc);
+   int n = zh_collect_keys_wave(len, nsym, sc);
+   zh_rank_sort_wave(sc->keys, sc->sorted, n);
+   int over = (n > 0 && (int)(sc->sorted[n - 1] >> 9) > maxbits) ? 1 : 0;
+   int rc = 0;
+   if (over) {
+      if (lane == 0) sc->count = (uint32_t)zh_limit_lengths(len, sc->sorted, n, maxbits);
+      zh_sync();
+      rc = (int)sc->count;
+      zh_sync();
+      n = zh_collect_keys_wave(len, nsym, sc);   // huffencoder.c:344: order again after the repair
+      zh_rank_sort_wave(sc->keys, sc->sorted, n);
+   }
+   if (lane == 0 && n > 0) zh_assign_codes(len, code, sc->sorted, n);
+   zh_sync();
+   return rc;
+}
+
+// huffencoder.c:107-148: every symbol has a length (static tables). All lanes call.
+__device__ inline void zh_huff_static_codes_wave(const uint8_t *len, uint16_t *code, int nsym, zh_huff_scratch_t *sc) {
+   const int lane = (int)zh_lane();
+   for (int s = lane; s < nsym; s += 64) sc->keys[s] = ((uint32_t)len[s] << 9) | (uint32_t)s;
+   zh_sync();
+   zh_rank_sort_wave(sc->keys, sc->sorted, nsym);
+   if (lane == 0) zh_assign_codes(len, code, sc->sorted, nsym);
+   zh_sync();
+}
+
+// huffencoder.c:532-538
+__device__ inline int zh_defined_count(const uint8_t *len, int nsym, int min_syms) {
+   int i = nsym;
+   while (i > min_syms && !len[i - 1]) i--;
+   return i;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Code-length alphabet (19 symbols): everything single-lane on a private slice, so that several mask
+// candidates can be evaluated by different lanes at the same time.
+// ---------------------------------------------------------------------------------------------------------
+struct zh_cl_t {
+   int32_t freq[ZH_NCL];
+   uint8_t len[ZH_NCL];
+   uint16_t code[ZH_NCL];
+};
+
+__device__ __forceinline__ int zh_cl_order(int k) {
+   // RFC 1951 §3.2.7 order: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+   const uint64_t lo = 0x0B050A0609070800ull | 0x0000000000000000ull;   // entries 3..10  (0,8,7,9,6,10,5,11)
+   if (k < 3) return 16 + k;
+   if (k < 11) return (int)((lo >> (8 * (k - 3))) & 0xff);
+   const uint64_t hi = 0x0F010E020D030C04ull;                              // entries 11..18 (4,12,3,13,2,14,1,15)
+   return (int)((hi >> (8 * (k - 11))) & 0xff);
+}
+
+// ordered list of (value<<9|sym) for the symbols with value != 0, by insertion sort. Returns count.
+template <typename T>
+__device__ inline int zh_small_sorted_keys(const T *value, int nsym, uint32_t *out) {
+   int n = 0;
+   for (int s = 0; s < nsym; s++) {
+      uint32_t v = (uint32_t)value[s];
+      if (!v) continue;
+      uint32_t k = (v << 9) | (uint32_t)s;
+      int j = n++;
+      while (j > 0 && out[j - 1] > k) {
+         out[j] = out[j - 1];
+         j--;
+      }
+      out[j] = k;
+   }
+   return n;
+}
+
+__device__ inline void zh_cl_lengths_lane(zh_cl_t *h) {
+   uint32_t keys[ZH_NCL];
+   int32_t A[ZH_NCL];
+   int n = zh_small_sorted_keys(h->freq, ZH_NCL, keys);
+   for (int s = 0; s < ZH_NCL; s++) h->len[s] = 0;
+   if (n <= 1) {
+      h->len[0] = 1;
+      return;
+   }
+   for (int i = 0; i < n; i++) A[i] = (int32_t)(keys[i] >> 9);
+   zh_mk_depths(A, n);
+   for (int i = 0; i < n; i++) h->len[keys[i] & 511u] = (uint8_t)A[i];
+}
+
+__device__ inline int zh_cl_build_lane(zh_cl_t *h, int maxbits) {
+   uint32_t keys[ZH_NCL];
+   zh_cl_lengths_lane(h);
+   int n = zh_small_sorted_keys(h->len, ZH_NCL, keys);
+   if (n > 0 && (int)(keys[n - 1] >> 9) > maxbits) {
+      if (zh_limit_lengths(h->len, keys, n, maxbits) < 0) return -1;
+      n = zh_small_sorted_keys(h->len, ZH_NCL, keys);
+   }
+   if (n > 0) zh_assign_codes(h->len, h->code, keys, n);
+   return 0;
+}
+
+// huffencoder.c:400-406
+__device__ inline int zh_cl_raw_table_size(const zh_cl_t *h) {
+   int i = ZH_NCL;
+   while (i > 4 && !h->len[zh_cl_order(i - 1)]) i--;
+   return i;
+}
+
+// One tokenizer for huffencoder.c:446-522 (count), :549-628 (size), :640-735 (write).
+// mask: 1 = code 16 usable, 2 = code 17, 4 = code 18, 8 = no 4+3 split of a 7-repeat, 16 = no 4+4 split of 8.
+template <typename Sink>
+__device__ inline void zh_cl_tokenize(const uint8_t *lens, int n, unsigned mask, Sink &sink) {
+   int i = 0;
+   while (i < n) {
+      const int v = lens[i];
+      int run = 1;
+      while (i + run < n && lens[i + run] == v) run++;
+      if (v == 0) {
+         if (run >= 3) {
+            while (run >= 11 && (mask & 4)) {
+               int take = run > 138 ? 138 : run;
+               sink.put(18, take - 11, 7);
+               run -= take;
+               i += take;
+            }
+            while (run >= 3 && (mask & 2)) {
+               int take = run > 10 ? 10 : run;
+               sink.put(17, take - 3, 3);
+               run -= take;
+               i += take;
+            }
+            if (run) {
+               sink.put(0, 0, 0);
+               i++;
+            }
+         }
+         else {
+            sink.put(0, 0, 0);
+            i++;
+         }
+      }
+      else {
+         sink.put(v > 15 ? 15 : v, 0, 0);
+         i++;
+         run--;
+         if (run == 7 && (mask & 1) && !(mask & 8)) {
+            sink.put(16, 1, 2);
+            sink.put(16, 0, 2);
+            run = 0;
+            i += 7;
+         }
+         else if (run == 8 && (mask & 1) && !(mask & 16)) {
+            sink.put(16, 1, 2);
+            sink.put(16, 1, 2);
+            run = 0;
+            i += 8;
+         }
+         while (run >= 3 && (mask & 1)) {
+            int take = run > 6 ? 6 : run;
+            sink.put(16, take - 3, 2);
+            run -= take;
+            i += take;
+         }
+      }
+   }
+}
+
+struct zh_cl_count_sink {
+   zh_cl_t *h;
+   __device__ __forceinline__ void put(int sym, int, int) { h->freq[sym]++; }
+};
+struct zh_cl_size_sink {
+   const zh_cl_t *h;
+   int bits;
+   __device__ __forceinline__ void put(int sym, int, int xbits) { bits += h->len[sym] + xbits; }
+};
+
+__device__ inline void zh_cl_reset(zh_cl_t *h) {
+   for (int s = 0; s < ZH_NCL; s++) {
+      h->freq[s] = 0;
+      h->len[s] = 0;
+      h->code[s] = 0;
+   }
+}
+
+// blockdeflate.c:594-613: header cost of a (lit, dist) pair — code-length alphabet histogrammed with mask 7,
+// sized with mask 31, its own lengths from the *unlimited* estimate. Single lane; lens = concatenated lengths.
+__device__ inline int zh_table_cost_lane(const uint8_t *lens, int n, zh_cl_t *h) {
+   zh_cl_reset(h);
+   zh_cl_count_sink cs{h};
+   zh_cl_tokenize(lens, n, 7, cs);
+   zh_cl_lengths_lane(h);
+   zh_cl_size_sink ss{h, 0};
+   zh_cl_tokenize(lens, n, 31, ss);
+   return 5 + 5 + 4 + 3 * zh_cl_raw_table_size(h) + ss.bits;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// huffutils.c:34-114 (zopfli's OptimizeHuffmanForRle), single lane, `keep` = scratch of `length` bytes.
+// ---------------------------------------------------------------------------------------------------------
+__device__ inline void zh_smooth_for_rle_lane(int length, int32_t *counts, uint8_t *keep) {
+   while (length > 0 && counts[length - 1] == 0) length--;
+   if (length == 0) return;
+   for (int i = 0; i < length; i++) keep[i] = 0;
+   {
+      uint32_t symbol = (uint32_t)counts[0];
+      int stride = 0;
+      for (int i = 0; i <= length; i++) {
+         if (i == length || (uint32_t)counts[i] != symbol) {
+            if ((symbol == 0 && stride >= 5) || (symbol != 0 && stride >= 7))
+               for (int k = 0; k < stride; k++) keep[i - k - 1] = 1;
+            stride = 1;
+            if (i != length) symbol = (uint32_t)counts[i];
+         }
+         else
+            stride++;
+      }
+   }
+   int stride = 0;
+   uint32_t limit = (uint32_t)counts[0], sum = 0;
+   for (int i = 0; i <= length; i++) {
+      bool brk = (i == length) || keep[i];
+      if (!brk) {
+         uint32_t c = (uint32_t)counts[i];
+         brk = (c > limit ? c - limit : limit - c) >= 4;
+      }
+      if (brk) {
+         if (stride >= 4 || (stride >= 3 && sum == 0)) {
+            int count = (int)((sum + (uint32_t)(stride / 2)) / (uint32_t)stride);
+            if (count < 1) count = 1;
+            if (sum == 0) count = 0;
+            for (int k = 0; k < stride; k++) counts[i - k - 1] = count;
+         }
+         stride = 0;
+         sum = 0;
+         if (i < length - 3)
+            limit = (uint32_t)((counts[i] + counts[i + 1] + counts[i + 2] + counts[i + 3] + 2) / 4);
+         else if (i < length)
+            limit = (uint32_t)counts[i];
+         else
+            limit = 0;
+      }
+      stride++;
+      if (i != length) sum += (uint32_t)counts[i];
+   }
+}

@@ -1,0 +1,81 @@
+// zh_platform.h — gfx950 (MI355X / CDNA4) platform layer: HIP runtime + wave64 primitives.
+//
+// Everything in csrc/ includes this as <zh_platform.h>. The only other provider of that header name is
+// tests/emu/zh_platform.h, a lock-step CPU emulator used by the `-m "not gpu"` tests to run the kernel
+// logic on a GPU-less machine; the product build never sees it (include path order in zultra_amd/build.py).
+//
+// Wave primitives are written for wave64 directly: DPP row operations for the intra-row steps, scalar
+// readlane for the cross-row step. No warp-32 idioms, no CUDA compatibility shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ZH_WAVE 64
+
+#define ZH_LAUNCH(kernel, grid, block, stream, ...) \
+   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (hipStream_t)(stream), __VA_ARGS__)
+
+__device__ __forceinline__ unsigned zh_lane() { return __lane_id(); }
+__device__ __forceinline__ uint64_t zh_ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint32_t zh_shfl(uint32_t v, int src_lane) { return (uint32_t)__shfl((int)v, src_lane, 64); }
+// lane must be wave-uniform
+__device__ __forceinline__ uint32_t zh_readlane(uint32_t v, int lane) {
+   return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ uint32_t zh_readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int zh_popc64(uint64_t m) { return __popcll(m); }
+__device__ __forceinline__ int zh_ctz64(uint64_t m) { return __ffsll((long long)m) - 1; }
+__device__ __forceinline__ int zh_clz32(uint32_t v) { return __clz((int)v); }
+
+// DPP controls (CDNA ISA): quad_perm, row_half_mirror, row_mirror
+#define ZH_DPP_QUAD_XOR1 0xB1
+#define ZH_DPP_QUAD_XOR2 0x4E
+#define ZH_DPP_ROW_HALF_MIRROR 0x141
+#define ZH_DPP_ROW_MIRROR 0x140
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t zh_dpp(uint32_t v) {
+   return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+// minimum over each 16-lane DPP row, result in every lane of the row (4 DPP steps, no LDS traffic)
+__device__ __forceinline__ uint32_t zh_row_min(uint32_t v) {
+   v = min(v, zh_dpp<ZH_DPP_QUAD_XOR1>(v));
+   v = min(v, zh_dpp<ZH_DPP_QUAD_XOR2>(v));
+   v = min(v, zh_dpp<ZH_DPP_ROW_HALF_MIRROR>(v));
+   v = min(v, zh_dpp<ZH_DPP_ROW_MIRROR>(v));
+   return v;
+}
+__device__ __forceinline__ uint32_t zh_row_sum(uint32_t v) {
+   v += zh_dpp<ZH_DPP_QUAD_XOR1>(v);
+   v += zh_dpp<ZH_DPP_QUAD_XOR2>(v);
+   v += zh_dpp<ZH_DPP_ROW_HALF_MIRROR>(v);
+   v += zh_dpp<ZH_DPP_ROW_MIRROR>(v);
+   return v;
+}
+// whole-wave reductions: row step on the VALU, the 4 row results combined on the scalar unit
+__device__ __forceinline__ uint32_t zh_wave_min(uint32_t v) {
+   v = zh_row_min(v);
+   uint32_t a = zh_readlane(v, 0), b = zh_readlane(v, 16), c = zh_readlane(v, 32), d = zh_readlane(v, 48);
+   return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ uint32_t zh_wave_sum(uint32_t v) {
+   v = zh_row_sum(v);
+   return zh_readlane(v, 0) + zh_readlane(v, 16) + zh_readlane(v, 32) + zh_readlane(v, 48);
+}
+// exclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t zh_wave_excl_sum(uint32_t v) {
+   uint32_t x = v;
+#pragma unroll
+   for (int d = 1; d < 64; d <<= 1) {
+      uint32_t y = (uint32_t)__shfl_up((int)x, d, 64);
+      if ((int)zh_lane() >= d) x += y;
+   }
+   return x - v;
+}
+
+// LDS visibility between the lanes of a workgroup (a single wave for the 64-thread kernels)
+__device__ __forceinline__ void zh_sync() { __syncthreads(); }
+
+__device__ __forceinline__ uint32_t zh_atomic_add_lds(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+__device__ __forceinline__ uint32_t zh_atomic_add_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }

@@ -1,0 +1,283 @@
+// zh_split.h — stage 2 of the hot path: greedy tokenisation and the block splitter, one wave per max-block.
+//
+// Replaces zultra_block_split (reference src/blockdeflate.c:634-813, called at src/libzultra.c:303) and the
+// greedy histogram it and the cost evaluation lean on (blockdeflate.c:333-361, :519-527).
+//
+// Observation that shapes the kernels: every greedy walk the reference makes inside one max-block — the
+// splitter's scan at each recursion level, the "left part" histograms, the per-sub-block initial entropy —
+// starts on a token boundary of the walk that started at the block start, because recursion ranges begin
+// at checkpoints and checkpoints are token ends. So there is exactly ONE greedy token chain per max-block.
+//   zh_tokenize  materialises it once (token position + packed symbols), 64 positions per step: the match
+//                lengths of a tile sit in one VGPR, the chain is followed on the scalar unit with
+//                v_readlane, and token lanes compact their record with a ballot prefix.
+//   zh_split     then works on token ranges: histograms are lane-parallel LDS atomics over tokens, the
+//                reference's checkpoints fall every 256 tokens, and only the drift test and the
+//                Moffat-Katajainen merges are serial.
+#pragma once
+#include <zh_platform.h>
+#include "zh_common.h"
+#include "zh_huffman.h"
+
+// token info: literal/length symbol (9 bits) | distance symbol (5 bits) << 9
+#define ZH_TOK_SYM(info) ((info) & 511u)
+#define ZH_TOK_DSYM(info) (((info) >> 9) & 31u)
+
+// Follow the chain through a 64-position tile. `len` holds, per lane, the step length of that position
+// (>=3: match, else literal). `carry` = offset of the first token start relative to the tile (may be >= 64).
+// Returns the mask of token starts among the first `limit` positions and updates carry for the next tile.
+__device__ inline uint64_t zh_chain_mask(uint32_t len, uint32_t &carry, uint32_t limit) {
+   uint64_t mask = 0;
+   uint32_t p = carry;
+   while (p < limit) {
+      mask |= 1ull << p;
+      uint32_t l = zh_readlane(len, (int)p);
+      p += (l >= ZH_MIN_MATCH) ? l : 1u;
+   }
+   carry = p - limit;   // only meaningful when limit == 64 (a full tile) or at the very end
+   return mask;
+}
+
+__global__ void __launch_bounds__(64)
+zh_tokenize(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
+            const zh_match_t *__restrict__ match, uint64_t match_stride, uint32_t *tok_pos, uint16_t *tok_info,
+            uint64_t tok_stride, uint32_t *ntok_out) {
+   const zh_block_t blk = blocks[blockIdx.x];
+   const uint8_t *win = data + blk.win_off;
+   const uint32_t *rows = (const uint32_t *)(match + (uint64_t)blockIdx.x * match_stride);
+   uint32_t *tp = tok_pos + (uint64_t)blockIdx.x * tok_stride;
+   uint16_t *ti = tok_info + (uint64_t)blockIdx.x * tok_stride;
+   const uint32_t lane = zh_lane();
+   const uint32_t n = blk.n;
+   uint32_t ntok = 0, carry = 0;
+
+   for (uint32_t base = 0; base < n; base += 64) {
+      const uint32_t limit = min(64u, n - base);
+      const uint32_t r = base + lane;
+      uint32_t m0 = 0, byte = 0;
+      if (r < n) {
+         m0 = rows[(uint64_t)r * ZH_NMATCH];   // slot 0 = longest match (matchfinder.c:221)
+         byte = win[blk.prev + r];
+      }
+      const uint32_t len = m0 & 0xffffu;
+      uint64_t mask = zh_chain_mask(len, carry, limit);
+      if ((mask >> lane) & 1ull) {
+         uint32_t idx = ntok + (uint32_t)zh_popc64(mask & ((1ull << lane) - 1));
+         uint32_t info = (len >= ZH_MIN_MATCH) ? ((257u + (uint32_t)zh_len_idx(len)) | ((uint32_t)zh_dist_sym(m0 >> 16) << 9)) : byte;
+         tp[idx] = blk.prev + r;
+         ti[idx] = (uint16_t)info;
+      }
+      ntok += (uint32_t)zh_popc64(mask);
+   }
+   if (lane == 0) ntok_out[blockIdx.x] = ntok;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-wave LDS workspace of zh_split
+// ---------------------------------------------------------------------------------------------------------
+struct zh_split_ws_t {
+   int32_t tot_lit[ZH_NLIT], tot_dist[ZH_NDIST];
+   int32_t left_lit[ZH_NLIT], left_dist[ZH_NDIST];
+   int32_t cur_lit[ZH_NLIT], cur_dist[ZH_NDIST];
+   uint8_t lit_len[ZH_NLIT], dist_len[ZH_NDIST];
+   uint8_t lens[ZH_NLIT + ZH_NDIST];
+   uint32_t fresh[18], seen[18];
+   zh_huff_scratch_t sc;
+   zh_cl_t cl;
+   int32_t tmp;
+};
+
+// blockdeflate.c:577-618 for the histogram in (lit, dist): unlimited lengths, body bits, header bits, +3.
+// All lanes call; returns the same value in every lane.
+__device__ inline int zh_dynamic_cost_wave(const int32_t *lit, const int32_t *dist, uint8_t *lit_len, uint8_t *dist_len,
+                                           uint8_t *lens, zh_cl_t *cl, int32_t *tmp, zh_huff_scratch_t *sc,
+                                           bool compute_lengths) {
+   const int lane = (int)zh_lane();
+   if (compute_lengths) {
+      zh_huff_lengths_wave(lit, lit_len, ZH_NLIT, sc);
+      zh_huff_lengths_wave(dist, dist_len, ZH_NDIST, sc);
+   }
+   uint32_t body = 0;
+   for (int s = lane; s < 257 + 29; s += 64) {
+      int xb = (s >= 257) ? zh_lenidx_xbits(s - 257) : 0;
+      body += (uint32_t)(lit[s] * ((int)lit_len[s] + xb));
+   }
+   if (lane < ZH_NDIST) body += (uint32_t)(dist[lane] * ((int)dist_len[lane] + zh_dist_xbits(lane)));
+   body = zh_wave_sum(body);
+
+   const int nlit = zh_defined_count(lit_len, ZH_NLIT, 257);
+   const int ndist = zh_defined_count(dist_len, ZH_NDIST, 1);
+   for (int s = lane; s < nlit; s += 64) lens[s] = lit_len[s];
+   if (lane < ndist) lens[nlit + lane] = dist_len[lane];
+   zh_sync();
+   if (lane == 0) *tmp = zh_table_cost_lane(lens, nlit + ndist, cl);
+   zh_sync();
+   int r = (int)body + *tmp + 3;
+   zh_sync();
+   return r;
+}
+
+// histogram of the greedy tokens [t0, t1) added into (lit, dist). All lanes call.
+__device__ inline void zh_token_histogram_wave(const uint16_t *ti, uint32_t t0, uint32_t t1, int32_t *lit, int32_t *dist) {
+   for (uint32_t t = t0 + zh_lane(); t < t1; t += 64) {
+      uint32_t info = ti[t];
+      uint32_t s = ZH_TOK_SYM(info);
+      atomicAdd(&lit[s], 1);
+      if (s > 256) atomicAdd(&dist[ZH_TOK_DSYM(info)], 1);
+   }
+   zh_sync();
+}
+
+// Search the best split of token range [t0, t1) (blockdeflate.c:659-773). Returns the token index of the
+// split boundary, or 0xFFFFFFFF. All lanes call; uniform result.
+__device__ inline uint32_t zh_split_search_wave(zh_split_ws_t *ws, const uint32_t *tp, const uint16_t *ti, uint32_t t0,
+                                                uint32_t t1, uint32_t start_pos, uint32_t end_pos) {
+   const uint32_t lane = zh_lane();
+
+   for (uint32_t s = lane; s < ZH_NLIT; s += 64) {
+      ws->tot_lit[s] = 0;
+      ws->left_lit[s] = 0;
+   }
+   if (lane < ZH_NDIST) {
+      ws->tot_dist[lane] = 0;
+      ws->left_dist[lane] = 0;
+   }
+   if (lane < 18) ws->seen[lane] = 0;
+   zh_sync();
+   zh_token_histogram_wave(ti, t0, t1, ws->tot_lit, ws->tot_dist);
+   if (lane == 0) ws->tot_lit[ZH_EOB] += 1;
+   zh_sync();
+   const int total_cost = zh_dynamic_cost_wave(ws->tot_lit, ws->tot_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl,
+                                               &ws->tmp, &ws->sc, true);
+
+   uint32_t nseen = 0;
+   uint32_t cp_prev = t0;             // token index where the current stats interval starts
+   uint32_t checkpoint = 0xFFFFFFFFu; // nLastGoodSplitIdx as a token boundary
+   uint32_t left_end = t0;            // nLastLeftEndOffset as a token boundary
+   uint32_t best = 0xFFFFFFFFu;
+   int best_gain = 0;
+
+   for (;;) {
+      // next check: first boundary c with c - cp_prev >= 256 tokens and pos(c) - start >= 512 (:705)
+      uint32_t c = cp_prev + 256;
+      if (c > t1) break;
+      while (c < t1 && tp[c] - start_pos < 512) c++;
+      {
+         uint32_t pc = (c < t1) ? tp[c] : end_pos;
+         if (pc - start_pos < 512) break;   // ran out of tokens before 512 bytes
+      }
+      const uint32_t nfresh = c - cp_prev;
+
+      if (lane < 18) ws->fresh[lane] = 0;
+      zh_sync();
+      for (uint32_t t = cp_prev + lane; t < c; t += 64) {
+         uint32_t s = ZH_TOK_SYM(ti[t]);
+         uint32_t bin = (s < 256) ? (((s >> 4) & 0xc) | (s & 3)) : (s >= 263 ? 17u : 16u);   // :689-699 (len >= 9 <=> symbol >= 263)
+         atomicAdd(&ws->fresh[bin], 1u);
+      }
+      zh_sync();
+
+      if (nseen) {
+         uint32_t d = 0;
+         if (lane < 18) {
+            uint32_t expected = ws->seen[lane] * nfresh;   // uint32 wrap is part of the behaviour (:710-711)
+            uint32_t actual = ws->fresh[lane] * nseen;
+            d = expected > actual ? expected - actual : actual - expected;
+         }
+         const uint32_t drift = zh_wave_sum(d);
+         if ((drift / nfresh) >= (nseen * 45 / 100) && checkpoint != 0xFFFFFFFFu) {
+            // left += tokens [left_end, checkpoint); right = total - left (:732-743)
+            zh_token_histogram_wave(ti, left_end, checkpoint, ws->left_lit, ws->left_dist);
+            if (lane == 0) ws->left_lit[ZH_EOB] = 1;
+            zh_sync();
+            const int lcost = zh_dynamic_cost_wave(ws->left_lit, ws->left_dist, ws->lit_len, ws->dist_len, ws->lens,
+                                                   &ws->cl, &ws->tmp, &ws->sc, true);
+            for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws->cur_lit[s] = ws->tot_lit[s] - ws->left_lit[s];
+            if (lane < ZH_NDIST) ws->cur_dist[lane] = ws->tot_dist[lane] - ws->left_dist[lane];
+            zh_sync();
+            if (lane == 0) ws->cur_lit[ZH_EOB] = 1;
+            zh_sync();
+            const int rcost = zh_dynamic_cost_wave(ws->cur_lit, ws->cur_dist, ws->lit_len, ws->dist_len, ws->lens,
+                                                   &ws->cl, &ws->tmp, &ws->sc, true);
+            const int gain = total_cost - (lcost + rcost);
+            if (gain >= 0 && (best == 0xFFFFFFFFu || best_gain < gain)) {
+               best = checkpoint;
+               best_gain = gain;
+            }
+            left_end = checkpoint;
+         }
+      }
+      if (lane < 18) ws->seen[lane] += ws->fresh[lane];
+      zh_sync();
+      nseen += nfresh;
+      checkpoint = c;
+      cp_prev = c;
+      if (c >= t1) break;
+   }
+   return best;
+}
+
+// One wave per max-block. Output: split_tok[b*65 + k] token boundaries (k = 0..count, first = 0, last = ntok),
+// split_cnt[b] = number of sub-blocks.
+__global__ void __launch_bounds__(64)
+zh_split(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ tok_pos, const uint16_t *__restrict__ tok_info,
+         uint64_t tok_stride, const uint32_t *__restrict__ ntok_in, uint32_t *split_tok, uint32_t *split_cnt) {
+   __shared__ zh_split_ws_t ws;
+   const zh_block_t blk = blocks[blockIdx.x];
+   const uint32_t *tp = tok_pos + (uint64_t)blockIdx.x * tok_stride;
+   const uint16_t *ti = tok_info + (uint64_t)blockIdx.x * tok_stride;
+   const uint32_t ntok = ntok_in[blockIdx.x];
+   const uint32_t block_end = blk.prev + blk.n;
+   uint32_t *out = split_tok + (uint64_t)blockIdx.x * (ZH_MAX_SPLITS + 1);
+
+   // explicit recursion (depth <= 6): frames hold [t0,t1), the chosen boundary and a phase
+   uint32_t f_t0[8], f_t1[8], f_best[8];
+   int f_phase[8];
+   int sp = 0;
+   uint32_t count = 0;   // interior splits recorded so far (max 63, :805)
+   f_t0[0] = 0;
+   f_t1[0] = ntok;
+   f_phase[0] = 0;
+   f_best[0] = 0;
+
+   if (zh_lane() == 0) out[0] = 0;
+
+   while (sp >= 0) {
+      const uint32_t t0 = f_t0[sp], t1 = f_t1[sp];
+      if (f_phase[sp] == 0) {
+         const uint32_t p0 = (t0 < ntok) ? tp[t0] : block_end;
+         const uint32_t p1 = (t1 < ntok) ? tp[t1] : block_end;
+         if (count >= ZH_MAX_SPLITS - 1 || sp >= 6 || (p1 - p0) < 8192) {   // :643-647
+            sp--;
+            continue;
+         }
+         const uint32_t b = zh_split_search_wave(&ws, tp, ti, t0, t1, p0, p1);
+         if (b == 0xFFFFFFFFu) {
+            sp--;
+            continue;
+         }
+         f_best[sp] = b;
+         f_phase[sp] = 1;
+         f_t0[sp + 1] = t0;
+         f_t1[sp + 1] = b;
+         f_phase[sp + 1] = 0;
+         sp++;
+      }
+      else if (f_phase[sp] == 1) {
+         if (count < ZH_MAX_SPLITS - 1) {
+            count++;
+            if (zh_lane() == 0) out[count] = f_best[sp];
+         }
+         f_phase[sp] = 2;
+         f_t0[sp + 1] = f_best[sp];
+         f_t1[sp + 1] = t1;
+         f_phase[sp + 1] = 0;
+         sp++;
+      }
+      else
+         sp--;
+   }
+   if (zh_lane() == 0) {
+      out[count + 1] = ntok;
+      split_cnt[blockIdx.x] = count + 1;
+   }
+}
