@@ -61,6 +61,10 @@ typedef struct zultra_hip_timing_s {
 /* Number of usable HIP devices (0 if none). */
 int zultra_hip_device_count(void);
 
+/* Device self-check of the wave64 primitives the kernels rely on (DPP row reductions, readlane, prefix sums)
+ * against plain LDS arithmetic. Returns 0 when they agree, a positive count of mismatches, negative on HIP errors. */
+int zultra_hip_selftest(void);
+
 /* Create a context on `device` able to take batches of up to max_blocks max-blocks of up to max_block_size bytes
  * (clamped like libzultra.c:87-92). All device memory is allocated here and released by zultra_hip_destroy
  * (the reference allocates in zultra_stream_init and frees in zultra_stream_end, libzultra.c:82-166,521-565).
@@ -99,7 +103,9 @@ int zultra_hip_get_parse(zultra_hip_ctx_t *ctx, uint32_t block, uint16_t *out);
  *   raw          : the raw bytes of the batch's max-blocks, max-block b at raw + raw_off[b] (for stored sub-blocks)
  *   final_block  : index of the max-block that ends the stream (ZULTRA_FINALIZE and no more input), or -1
  * Writes whole bytes to out (capacity out_cap) and returns the number written, or (size_t)-1 on overflow / error
- * (the reference's ZULTRA_ERROR_DST). Call zultra_hip_stitch_finish() after the last batch to pad to a byte
+ * (the reference's ZULTRA_ERROR_DST). With out == NULL nothing is written: the call only advances `state` and returns
+ * the byte count, which is how a rank learns at which bit offset its shard starts (multi-GPU).
+ * `state` may start at any phase 0..7 with acc = 0: the first byte then carries only this shard's bits. Call zultra_hip_stitch_finish() after the last batch to pad to a byte
  * (libzultra.c:414-417).
  */
 typedef struct zultra_hip_bitstate_s {

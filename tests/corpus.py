@@ -153,3 +153,53 @@ def mixed(size, seed=1):
         total += seg
         k += 1
     return np.concatenate(parts)[:size]
+
+
+def text_like_fast(size, seed=1):
+    """Vectorised variant of text_like for benchmark-sized inputs (100 MB in a few seconds): Zipf word stream with
+    spaces, sentence punctuation, paragraph breaks and a sprinkle of wiki-style link / entity markup."""
+    rs = np.random.RandomState(seed)
+    words = _vocab(np.random.RandomState(4242), 65536)
+    extra = [b"[[" + w + b"]]" for w in words[:256]] + [b"&quot;" + w + b"&quot;" for w in words[:128]] + \
+            [b"'''" + w + b"'''" for w in words[:128]] + [str(y).encode() for y in range(1800, 2056)]
+    table = words + extra
+    maxlen = max(len(w) for w in table) + 2
+    tab = np.zeros((len(table), maxlen), dtype=np.uint8)
+    lens = np.zeros(len(table), dtype=np.int64)
+    for i, w in enumerate(table):
+        tab[i, :len(w)] = np.frombuffer(w, dtype=np.uint8)
+        lens[i] = len(w)
+    out = np.empty(size + 64, dtype=np.uint8)
+    pos = 0
+    while pos < size:
+        nw = min(4_000_000, (size - pos) // 4 + 64)
+        ids = rs.zipf(1.19, size=nw) - 1
+        ids = np.where(ids >= len(words), rs.randint(0, len(words), size=nw), ids)
+        r = rs.randint(0, 100, size=nw)
+        ids = np.where(r < 7, len(words) + rs.randint(0, len(extra), size=nw), ids)
+        sep = rs.randint(0, 64, size=nw)
+        # separator: 0 -> ". " , 1 -> ", ", 2 -> ".\n\n" (rare: only when sep==2 and r<50), else " "
+        seplen = np.where(sep == 0, 2, np.where(sep == 1, 2, np.where((sep == 2) & (r < 50), 3, 1)))
+        wl = lens[ids]
+        tot = wl + seplen
+        offs = np.cumsum(tot) - tot
+        need = int(offs[-1] + tot[-1])
+        buf = np.full(need + 4, 32, dtype=np.uint8)
+        for j in range(maxlen):
+            m = wl > j
+            if not m.any():
+                break
+            buf[offs[m] + j] = tab[ids[m], j]
+        so = offs + wl
+        m0 = sep == 0
+        buf[so[m0]] = ord(".")
+        m1 = sep == 1
+        buf[so[m1]] = ord(",")
+        m2 = (sep == 2) & (r < 50)
+        buf[so[m2]] = ord(".")
+        buf[so[m2] + 1] = 10
+        buf[so[m2] + 2] = 10
+        take = min(need, size - pos)
+        out[pos:pos + take] = buf[:take]
+        pos += take
+    return out[:size]

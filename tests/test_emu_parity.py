@@ -1,0 +1,112 @@
+"""CPU (no GPU needed): the product's own kernel sources, compiled against the lock-step wave emulator in
+tests/emu/, checked stage by stage against the oracle and on whole streams against the golden vectors.
+This exercises the kernel logic and the host layer (stream state machine, batching, stitcher); the `-m gpu`
+tests repeat the same checks on the real MI355X build."""
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+import corpus
+import golden_util as G
+from parity_util import check_window
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import build_emu
+    from zultra_amd._ffi import Lib
+    return Lib(build_emu.build())
+
+
+def test_emu_is_not_the_product_library(emu):
+    import zultra_amd
+    assert os.path.realpath(emu.path) != os.path.realpath(zultra_amd.LIB_PATH)
+    assert "tests/emu/_build" in emu.path
+
+
+@pytest.mark.parametrize("case", [
+    ("text", lambda: corpus.text_like(9000, 3), 1000, 8000),
+    ("text_split", lambda: corpus.text_like(60000, 21)[30000:42000], 0, 12000),
+    ("selftest", lambda: corpus.selftest_data(6000, 77, 15, 0.5), 1000, 5000),
+    ("binary2", lambda: corpus.selftest_data(5000, 5, 2, 0.3), 0, 5000),
+    ("zeros", lambda: corpus.constant(3000), 500, 2500),
+    ("period3", lambda: corpus.periodic(2500, 3), 0, 2500),
+    ("noise", lambda: corpus.noise(3000, 1), 0, 3000),
+    ("tiny", lambda: corpus.text_like(10, 1), 0, 10),
+    ("three", lambda: corpus.text_like(3, 1), 0, 3),
+    ("one", lambda: corpus.text_like(1, 1), 0, 1),
+    ("end_clamp", lambda: np.concatenate([corpus.noise(300, 2), corpus.constant(700, 65)]), 0, 1000),
+], ids=lambda c: c[0])
+def test_stages_vs_oracle(emu, oracle, case):
+    name, gen, prev, n = case
+    check_window(emu, oracle, gen(), prev, n, tag=name)
+
+
+@pytest.mark.parametrize("name", ["tiny_100", "one_byte", "two_bytes", "json_4k", "json_4k_b", "selftest_a1_p0"])
+def test_golden_streams(emu, name):
+    c = G.stream_case(name)
+    G.check_stream_output(c, emu.memory_compress(c["data"], c["flags"], c["max_block"], c["dictionary"]))
+
+
+def test_multiblock_stream_bit_carry_and_stored_fallback(emu, oracle):
+    # 3 max-blocks of 32 KiB: text | noise (stored, phase-dependent padding) | text, gzip framing
+    t = corpus.text_like(40000, 5)
+    d = np.concatenate([t[:33000], corpus.noise(33000, 3), t[33000:36000]])
+    got = emu.memory_compress(d, 2, 32768)
+    assert got == oracle.memory_compress(d, 2, 32768)
+    assert zlib.decompress(got, 31) == d.tobytes()
+
+
+def test_dictionary_stream(emu, oracle):
+    t = corpus.text_like(12000, 8)
+    got = emu.memory_compress(t[4000:], 1, 32768, t[:4000])
+    assert got == oracle.memory_compress(t[4000:], 1, 32768, t[:4000])
+    assert zlib.decompressobj(15, zdict=t[:4000].tobytes()).decompress(got) == t[4000:].tobytes()
+
+
+def test_streaming_api_chunking_does_not_change_the_bytes(emu, oracle):
+    # libzultra.c:259-269: blocks are cut at nMaxBlockSize whatever the chunking; tool/zultra.c:161 feeds 16 KiB chunks
+    d = corpus.json_like(70000, 3)
+    want = oracle.memory_compress(d, 2, 32768)
+    for chunk in (16384, 40000, 70000):
+        s = emu.stream(2, 32768)
+        out = bytearray()
+        pos = 0
+        st = 0
+        while pos < len(d):
+            part = d[pos:pos + chunk]
+            pos += len(part)
+            st, b = s.compress(part, finalize=(pos >= len(d)), out_chunk=5000)
+            out += b
+        assert st == 1   # ZULTRA_STREAM_END
+        assert s.total_in == len(d) and s.total_out == len(out)
+        st2, _ = s.compress(np.zeros(0, dtype=np.uint8), True)
+        assert st2 == -5   # further calls: ZULTRA_ERROR_COMPRESSION (libzultra.c:204-205)
+        s.end()
+        assert bytes(out) == want
+
+
+def test_error_behaviour_matches_reference(emu):
+    t = corpus.text_like(100, 1)
+    assert emu.memory_compress(t[:0], 2, 0) is None              # empty input never finalizes (libzultra.c:275)
+    for cap in range(0, 12):                                      # tool/zultra.c:521-524
+        assert emu.memory_compress(t, 1, 0, cap=cap) is None
+    s = emu.stream(0, 0)
+    s.compress(t, False)
+    assert s.set_dictionary(t) == -5                              # only before the first compress (libzultra.c:180)
+    s.end()
+
+
+def test_memory_bound_and_checksums(emu, oracle):
+    for n in (0, 1, 65535, 65536, 10 ** 6):
+        for flags in (0, 1, 2):
+            for bs in (0, 32768, 65536, 1 << 22):
+                assert emu.memory_bound(n, flags, bs) == oracle.memory_bound(n, flags, bs)
+    d = corpus.text_like(70001, 4)
+    assert emu.checksum(d, 2) == zlib.crc32(d.tobytes())
+    assert emu.checksum(d, 1) == zlib.adler32(d.tobytes())

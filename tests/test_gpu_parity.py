@@ -1,0 +1,130 @@
+"""GPU (MI355X): the product library zultra_amd/libzultra_amd.so, through its C ABI, against the oracle
+(same seeded inputs, stage by stage), against the golden vectors produced by the compiled reference, and —
+at full benchmark sizes — through size-independent properties (inflate round trip, block independence)."""
+import zlib
+
+import numpy as np
+import pytest
+
+import corpus
+import golden_util as G
+from parity_util import check_window
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import zultra_amd
+    L = zultra_amd.lib()            # raises if the .so is missing: no fallback
+    assert L.device_count() >= 1, "no HIP device visible"
+    return L
+
+
+def test_wave_primitives_selfcheck(gpu):
+    # zh_selftest runs the DPP/readlane reductions against plain shuffles on the device
+    import ctypes as C
+    f = gpu.L.zultra_hip_selftest
+    f.restype = C.c_int
+    assert f() == 0
+
+
+@pytest.mark.parametrize("case", [
+    ("text_hist", lambda: corpus.text_like(98304, 3), 32768, 65536, 65536),
+    ("text_first", lambda: corpus.text_like(65536, 4), 0, 65536, 65536),
+    ("text_split", lambda: corpus.text_like(60000, 21)[30000:50000], 0, 20000, 32768),
+    ("mixed", lambda: corpus.mixed(98304, 5), 32768, 65536, 65536),
+    ("selftest15", lambda: corpus.selftest_data(49152, 123, 15, 0.5), 16384, 32768, 32768),
+    ("selftest2", lambda: corpus.selftest_data(49152, 123, 2, 0.5), 16384, 32768, 32768),
+    ("selftest256", lambda: corpus.selftest_data(49152, 123, 256, 0.0), 16384, 32768, 32768),
+    ("zeros", lambda: corpus.constant(70000), 4464, 65536, 65536),
+    ("period3", lambda: corpus.periodic(50000, 3), 0, 50000, 65536),
+    ("noise", lambda: corpus.noise(40000, 1), 0, 40000, 65536),
+    ("sparse", lambda: corpus.sparse_ones(98304), 32768, 65536, 65536),
+    ("tiny", lambda: corpus.text_like(10, 1), 0, 10, 32768),
+    ("three", lambda: corpus.text_like(3, 1), 0, 3, 32768),
+    ("one", lambda: corpus.text_like(1, 1), 0, 1, 32768),
+    ("json4k", lambda: corpus.json_like(4096, 3), 0, 4096, 32768),
+    ("big_block", lambda: corpus.text_like(300000, 6), 32768, 267232, 1 << 20),
+], ids=lambda c: c[0])
+def test_stages_vs_oracle(gpu, oracle, case):
+    name, gen, prev, n, bs = case
+    check_window(gpu, oracle, gen(), prev, n, max_block=bs, tag=name)
+
+
+@pytest.mark.parametrize("name", G.stream_names())
+def test_golden_streams(gpu, name):
+    c = G.stream_case(name)
+    G.check_stream_output(c, gpu.memory_compress(c["data"], c["flags"], c["max_block"], c["dictionary"]))
+
+
+@pytest.mark.parametrize("flags,bs", [(2, 65536), (1, 32768), (0, 0)])
+def test_stream_vs_oracle_multiblock(gpu, oracle, flags, bs):
+    d = np.concatenate([corpus.text_like(300000, 9), corpus.noise(90000, 2), corpus.mixed(200000, 3)])
+    got = gpu.memory_compress(d, flags, bs)
+    assert got == oracle.memory_compress(d, flags, bs)
+
+
+def test_fuzz_streams_vs_oracle(gpu, oracle):
+    rs = np.random.RandomState(77)
+    for it in range(10):
+        n = int(rs.randint(1, 150000))
+        kind = it % 4
+        if kind == 0:
+            d = corpus.mixed(n, 500 + it)
+        elif kind == 1:
+            d = corpus.selftest_data(n, 600 + it, corpus.SELFTEST_ALPHABETS[it % 12], [0.0, 0.3, 0.7, 0.995][it % 4])
+        elif kind == 2:
+            d = corpus.text_like(n, 700 + it)
+        else:
+            d = np.concatenate([corpus.json_like(n // 2, it), corpus.noise(n - n // 2, it)])
+        flags, bs = int(rs.randint(0, 3)), [0, 32768, 65536][it % 3]
+        assert gpu.memory_compress(d, flags, bs) == oracle.memory_compress(d, flags, bs), (it, n, flags, bs)
+
+
+def test_streaming_api_chunking(gpu, oracle):
+    d = corpus.text_like(500000, 12)
+    want = oracle.memory_compress(d, 2, 65536)
+    for chunk in (16384, 100000, 500000):
+        s = gpu.stream(2, 65536)
+        out = bytearray()
+        pos, st = 0, 0
+        while pos < len(d):
+            part = d[pos:pos + chunk]
+            pos += len(part)
+            st, b = s.compress(part, finalize=(pos >= len(d)), out_chunk=16384)
+            out += b
+        assert st == 1
+        s.end()
+        assert bytes(out) == want
+
+
+def test_errors(gpu):
+    t = corpus.text_like(100, 1)
+    assert gpu.memory_compress(t[:0], 2, 0) is None
+    for cap in range(0, 12):
+        assert gpu.memory_compress(t, 1, 0, cap=cap) is None
+
+
+def test_full_size_properties(gpu, oracle):
+    """Benchmark-sized input (the oracle would take minutes): inflate round trip, size sanity versus zlib -9, and
+    block independence — the same max-blocks compressed in two different batch splits give identical bits."""
+    d = corpus.text_like(24 << 20, 31)
+    out = gpu.memory_compress(d, 2, 65536)
+    assert out is not None
+    assert zlib.decompress(out, 31) == d.tobytes()
+    z9 = len(zlib.compress(d.tobytes(), 9))
+    assert len(out) < z9, (len(out), z9)
+    # streaming in 1 MiB chunks goes through different batch boundaries; the bytes must not change
+    s = gpu.stream(2, 65536)
+    acc = bytearray()
+    for pos in range(0, len(d), 1 << 20):
+        st, b = s.compress(d[pos:pos + (1 << 20)], finalize=(pos + (1 << 20) >= len(d)), out_chunk=1 << 20)
+        acc += b
+    s.end()
+    assert bytes(acc) == out
+    # spot-check a few max-blocks of the big input against the oracle, stage by stage
+    for blk in (0, 7, 200):
+        lo = blk * 65536
+        prev = 32768 if blk else 0
+        check_window(gpu, oracle, d[lo - prev: lo + 65536], prev, 65536, max_block=65536, tag="blk%d" % blk)

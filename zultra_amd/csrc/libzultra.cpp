@@ -187,11 +187,14 @@ struct Sink {
    size_t cap, pos;
    uint32_t acc, nacc;
    bool overflow;
+   bool dry;   // count only (out == NULL): used to plan bit offsets of later shards
    inline void byte(uint8_t b) {
-      if (pos < cap)
-         out[pos] = b;
-      else
-         overflow = true;
+      if (!dry) {
+         if (pos < cap)
+            out[pos] = b;
+         else
+            overflow = true;
+      }
       pos++;
    }
    inline void bits(uint32_t v, uint32_t n) {   // n <= 16
@@ -213,6 +216,11 @@ struct Sink {
    // append nbits of a phase-0 bit string
    void append(const uint8_t *src, uint64_t nbits) {
       const uint64_t full = nbits >> 3;
+      if (dry) {
+         pos += full;
+         if (nbits & 7) bits(0, (uint32_t)(nbits & 7));
+         return;
+      }
       if (nacc == 0) {
          size_t room = pos < cap ? cap - pos : 0;
          size_t k = full < room ? (size_t)full : room;
@@ -246,7 +254,7 @@ struct Sink {
 extern "C" size_t zultra_hip_stitch(zultra_hip_bitstate_t *state, const zultra_hip_subblock_t *subs, uint32_t nsubs,
                                     const uint8_t *payload, const uint8_t *raw, const uint64_t *raw_off, uint32_t max_block_size,
                                     int final_block, uint8_t *out, size_t out_cap) {
-   Sink s{out, out_cap, 0, state->acc, state->nacc, false};
+   Sink s{out, out_cap, 0, state->acc, state->nacc, false, out == NULL};
    // capacity of the reference's per-max-block output buffer (libzultra.c:115): exceeding it is ZULTRA_ERROR_DST
    const size_t blockbuf_cap = 1 + (size_t)max_block_size + 5 * ((size_t)max_block_size / 65535 + 1);
    size_t block_base = 0;
@@ -274,7 +282,7 @@ extern "C" size_t zultra_hip_stitch(zultra_hip_bitstate_t *state, const zultra_h
       }
       else {
          // stored, pieces of at most 65535 bytes (:350-397)
-         const uint8_t *src = raw + raw_off[sb.block] + sb.start;
+         const uint8_t *src = s.dry ? NULL : raw + raw_off[sb.block] + sb.start;
          uint32_t rem = sb.size;
          while (rem) {
             const uint32_t piece = rem > 65535 ? 65535 : rem;
@@ -286,12 +294,14 @@ extern "C" size_t zultra_hip_stitch(zultra_hip_bitstate_t *state, const zultra_h
             s.byte((uint8_t)(piece >> 8));
             s.byte((uint8_t)((piece & 0xff) ^ 0xff));
             s.byte((uint8_t)((piece >> 8) ^ 0xff));
-            if (s.pos + piece <= s.cap)
-               memcpy(s.out + s.pos, src, piece);
-            else
-               s.overflow = true;
+            if (!s.dry) {
+               if (s.pos + piece <= s.cap)
+                  memcpy(s.out + s.pos, src, piece);
+               else
+                  s.overflow = true;
+            }
             s.pos += piece;
-            src += piece;
+            if (!s.dry) src += piece;
             rem -= piece;
          }
       }

@@ -77,6 +77,70 @@ static uint32_t zh_clamp_block(uint32_t n) {
    return n;
 }
 
+// ---- wave primitive self-check -------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) zh_selftest_kernel(uint32_t seed, uint32_t *bad) {
+   __shared__ uint32_t v[64];
+   const uint32_t lane = zh_lane();
+   uint32_t errors = 0;
+   for (uint32_t round = 0; round < 64; round++) {
+      uint32_t x = (seed + round * 977u + lane * 2654435761u) * 2246822519u;
+      x ^= x >> 15;
+      if (round & 1) x &= 0xffffu;      // small values: sums stay exact
+      if (round == 5) x = 0xFFFFFFFFu;  // identity of the min reduction in every lane
+      v[lane] = x;
+      zh_sync();
+      uint32_t mn = 0xFFFFFFFFu, sm = 0, ex = 0, rmn = 0xFFFFFFFFu;
+      for (uint32_t k = 0; k < 64; k++) {
+         mn = min(mn, v[k]);
+         sm += v[k];
+         if (k < lane) ex += v[k];
+         if ((k >> 4) == (lane >> 4)) rmn = min(rmn, v[k]);
+      }
+      if (zh_wave_min(x) != mn) errors++;
+      if (zh_wave_sum(x) != sm) errors++;
+      if (zh_wave_excl_sum(x) != ex) errors++;
+      if (zh_row_min(x) != rmn) errors++;
+      if (zh_readlane(x, (int)(round & 63)) != v[round & 63]) errors++;
+      if (zh_shfl(x, (int)((lane * 7 + round) & 63)) != v[(lane * 7 + round) & 63]) errors++;
+      uint64_t b = zh_ballot((x & 4) != 0), bref = 0;
+      for (uint32_t k = 0; k < 64; k++) bref |= (uint64_t)((v[k] & 4) != 0) << k;
+      if (b != bref) errors++;
+      if (zh_readfirstlane(x) != v[0]) errors++;
+      zh_sync();
+   }
+   // RFC 1951 symbol arithmetic against first principles
+   if (lane == 0) {
+      uint32_t d = 1;
+      for (int s = 0; s < 30; s++) {
+         int xb = s < 4 ? 0 : s / 2 - 1;
+         if (zh_dist_base(s) != d || zh_dist_xbits(s) != xb) errors++;
+         for (uint32_t k = 0; k < (1u << xb); k += (xb > 6 ? 37 : 1))
+            if (zh_dist_sym(d + k) != s) errors++;
+         if (zh_dist_sym(d + (1u << xb) - 1) != s) errors++;
+         d += 1u << xb;
+      }
+      for (uint32_t len = 3; len <= 258; len++) {
+         int idx = zh_len_idx(len);
+         uint32_t base = zh_lenidx_base(idx);
+         if (len < base || len - base >= (1u << zh_lenidx_xbits(idx)) || idx > 28) errors++;
+         if (idx < 28 && zh_lenidx_base(idx + 1) <= len && !(idx == 27 && len < 258)) errors++;
+      }
+   }
+   if (errors) atomicAdd(bad, errors);
+}
+
+extern "C" int zultra_hip_selftest(void) {
+   int ndev = 0;
+   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -1;
+   uint32_t *d_bad = NULL, bad = 0;
+   if (hipMalloc((void **)&d_bad, sizeof(uint32_t)) != hipSuccess) return -2;
+   if (hipMemset(d_bad, 0, sizeof(uint32_t)) != hipSuccess) return -3;
+   ZH_LAUNCH(zh_selftest_kernel, 8, 64, 0, 12345u, d_bad);
+   if (hipMemcpy(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return -4;
+   (void)hipFree(d_bad);
+   return (int)bad;
+}
+
 extern "C" int zultra_hip_device_count(void) {
    int n = 0;
    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -91,26 +155,26 @@ static int zh_alloc(zultra_hip_ctx_t *c, T **p, size_t count) {
 
 extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    if (!c) return;
-   hipSetDevice(c->device);
-   hipFree(c->d_data);
-   hipFree(c->d_blocks);
-   hipFree(c->d_sort_a);
-   hipFree(c->d_sort_b);
-   hipFree(c->d_match);
-   hipFree(c->d_tok_pos);
-   hipFree(c->d_tok_info);
-   hipFree(c->d_ntok);
-   hipFree(c->d_split_tok);
-   hipFree(c->d_split_cnt);
-   hipFree(c->d_sub_base);
-   hipFree(c->d_best);
-   hipFree(c->d_work);
-   hipFree(c->d_results);
-   hipFree(c->d_payload);
-   if (c->h_payload) hipHostFree(c->h_payload);
+   (void)hipSetDevice(c->device);
+   (void)hipFree(c->d_data);
+   (void)hipFree(c->d_blocks);
+   (void)hipFree(c->d_sort_a);
+   (void)hipFree(c->d_sort_b);
+   (void)hipFree(c->d_match);
+   (void)hipFree(c->d_tok_pos);
+   (void)hipFree(c->d_tok_info);
+   (void)hipFree(c->d_ntok);
+   (void)hipFree(c->d_split_tok);
+   (void)hipFree(c->d_split_cnt);
+   (void)hipFree(c->d_sub_base);
+   (void)hipFree(c->d_best);
+   (void)hipFree(c->d_work);
+   (void)hipFree(c->d_results);
+   (void)hipFree(c->d_payload);
+   if (c->h_payload) (void)hipHostFree(c->h_payload);
    for (int i = 0; i < 8; i++)
-      if (c->ev[i]) hipEventDestroy(c->ev[i]);
-   if (c->stream) hipStreamDestroy(c->stream);
+      if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+   if (c->stream) (void)hipStreamDestroy(c->stream);
    delete c;
 }
 
@@ -234,14 +298,14 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    ZH_CHECK(c, hipGetLastError());
    c->nsubs = nsubs;
 
-   hipEventElapsedTime(&c->timing.h2d_ms, c->ev[0], c->ev[1]);
-   hipEventElapsedTime(&c->timing.matchfinder_ms, c->ev[1], c->ev[2]);
-   hipEventElapsedTime(&c->timing.group_ms, c->ev[1], c->ev[6]);
-   hipEventElapsedTime(&c->timing.frontier_ms, c->ev[6], c->ev[2]);
-   hipEventElapsedTime(&c->timing.tokenize_split_ms, c->ev[2], c->ev[3]);
-   hipEventElapsedTime(&c->timing.encode_ms, c->ev[3], c->ev[4]);
-   hipEventElapsedTime(&c->timing.d2h_ms, c->ev[4], c->ev[5]);
-   hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[5]);
+   (void)hipEventElapsedTime(&c->timing.h2d_ms, c->ev[0], c->ev[1]);
+   (void)hipEventElapsedTime(&c->timing.matchfinder_ms, c->ev[1], c->ev[2]);
+   (void)hipEventElapsedTime(&c->timing.group_ms, c->ev[1], c->ev[6]);
+   (void)hipEventElapsedTime(&c->timing.frontier_ms, c->ev[6], c->ev[2]);
+   (void)hipEventElapsedTime(&c->timing.tokenize_split_ms, c->ev[2], c->ev[3]);
+   (void)hipEventElapsedTime(&c->timing.encode_ms, c->ev[3], c->ev[4]);
+   (void)hipEventElapsedTime(&c->timing.d2h_ms, c->ev[4], c->ev[5]);
+   (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[5]);
    return (int)nsubs;
 }
 
