@@ -95,6 +95,12 @@ int zultra_hip_get_matches(zultra_hip_ctx_t *ctx, uint32_t block, uint16_t *out)
 int zultra_hip_get_splits(zultra_hip_ctx_t *ctx, uint32_t block, int *out /* [64] */);
 int zultra_hip_get_parse(zultra_hip_ctx_t *ctx, uint32_t block, uint16_t *out);
 
+/* Diagnostics: when enabled, zh_encode records 16 shader-clock stamps per sub-block (phase boundaries: cost
+ * evaluation, tentative codes, 4 x (parse, histogram+codes), literalisation, alternative tables, header, tokens).
+ * get_profile copies them out ([sub-block][16], stream order) and returns the number of sub-blocks copied. */
+int zultra_hip_set_profile(zultra_hip_ctx_t *ctx, int enable);
+int zultra_hip_get_profile(zultra_hip_ctx_t *ctx, uint64_t *out, uint32_t max_subblocks);
+
 /*
  * Stitcher (host): appends the framed sub-blocks of a batch to a deflate stream, reproducing libzultra.c:327-398
  * (3 header bits, compressed-or-stored decision from the running bit phase, stored pieces of <= 65535 bytes) and

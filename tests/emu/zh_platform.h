@@ -177,6 +177,22 @@ inline int zh_popc64(uint64_t m) { return __builtin_popcountll(m); }
 inline int zh_ctz64(uint64_t m) { return m ? __builtin_ctzll(m) : -1; }
 inline int zh_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 
+template <int N>
+inline uint32_t zh_row_shr(uint32_t v) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [] {
+      int l = g_cur & 15;
+      return l >= N ? g_slot[g_cur - N] : g_slot[g_cur];
+   });
+}
+template <int N>
+inline uint32_t zh_row_shl(uint32_t v) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [] {
+      int l = g_cur & 15;
+      return l + N < 16 ? g_slot[g_cur + N] : g_slot[g_cur];
+   });
+}
 inline uint32_t zh_row_min(uint32_t v) {
    using namespace zh_emu;
    return (uint32_t)collect(v, [] {
@@ -231,6 +247,7 @@ inline uint32_t atomicOr(uint32_t *p, uint32_t v) {
    *p = o | v;
    return o;
 }
+inline uint64_t zh_clock() { return 0; }
 inline void __threadfence_block() {}
 inline void __threadfence() {}
 struct uint2 {

@@ -47,6 +47,8 @@ struct zultra_hip_ctx_s {
    zh_work_t *d_work;
    zh_subblock_t *d_results;
    uint8_t *d_payload;
+   uint64_t *d_prof;   // optional in-kernel phase stamps (zultra_hip_set_profile)
+   int profile;
 
    // host mirrors of the last batch
    std::vector<zh_block_t> blocks;
@@ -106,6 +108,10 @@ __global__ void __launch_bounds__(64) zh_selftest_kernel(uint32_t seed, uint32_t
       for (uint32_t k = 0; k < 64; k++) bref |= (uint64_t)((v[k] & 4) != 0) << k;
       if (b != bref) errors++;
       if (zh_readfirstlane(x) != v[0]) errors++;
+      if (zh_row_shr<1>(x) != v[(lane & 15) >= 1 ? lane - 1 : lane]) errors++;
+      if (zh_row_shr<4>(x) != v[(lane & 15) >= 4 ? lane - 4 : lane]) errors++;
+      if (zh_row_shl<1>(x) != v[(lane & 15) + 1 < 16 ? lane + 1 : lane]) errors++;
+      if (zh_row_shl<2>(x) != v[(lane & 15) + 2 < 16 ? lane + 2 : lane]) errors++;
       zh_sync();
    }
    // RFC 1951 symbol arithmetic against first principles
@@ -171,6 +177,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_work);
    (void)hipFree(c->d_results);
    (void)hipFree(c->d_payload);
+   (void)hipFree(c->d_prof);
    if (c->h_payload) (void)hipHostFree(c->h_payload);
    for (int i = 0; i < 8; i++)
       if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -259,8 +266,12 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    ZH_LAUNCH(zh_mf_group, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, c->d_sort_a, c->d_sort_b,
              c->sort_stride);
    ZH_CHECK(c, hipEventRecord(c->ev[6], st));
-   ZH_LAUNCH(zh_mf_frontier, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const uint32_t *)c->d_sort_a,
-             c->sort_stride, c->d_match, c->match_stride);
+   if (c->W <= ZH_MF_LDS_WINDOW)
+      ZH_LAUNCH(zh_mf_frontier<true>, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks,
+                (const uint32_t *)c->d_sort_a, c->sort_stride, c->d_match, c->match_stride);
+   else
+      ZH_LAUNCH(zh_mf_frontier<false>, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks,
+                (const uint32_t *)c->d_sort_a, c->sort_stride, c->d_match, c->match_stride);
    ZH_CHECK(c, hipEventRecord(c->ev[2], st));
 
    // stage 2: greedy token chain + splitter
@@ -286,7 +297,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
              (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work);
    ZH_LAUNCH(zh_encode, nsubs, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const zh_match_t *)c->d_match, c->match_stride,
              (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_best, c->best_stride, c->d_payload,
-             c->d_results);
+             c->d_results, c->profile ? c->d_prof : (uint64_t *)NULL);
    ZH_CHECK(c, hipEventRecord(c->ev[4], st));
 
    c->results.resize(nsubs);
@@ -321,6 +332,24 @@ extern "C" const uint8_t *zultra_hip_payload(const zultra_hip_ctx_t *c, size_t *
 }
 extern "C" void zultra_hip_last_timing(const zultra_hip_ctx_t *c, zultra_hip_timing_t *t) {
    if (c && t) *t = c->timing;
+}
+
+extern "C" int zultra_hip_set_profile(zultra_hip_ctx_t *c, int enable) {
+   if (!c) return -1;
+   if (enable && !c->d_prof) {
+      ZH_CHECK(c, hipSetDevice(c->device));
+      ZH_CHECK(c, hipMalloc((void **)&c->d_prof, (size_t)c->max_blocks * ZH_MAX_SPLITS * 16 * sizeof(uint64_t)));
+   }
+   c->profile = enable;
+   return 0;
+}
+
+extern "C" int zultra_hip_get_profile(zultra_hip_ctx_t *c, uint64_t *out, uint32_t max_subblocks) {
+   if (!c || !c->d_prof) return -1;
+   uint32_t n = c->nsubs < max_subblocks ? c->nsubs : max_subblocks;
+   ZH_CHECK(c, hipSetDevice(c->device));
+   ZH_CHECK(c, hipMemcpy(out, c->d_prof, (size_t)n * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+   return (int)n;
 }
 
 extern "C" int zultra_hip_get_matches(zultra_hip_ctx_t *c, uint32_t block, uint16_t *out) {

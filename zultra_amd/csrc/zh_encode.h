@@ -8,11 +8,12 @@
 // alternative tables, the 20-way search over code-length RLE masks, header and token emission.
 //
 // Mapping onto a CDNA4 wave:
-//  * optimal parse: the recurrence is serial in the position, so the 64 lanes are spread over the candidates
-//    of ONE position: lane = (match slot m: 0..7) x (length phase s: 0..7); lane (m,s) prices lengths
-//    len_m - s, len_m - s - 8, ...; one DPP/readlane min-reduction per position picks the winner with the
-//    reference's tie rule folded into the key (cost, slot, longest-first). Costs live in a 512-entry LDS ring,
-//    match rows are staged 64 positions at a time with coalesced loads.
+//  * optimal parse: the recurrence is serial in the position, but the match candidates of positions i, i-1, i-2
+//    only read cost[>= i+1]; so each step prices THREE positions, one per 16-lane DPP row. Candidates collapse to
+//    one per length (cheapest eligible distance, found by a prefix-min when a tile of 63 positions is staged), so a
+//    row's 16 lanes cover lengths 3..18 in one go; one row-wise DPP min picks each row's winner with the reference's
+//    tie rule in the key (cost, slot, longest-first); the three literal-vs-match decisions chain on the scalar unit.
+//    Costs live in a 512-entry LDS ring; match rows arrive with coalesced loads issued one tile ahead.
 //  * every forward walk over the chosen parse (histogram, literalisation, emission) follows the token chain on
 //    the scalar unit (v_readlane over a 64-position tile held in one VGPR) and lets the token lanes work in
 //    parallel; emission gets its bit offsets from a wave prefix sum and ORs 48-bit token codes into an LDS
@@ -40,6 +41,8 @@ struct zh_enc_ws_t {
    int32_t cost[512];                // ring of cost[i & 511] (the reference's cost[] at blockdeflate.c:255)
    uint32_t tile[64 * ZH_NMATCH];    // staged match rows: len(9) | dist symbol(5)<<9 | offset<<16
    uint32_t best_tile[64];
+   uint32_t npos[64];                // per staged position: number of long slots | longest short length << 4
+   uint8_t bo[64 * 40];              // per staged position and length k-3: cheapest distance price << 3 | slot
    uint32_t obuf[ZH_OBUF_WORDS];
    zh_huff_scratch_t sc;
    zh_cl_t cl;
@@ -59,87 +62,202 @@ __device__ inline void zh_refresh_prices_wave(zh_enc_ws_t *ws) {
 }
 
 // ---- backward optimal parse (blockdeflate.c:254-323) ----------------------------------------------------
+// cost[i] = min(literal(i) + cost[i+1], min over match slots m and lengths k of len(k) + dist(m) + cost[i+k]).
+//
+// Two observations shape the kernel (a lone wave issues ~1 instruction per 4-5 clocks, so the instruction count per
+// position is what matters, not LDS latency):
+//  1. Per length k only the cheapest distance among the slots that reach k can win, and with the reference's order
+//     (slot ascending, then length descending, strict improvement) the winner is the lexicographic minimum of
+//     (cost, slot, -k). So the candidates of a position collapse to one per length: while a tile of 63 positions is
+//     staged (off the serial path) every position gets a byte table bo[k-3] = (cheapest distance price << 3 | slot)
+//     for k = 3..39, built with a prefix-min over its slots. Slots stored with length >= 40 are only ever tried at
+//     their full (end-clamped) length (blockdeflate.c:286-297); they keep their own entries ("long slots").
+//  2. The match part of positions i, i-1, i-2 only needs cost[>= i+1] (k >= 3), so three positions are priced per
+//     step, one per 16-lane DPP row (row 3 idles): lane s of a row prices k = 3+s (and 19+s, 35+s when the position
+//     reaches that far), one row-wise DPP min yields each row's winner, and the three literal-vs-match decisions
+//     chain on the scalar unit.
+#define ZH_DP_TILE 63   // positions staged per tile (21 triples)
+#define ZH_DP_BO 40     // bytes of per-length table per position (k = 3..39 -> 37 used)
+
+// Global loads of one tile (8 match-row dwords per lane + the lane's byte), issued together so that their latency
+// overlaps the 21 steps of the previous tile. Lane l owns slot (l & 7) of positions base + q*8 + (l >> 3).
+struct zh_dp_regs_t {
+   uint32_t raw[ZH_NMATCH];
+   uint32_t byte;
+};
+__device__ __forceinline__ void zh_dp_fetch(zh_dp_regs_t &r, const uint8_t *win, const uint32_t *rows, uint32_t prev, int64_t base,
+                                            int64_t lo, uint32_t lane) {
+#pragma unroll
+   for (uint32_t q = 0; q < ZH_NMATCH; q++) {
+      const uint32_t idx = q * 64 + lane;
+      const int64_t pos = base + (idx >> 3);
+      const bool ok = idx < ZH_DP_TILE * ZH_NMATCH && pos >= lo;
+      const int64_t cp = ok ? pos : lo;                       // clamped address: the load is always legal
+      const uint32_t v = rows[(uint64_t)(cp - prev) * ZH_NMATCH + (idx & 7)];
+      r.raw[q] = ok ? v : 0;
+   }
+   const int64_t bp = base + lane;
+   const bool okb = lane < ZH_DP_TILE && bp >= lo;
+   const uint32_t bv = win[okb ? bp : lo];
+   r.byte = okb ? bv : 0x100u;
+}
+
 __device__ inline void zh_optimal_parse_wave(zh_enc_ws_t *ws, const uint8_t *win, const uint32_t *rows /* row r = pos - prev */,
-                                             uint32_t prev, uint32_t start, uint32_t end, uint32_t *best_out /* index = pos - prev */) {
+                                             uint32_t prev, uint32_t start, uint32_t end, uint32_t *best_out /* index = pos - prev */,
+                                             uint64_t *loop_clocks = nullptr) {
    const uint32_t lane = zh_lane();
-   const uint32_t m = lane >> 3, s = lane & 7;
+   const uint32_t row = lane >> 4, s = lane & 15;
+   uint64_t loop_acc = 0;
    if (end <= start) return;
    zh_refresh_prices_wave(ws);
+   // this lane's length prices: k = 3+s, 19+s, 35+s
+   const uint32_t lc0 = ws->lencost[s], lc1 = ws->lencost[16 + s], lc2 = ws->lencost[32 + (s & 7)];
 
-   int32_t cost_next = 0;   // cost[i+1], wave-uniform
+   int32_t cost_next = 0;   // cost[top+1], wave-uniform
    if (lane == 0) ws->cost[end & 511] = 0;
    zh_sync();
 
-   const uint32_t first_tile = start & ~63u;
-   for (uint32_t tb = (end - 1) & ~63u;; tb -= 64) {
-      // stage the match rows and literal prices of positions [tb, tb+64) that lie inside [start, end)
-      for (uint32_t q = 0; q < ZH_NMATCH; q++) {
-         uint32_t idx = q * 64 + lane;
-         uint32_t pos = tb + (idx >> 3);
-         uint32_t e = 0;
-         if (pos >= start && pos < end) {
-            uint32_t raw = rows[(uint64_t)(pos - prev) * ZH_NMATCH + (idx & 7)];
-            uint32_t len = raw & 0xffffu, off = raw >> 16;
-            if (len >= ZH_MIN_MATCH) e = len | ((uint32_t)zh_dist_sym(off) << 9) | (off << 16);
-         }
-         ws->tile[idx] = e;
-      }
-      uint32_t litcost = 0;
-      {
-         uint32_t pos = tb + lane;
-         if (pos >= start && pos < end) litcost = ws->lit_len[win[pos]];
-      }
-      zh_sync();
-
-      const uint32_t hi = min(end - 1, tb + 63), lo = max(start, tb);
-      for (uint32_t i = hi;; i--) {
-         const uint32_t e = ws->tile[(i - tb) * ZH_NMATCH + m];
-         const uint32_t len = e & 511u;
-         uint32_t key = 0xFFFFFFFFu;
-         if (len >= ZH_MIN_MATCH) {
-            const uint32_t mlen = min(len, end - i);          // end clamp (blockdeflate.c:283-284)
-            const uint32_t oc = ws->distcost[(e >> 9) & 31u];
-            if (len >= ZH_LEAVE_ALONE) {
-               if (s == 0) {
-                  uint32_t enc = mlen - ZH_MIN_MATCH;           // wraps below 3, then saturates (:289, :216-219)
-                  if (enc > 255) enc = 255;
-                  uint32_t c = (uint32_t)ws->lencost[enc] + oc + (uint32_t)ws->cost[(i + mlen) & 511];
-                  key = (c << 9) | (m << 6);
-               }
-            }
-            else {
-               for (int k = (int)mlen - (int)s; k >= ZH_MIN_MATCH; k -= 8) {
-                  uint32_t c = (uint32_t)ws->lencost[k - ZH_MIN_MATCH] + oc + (uint32_t)ws->cost[(i + (uint32_t)k) & 511];
-                  uint32_t kk = (c << 9) | (m << 6) | (mlen - (uint32_t)k);
-                  key = min(key, kk);
-               }
-            }
-         }
-         const uint32_t kmin = zh_wave_min(key);
-         const int32_t lit = (int32_t)zh_readlane(litcost, (int)(i - tb)) + cost_next;
-         int32_t newcost = lit;
-         uint32_t pick = 0;
-         if (kmin != 0xFFFFFFFFu && (int32_t)(kmin >> 9) < lit) {   // strictly cheaper than the literal (:292,:307)
-            const uint32_t e2 = ws->tile[(i - tb) * ZH_NMATCH + ((kmin >> 6) & 7u)];
-            const uint32_t mlen2 = min(e2 & 511u, end - i);
-            newcost = (int32_t)(kmin >> 9);
-            pick = (mlen2 - (kmin & 63u)) | (e2 & 0xffff0000u);
-         }
-         if (lane == 0) {
-            ws->cost[i & 511] = newcost;
-            ws->best_tile[i - tb] = pick;
-         }
-         cost_next = newcost;
-         if (i == lo) break;
-      }
-      zh_sync();
-      {
-         uint32_t pos = tb + lane;
-         if (pos >= start && pos < end) best_out[pos - prev] = ws->best_tile[lane];
-      }
-      zh_sync();
-      if (tb == first_tile) break;
+   zh_dp_regs_t regs;
+   {
+      const int64_t hi0 = (int64_t)end - 1, base0 = hi0 - (ZH_DP_TILE - 1);
+      zh_dp_fetch(regs, win, rows, prev, base0, base0 > (int64_t)start ? base0 : (int64_t)start, lane);
    }
+
+   for (int64_t hi = (int64_t)end - 1; hi >= (int64_t)start; hi -= ZH_DP_TILE) {
+      const int64_t base64 = hi - (ZH_DP_TILE - 1);                     // tile index a <-> window position base + a
+      const int32_t base = (int32_t)base64;
+      const int32_t alo = base64 >= (int64_t)start ? 0 : (int32_t)((int64_t)start - base64);   // first tile index in range
+      const int32_t rb = (int32_t)end - base;                           // room of tile index a = rb - a
+
+      // ---- stage the tile: per-slot entries, per-length tables, per-position summaries ---------------------------
+      const uint32_t m8 = lane & 7;
+#pragma unroll
+      for (uint32_t q = 0; q < ZH_NMATCH; q++) {
+         const uint32_t a = q * 8 + (lane >> 3);
+         const uint32_t raw = regs.raw[q];
+         const uint32_t len = raw & 0xffffu, off = raw >> 16;
+         const bool valid = len >= ZH_MIN_MATCH;
+         const bool is_long = len >= ZH_LEAVE_ALONE;
+         const uint32_t oc = valid ? (uint32_t)ws->distcost[zh_dist_sym(off)] : 31u;
+         // inclusive prefix-min over the SHORT slots 0..m of this position of (price << 3 | slot): DPP row shifts
+         uint32_t pm = (valid && !is_long) ? ((oc << 3) | m8) : 0xFFu;
+         {
+            const uint32_t o1 = zh_row_shr<1>(pm);
+            if (m8 >= 1) pm = min(pm, o1);
+            const uint32_t o2 = zh_row_shr<2>(pm);
+            if (m8 >= 2) pm = min(pm, o2);
+            const uint32_t o4 = zh_row_shr<4>(pm);
+            if (m8 >= 4) pm = min(pm, o4);
+         }
+         const uint32_t nxt = zh_row_shl<1>(len);                            // length stored in slot m+1
+         const uint32_t below = (m8 < 7 && nxt >= ZH_MIN_MATCH) ? nxt : 2u;  // lengths <= below belong to later slots
+         const uint64_t longmask = zh_ballot(is_long);
+         const uint64_t validmask = zh_ballot(valid);
+         if (a < ZH_DP_TILE) {
+            ws->tile[a * ZH_NMATCH + m8] = valid ? (len | (oc << 9) | (off << 16)) : 0;
+            if (valid && !is_long)
+               for (uint32_t k = below + 1; k <= len; k++) ws->bo[a * ZH_DP_BO + k - 3] = (uint8_t)pm;
+            if (m8 == 0) {
+               const uint32_t nlong = (uint32_t)__popc((uint32_t)((longmask >> (lane & 56u)) & 0xffu));     // long slots are a prefix
+               const uint32_t nvalid = (uint32_t)__popc((uint32_t)((validmask >> (lane & 56u)) & 0xffu));
+               ws->npos[a] = nlong | (nvalid << 4);
+            }
+         }
+      }
+      zh_sync();
+      for (uint32_t a = lane; a < ZH_DP_TILE; a += 64) {
+         const uint32_t info = ws->npos[a];
+         const uint32_t nlong = info & 15u, nvalid = info >> 4;
+         const uint32_t kmax = nvalid > nlong ? (ws->tile[a * ZH_NMATCH + nlong] & 511u) : 0u;   // longest short length
+         ws->npos[a] = nlong | (kmax << 4);
+      }
+      const uint32_t litcost = regs.byte < 256 ? ws->lit_len[regs.byte] : 0;
+      zh_sync();
+      // start the next tile's loads now; they complete while this tile is priced
+      if (base64 - 1 >= (int64_t)start) {
+         const int64_t nbase = base64 - ZH_DP_TILE;
+         zh_dp_fetch(regs, win, rows, prev, nbase, nbase > (int64_t)start ? nbase : (int64_t)start, lane);
+      }
+
+      // ---- price the tile, three positions per step ---------------------------------------------------------------
+      const uint64_t t_loop = loop_clocks ? zh_clock() : 0;
+      const uint32_t cb = (uint32_t)base + 3 + s;          // cost index of this lane's first length: (cb + a) & 511
+      const bool row_ok = row < 3;
+      for (int32_t t = ZH_DP_TILE - 1; t >= alo; t -= 3) {
+         const int32_t a = t - (int32_t)row;
+         const bool active = row_ok && a >= alo;
+         uint32_t key = 0xFFFFFFFFu;
+         uint32_t info = 0, kmax = 0;
+         if (active) {
+            info = ws->npos[a];
+            kmax = min(info >> 4, (uint32_t)(rb - a));              // end clamp (blockdeflate.c:283-284)
+            if (3 + s <= kmax) {
+               const uint32_t b = ws->bo[(uint32_t)a * ZH_DP_BO + s];
+               const uint32_t c = lc0 + (b >> 3) + (uint32_t)ws->cost[(cb + (uint32_t)a) & 511];
+               key = (c << 9) | ((b & 7u) << 6) | (36u - s);        // 39 - k
+            }
+         }
+         // rarely needed parts: lengths 19..39, and slots stored with length >= 40
+         if (zh_ballot(kmax > 18u || (info & 15u) != 0)) {
+            if (active) {
+               const uint32_t room = (uint32_t)(rb - a);
+               if (19 + s <= kmax) {
+                  const uint32_t b = ws->bo[(uint32_t)a * ZH_DP_BO + 16 + s];
+                  const uint32_t c = lc1 + (b >> 3) + (uint32_t)ws->cost[(cb + 16 + (uint32_t)a) & 511];
+                  key = min(key, (c << 9) | ((b & 7u) << 6) | (20u - s));
+               }
+               if (s < 5 && 35 + s <= kmax) {
+                  const uint32_t b = ws->bo[(uint32_t)a * ZH_DP_BO + 32 + s];
+                  const uint32_t c = lc2 + (b >> 3) + (uint32_t)ws->cost[(cb + 32 + (uint32_t)a) & 511];
+                  key = min(key, (c << 9) | ((b & 7u) << 6) | (4u - s));
+               }
+               if (s < (info & 15u)) {                              // long slot s: full (clamped) length only
+                  const uint32_t e = ws->tile[(uint32_t)a * ZH_NMATCH + s];
+                  const uint32_t mlen = min(e & 511u, room);
+                  uint32_t enc = mlen - ZH_MIN_MATCH;               // wraps below 3, then saturates (:289, :216-219)
+                  if (enc > 255) enc = 255;
+                  const uint32_t c = (uint32_t)ws->lencost[enc] + ((e >> 9) & 31u) +
+                                     (uint32_t)ws->cost[((uint32_t)base + (uint32_t)a + mlen) & 511];
+                  key = min(key, (c << 9) | (s << 6));
+               }
+            }
+         }
+         const uint32_t rkey = zh_row_min(key);   // every lane of a row now holds that row's best match candidate
+         // literal first; a match must be strictly cheaper (:292,:307). An absent candidate (all ones) prices at 2^23-1.
+         const int32_t m0 = (int32_t)(zh_readlane(rkey, 0) >> 9), m1 = (int32_t)(zh_readlane(rkey, 16) >> 9),
+                       m2 = (int32_t)(zh_readlane(rkey, 32) >> 9);
+         const int32_t l0 = (int32_t)zh_readlane(litcost, t) + cost_next;
+         const int32_t c0 = min(l0, m0);
+         const int32_t l1 = (int32_t)zh_readlane(litcost, (t - 1) & 63) + c0;
+         const int32_t c1 = min(l1, m1);
+         const int32_t l2 = (int32_t)zh_readlane(litcost, (t - 2) & 63) + c1;
+         const int32_t c2 = min(l2, m2);
+         if (active && s == 0) {
+            const int32_t myc = row == 0 ? c0 : (row == 1 ? c1 : c2);
+            const int32_t myl = row == 0 ? l0 : (row == 1 ? l1 : l2);
+            ws->cost[((uint32_t)base + (uint32_t)a) & 511] = myc;
+            ws->best_tile[a] = (myc < myl) ? rkey : 0xFFFFFFFFu;   // decoded when the tile is flushed
+         }
+         cost_next = (t - 2 >= alo) ? c2 : ((t - 1 >= alo) ? c1 : c0);
+         zh_ballot(true);   // orders the LDS cost writes before the next step's reads (free in lock-step on the GPU)
+      }
+      if (loop_clocks) loop_acc += zh_clock() - t_loop;
+      zh_sync();
+      // flush: decode the winning (slot, length) of each position and store the parse
+      if ((int32_t)lane < ZH_DP_TILE && (int32_t)lane >= alo) {
+         const uint32_t kk = ws->best_tile[lane];
+         uint32_t pick = 0;
+         if (kk != 0xFFFFFFFFu) {
+            const uint32_t m = (kk >> 6) & 7u;
+            const uint32_t e = ws->tile[lane * ZH_NMATCH + m];
+            const uint32_t len = (m < (ws->npos[lane] & 15u)) ? min(e & 511u, (uint32_t)(rb - (int32_t)lane)) : (39u - (kk & 63u));
+            pick = len | (e & 0xffff0000u);
+         }
+         best_out[(uint32_t)(base + (int32_t)lane) - prev] = pick;
+      }
+      zh_sync();
+   }
+   if (loop_clocks && lane == 0) *loop_clocks = loop_acc;
 }
 
 // ---- histogram of the chosen parse (blockdeflate.c:371-400) ---------------------------------------------
@@ -327,7 +445,7 @@ struct zh_work_t {
 __global__ void __launch_bounds__(64)
 zh_encode(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match,
           uint64_t match_stride, const uint16_t *__restrict__ tok_info, uint64_t tok_stride, const zh_work_t *__restrict__ work,
-          uint32_t *best_all, uint64_t best_stride, uint8_t *payload, zh_subblock_t *results) {
+          uint32_t *best_all, uint64_t best_stride, uint8_t *payload, zh_subblock_t *results, uint64_t *prof) {
    __shared__ zh_enc_ws_t ws;
    const zh_work_t wk = work[blockIdx.x];
    const zh_block_t blk = blocks[wk.block];
@@ -340,6 +458,12 @@ zh_encode(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ block
    const uint32_t cap_bits = wk.out_cap * 8;
    const uint32_t start = wk.start, end = wk.start + wk.size;
    const uint32_t lane = zh_lane();
+   // optional phase profile: 16 shader-clock stamps per sub-block (prof == NULL in normal runs)
+#define ZH_STAMP(k)                                                       \
+   do {                                                                   \
+      if (prof && lane == 0) prof[(uint64_t)wk.index * 16 + (k)] = zh_clock(); \
+   } while (0)
+   ZH_STAMP(0);
 
    // ---- libzultra.c:317-324: greedy histogram, static price, dynamic price -------------------------------
    for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws.lit_freq[s] = 0;
@@ -360,6 +484,7 @@ zh_encode(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ block
    const int dynamic_cost = zh_dynamic_cost_wave(ws.lit_freq, ws.dist_freq, ws.lit_len, ws.dist_len, ws.lens, &ws.cl, &ws.tmp,
                                                  &ws.sc, true);
    const uint32_t is_dynamic = (static_cost <= dynamic_cost) ? 0u : 1u;
+   ZH_STAMP(1);
 
    uint32_t failed = 0;
    uint32_t bitpos = 0;
@@ -377,14 +502,16 @@ zh_encode(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ block
       // ---- blockdeflate.c:859-920: the greedy histogram is still in place -----------------------------------
       if (zh_huff_build_wave(ws.lit_freq, ws.lit_len, ws.lit_code, ZH_NLIT, 15, &ws.sc) < 0) failed = 1;
       if (zh_huff_build_wave(ws.dist_freq, ws.dist_len, ws.dist_code, ZH_NDIST, 15, &ws.sc) < 0) failed = 1;
+      ZH_STAMP(2);
       for (int pass = 0; pass <= 3; pass++) {
          for (uint32_t s = lane; s < ZH_NLIT; s += 64)
             if (!ws.lit_len[s]) ws.lit_len[s] = 9;
          if (lane < ZH_NDIST && !ws.dist_len[lane]) ws.dist_len[lane] = 6;
          zh_sync();
-         zh_optimal_parse_wave(&ws, win, rows, prev, start, end, best);
+         zh_optimal_parse_wave(&ws, win, rows, prev, start, end, best, (prof && pass == 3) ? &prof[(uint64_t)wk.index * 16 + 15] : nullptr);
          __threadfence_block();
          zh_sync();
+         ZH_STAMP(3 + 2 * pass);
          zh_parse_histogram_wave(&ws, win, prev, start, end, best);
          if (pass == 3 && lane == 0) {
             int used = 0;
@@ -402,9 +529,11 @@ zh_encode(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ block
          zh_sync();
          if (zh_huff_build_wave(ws.lit_freq, ws.lit_len, ws.lit_code, ZH_NLIT, 15, &ws.sc) < 0) failed = 1;
          if (zh_huff_build_wave(ws.dist_freq, ws.dist_len, ws.dist_code, ZH_NDIST, 15, &ws.sc) < 0) failed = 1;
+         ZH_STAMP(4 + 2 * pass);
       }
 
       zh_literalize_wave(&ws, win, prev, start, end, best);   // histograms stay as they were (:923)
+      ZH_STAMP(11);
 
       // ---- blockdeflate.c:925-945: RLE-friendlier alternative ------------------------------------------------
       {
@@ -435,6 +564,7 @@ zh_encode(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ block
          zh_sync();
       }
 
+      ZH_STAMP(12);
       // ---- blockdeflate.c:947-992: header ---------------------------------------------------------------------
       const int nlit = zh_defined_count(ws.lit_len, ZH_NLIT, 257);
       const int ndist = zh_defined_count(ws.dist_len, ZH_NDIST, 1);
@@ -490,9 +620,11 @@ zh_encode(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ block
 
    __threadfence_block();
    zh_sync();
+   ZH_STAMP(13);
    uint32_t nbits = 0;
    if (!failed) nbits = zh_emit_tokens_wave(&ws, win, prev, start, end, best, out, cap_bits, bitpos);
    if (nbits > cap_bits) failed = 1;   // outgrew the slot: the stitcher stores the sub-block instead
+   ZH_STAMP(14);
 
    if (lane == 0) {
       zh_subblock_t r;

@@ -123,21 +123,41 @@ __device__ __forceinline__ uint32_t zh_trigram(const uint8_t *p) {
    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 }
 
+// LDS_WIN: the whole window (<= ZH_MF_LDS_WINDOW bytes: 64 KiB max-blocks + 32 KiB history) is staged in LDS once
+// per workgroup with coalesced dword loads, so the byte probes of the scan hit the 160 KiB LDS instead of L1/L2.
+#define ZH_MF_LDS_WINDOW 98304
+
+template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
 zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
                const uint32_t *__restrict__ sorted, uint64_t sort_stride, zh_match_t *match,
                uint64_t match_stride) {
    __shared__ uint32_t next_chunk;
+   __shared__ uint32_t lwin32[LDS_WIN ? (ZH_MF_LDS_WINDOW / 4 + 4) : 1];
 
    const zh_block_t blk = blocks[blockIdx.x];
-   const uint8_t *win = data + blk.win_off;
+   const uint8_t *gwin = data + blk.win_off;
    const uint32_t prev = blk.prev;
    const uint32_t W = blk.prev + blk.n;
    const uint32_t M = W >= 3 ? W - 2 : 0;
    const uint32_t *S = sorted + (uint64_t)blockIdx.x * sort_stride;
    zh_match_t *rows = match + (uint64_t)blockIdx.x * match_stride;   // row r = block position prev + r
    const uint32_t lane = threadIdx.x & 63;
+   const uint8_t *win = gwin;
 
+   if (LDS_WIN) {
+      uint8_t *lw = (uint8_t *)lwin32;
+      if ((((uintptr_t)gwin) & 3u) == 0) {
+         const uint32_t *g32 = (const uint32_t *)gwin;
+         const uint32_t nw = W >> 2;
+         for (uint32_t k = threadIdx.x; k < nw; k += ZH_MF_THREADS) lwin32[k] = g32[k];
+         for (uint32_t k = (nw << 2) + threadIdx.x; k < W; k += ZH_MF_THREADS) lw[k] = gwin[k];
+      }
+      else {
+         for (uint32_t k = threadIdx.x; k < W; k += ZH_MF_THREADS) lw[k] = gwin[k];
+      }
+      win = lw;
+   }
    if (threadIdx.x == 0) next_chunk = 0;
    __syncthreads();
 

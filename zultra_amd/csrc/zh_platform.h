@@ -38,6 +38,16 @@ __device__ __forceinline__ uint32_t zh_dpp(uint32_t v) {
    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
 }
 
+// value of lane (l - N) / (l + N) of the same 16-lane DPP row; lanes without such a neighbour keep their own value
+template <int N>
+__device__ __forceinline__ uint32_t zh_row_shr(uint32_t v) {
+   return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x110 + N, 0xF, 0xF, false);
+}
+template <int N>
+__device__ __forceinline__ uint32_t zh_row_shl(uint32_t v) {
+   return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x100 + N, 0xF, 0xF, false);
+}
+
 // minimum over each 16-lane DPP row, result in every lane of the row (4 DPP steps, no LDS traffic)
 __device__ __forceinline__ uint32_t zh_row_min(uint32_t v) {
    v = min(v, zh_dpp<ZH_DPP_QUAD_XOR1>(v));
@@ -73,6 +83,9 @@ __device__ __forceinline__ uint32_t zh_wave_excl_sum(uint32_t v) {
    }
    return x - v;
 }
+
+// shader-clock stamp for the optional in-kernel phase profile (diagnostics only)
+__device__ __forceinline__ uint64_t zh_clock() { return (uint64_t)clock64(); }
 
 // LDS visibility between the lanes of a workgroup (a single wave for the 64-thread kernels)
 __device__ __forceinline__ void zh_sync() { __syncthreads(); }
