@@ -4,7 +4,8 @@ enwik8-sized text (config[1]); one JSON line on rank 0.
 
 A "step" = one pass of the whole job over this rank's 100 MB shard, input already resident in HBM:
    stage 1-3 kernels (match rows, token chain + splitter, per-sub-block encode) -> per-sub-block bit strings
-   -> D2H -> host stitch at the shard's true bit offset (+ for N>1: descriptor all-gather and byte gather over RCCL)
+   -> device stitch (zh_stitch) at the shard's true bit offset, per-block CRC-32 on the device (zh_crc32_blocks)
+   -> (N>1: descriptor all-gather and byte gather over RCCL) -> D2H of the finished deflate bytes on rank 0
    -> gzip stream on rank 0 (header, deflate bits, CRC-32/ISIZE footer).
 N>1 is weak scaling: every rank compresses its own 100 MB shard of one N x 100 MB stream.
 
@@ -114,7 +115,7 @@ def main():
     torch.cuda.synchronize()
     ctx = L.context(bs, nblocks, device=local_rank)
 
-    class FakeDist:   # N == 1: same code path without a process group
+    class OneRank:   # N == 1: same code path without a process group
         @staticmethod
         def get_rank():
             return 0
@@ -123,26 +124,18 @@ def main():
         def get_world_size():
             return 1
 
-        @staticmethod
-        def all_reduce(t):
-            return None
-
-        @staticmethod
-        def all_gather(lst, t):
-            lst[0].copy_(t)
-
-        @staticmethod
-        def gather(t, lst, dst=0):
-            lst[0].copy_(t)
-
-    D = dist if world > 1 else FakeDist
+    D = dist if world > 1 else OneRank
     timings = []
 
     def step():
         ctx.compress_blocks(d_data.data_ptr(), blocks, data_on_device=True, data_size=d_data.numel())
         timings.append(ctx.timing())
-        body, info = sharded.assemble(L, ctx, shard, raw_offs, bs, D, torch, device, is_stream_end_rank=(rank == world - 1))
-        crc = L.checksum(shard, flags)   # gzip footer needs CRC-32 of the input (host, frame.c:324-354)
+        # gzip footer CRC-32: per-max-block values computed on the device next to the compression, folded on the host
+        crc = 0
+        for lin, (_, _, nb) in zip(ctx.block_crc32(), blocks):
+            crc = L.crc32_append(crc, lin, nb)
+        body, info = sharded.assemble(L, ctx, bs, D, torch, device, is_stream_end_rank=(rank == world - 1), nblocks_local=nblocks)
+        timings[-1]["stitch_ms"] = ctx.timing()["stitch_ms"]
         return body, crc
 
     def barrier():
@@ -170,7 +163,8 @@ def main():
         # per-kernel device times (HIP events on the library stream), averaged over the timed steps
         avg = {k: float(np.mean([t[k] for t in timings])) for k in timings[0]}
         kernels = {"zh_mf_group": avg["group_ms"], "zh_mf_frontier": avg["frontier_ms"],
-                   "zh_tokenize+zh_split": avg["tokenize_split_ms"], "zh_plan_subblocks+zh_encode": avg["encode_ms"]}
+                   "zh_tokenize+zh_split": avg["tokenize_split_ms"], "zh_plan_subblocks+zh_encode": avg["encode_ms"],
+                   "zh_stitch": avg["stitch_ms"]}
         dom = max(kernels, key=kernels.get)
         out_bytes = len(body) / world
         alg_bytes = n + out_bytes   # 1 B read + r B written per input byte
@@ -195,6 +189,7 @@ def main():
         import zlib
         hdr = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 2, 255])
         footer = int(crc).to_bytes(4, "little") + int(n & 0xffffffff).to_bytes(4, "little")
+        body = body.tobytes()
         if world == 1:
             gz = hdr + body + footer
             ok = zlib.decompress(gz, 31) == shard.tobytes()

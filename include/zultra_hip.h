@@ -55,7 +55,7 @@ typedef struct zultra_hip_subblock_s {
 /* Timings of the last batch, milliseconds, measured with HIP events on the context's stream. */
 typedef struct zultra_hip_timing_s {
    float h2d_ms, matchfinder_ms, tokenize_split_ms, encode_ms, d2h_ms, total_ms;
-   float group_ms, frontier_ms;
+   float group_ms, frontier_ms, stitch_ms;
 } zultra_hip_timing_t;
 
 /* Number of usable HIP devices (0 if none). */
@@ -123,6 +123,24 @@ size_t zultra_hip_stitch(zultra_hip_bitstate_t *state, const zultra_hip_subblock
                          const uint8_t *payload, const uint8_t *raw, const uint64_t *raw_off, uint32_t max_block_size,
                          int final_block, uint8_t *out, size_t out_cap);
 size_t zultra_hip_stitch_finish(zultra_hip_bitstate_t *state, uint8_t *out, size_t out_cap);
+
+/*
+ * Stitcher (device): same result as zultra_hip_stitch for the last batch, but the phase-dependent decisions are planned
+ * on the host from the 48-byte descriptors only and the bits are moved by a kernel; the stream stays in HBM.
+ *   state->nacc : pending bits (0..7) before the batch; updated to the pending bits after it (state->acc is not used:
+ *                 the caller ORs its pending bits into byte 0 of the result, and reads the new partial byte back).
+ *   *end_bit    : bits from the start of byte 0 to the end of the batch; the buffer holds ceil(end_bit/8) bytes.
+ * Returns 0, -2 where the reference fails with ZULTRA_ERROR_DST, -1 on HIP errors.
+ */
+int zultra_hip_stitch_device(zultra_hip_ctx_t *ctx, zultra_hip_bitstate_t *state, int final_block, uint64_t *end_bit);
+const void *zultra_hip_stream_device(const zultra_hip_ctx_t *ctx);
+int zultra_hip_stream_read(zultra_hip_ctx_t *ctx, void *out, size_t offset, size_t nbytes);
+
+/* CRC-32 of every max-block of the last batch, computed on the device while the blocks are compressed: out[b] is the
+ * linear part (zero initial state, no final inversion). zultra_crc32_append() folds one block into a running gzip CRC
+ * exactly as zultra_frame_update_checksum(crc, block, len, GZIP) would (reference src/frame.c:324-354,473-480). */
+int zultra_hip_block_crc32(const zultra_hip_ctx_t *ctx, uint32_t *out);
+uint32_t zultra_crc32_append(uint32_t crc, uint32_t block_linear_crc, size_t block_len);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ class SubBlock(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [(k, C.c_float) for k in ("h2d_ms", "matchfinder_ms", "tokenize_split_ms", "encode_ms", "d2h_ms", "total_ms",
-                                         "group_ms", "frontier_ms")]
+                                         "group_ms", "frontier_ms", "stitch_ms")]
 
 
 class BitState(C.Structure):
@@ -70,6 +70,7 @@ EXPORTS = [
     "zultra_hip_data_capacity", "zultra_hip_compress_blocks", "zultra_hip_subblocks", "zultra_hip_payload",
     "zultra_hip_last_timing", "zultra_hip_get_matches", "zultra_hip_get_splits", "zultra_hip_get_parse",
     "zultra_hip_stitch", "zultra_hip_stitch_finish", "zultra_hip_set_profile", "zultra_hip_get_profile",
+    "zultra_hip_stitch_device", "zultra_hip_stream_device", "zultra_hip_stream_read", "zultra_hip_block_crc32", "zultra_crc32_append",
 ]
 
 
@@ -160,6 +161,11 @@ class Lib:
         if start is None:
             start = self.L.zultra_frame_init_checksum(flags)
         return self.L.zultra_frame_update_checksum(start, data.ctypes.data, len(data), flags)
+
+    def crc32_append(self, crc, block_linear_crc, block_len):
+        self.L.zultra_crc32_append.argtypes = [C.c_uint32, C.c_uint32, C.c_size_t]
+        self.L.zultra_crc32_append.restype = C.c_uint32
+        return self.L.zultra_crc32_append(crc, int(block_linear_crc), block_len)
 
     def stream(self, flags, max_block=0):
         return Stream(self, flags, max_block)
@@ -307,6 +313,36 @@ class HipContext:
         if self.lib.L.zultra_hip_get_parse(self.h, block, m.ctypes.data) != 0:
             raise ZultraError("get_parse")
         return m
+
+    def stitch_device(self, final_block, phase=0):
+        """Device stitcher over the last batch -> (end_bit, new_phase); the stream stays in HBM (stream_ptr)."""
+        L = self.lib.L
+        L.zultra_hip_stitch_device.argtypes = [C.c_void_p, C.POINTER(BitState), C.c_int, C.POINTER(C.c_uint64)]
+        st = BitState(0, phase)
+        eb = C.c_uint64()
+        rc = L.zultra_hip_stitch_device(self.h, C.byref(st), final_block, C.byref(eb))
+        if rc != 0:
+            raise ZultraError("zultra_hip_stitch_device: %d %s" % (rc, L.zultra_hip_last_error(self.h).decode()))
+        return eb.value, st.nacc
+
+    def stream_ptr(self):
+        self.lib.L.zultra_hip_stream_device.argtypes = [C.c_void_p]
+        self.lib.L.zultra_hip_stream_device.restype = C.c_void_p
+        return self.lib.L.zultra_hip_stream_device(self.h)
+
+    def stream_read(self, nbytes, offset=0):
+        out = np.empty(nbytes, dtype=np.uint8)
+        self.lib.L.zultra_hip_stream_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        if self.lib.L.zultra_hip_stream_read(self.h, out.ctypes.data, offset, nbytes) != 0:
+            raise ZultraError("stream_read")
+        return out
+
+    def block_crc32(self):
+        n = len(self._blocks)
+        out = np.zeros(n, dtype=np.uint32)
+        self.lib.L.zultra_hip_block_crc32.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.L.zultra_hip_block_crc32(self.h, out.ctypes.data)
+        return out
 
     def stitch(self, raw, raw_offs, max_block, final_block, state=None, finish=True):
         """Host stitcher over the last batch -> (bytes, BitState)."""

@@ -54,6 +54,64 @@ static uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n) {
    return ~crc;
 }
 
+// ---- folding device-computed per-block CRCs into the running gzip checksum -----------------------------------------
+// With R(s, D) the raw register after feeding D from state s, R(s, D) = Z_n(s) ^ R(0, D) (n = |D|, Z_n = "feed n zero
+// bytes", linear over GF(2)); the device returns R(0, block). Z_n is kept as a 32x32 bit matrix per length.
+namespace {
+struct CrcShiftOp {
+   uint32_t col[32];   // image of each state bit
+   uint32_t apply(uint32_t v) const {
+      uint32_t r = 0;
+      for (int b = 0; v; v >>= 1, b++)
+         if (v & 1) r ^= col[b];
+      return r;
+   }
+};
+static void op_square(CrcShiftOp &dst, const CrcShiftOp &src) {
+   for (int b = 0; b < 32; b++) dst.col[b] = src.apply(src.col[b]);
+}
+static CrcShiftOp crc_shift_op(size_t nbytes) {
+   std::call_once(g_crc_once, crc_init);
+   CrcShiftOp pw, res, tmp;
+   for (int b = 0; b < 32; b++) {           // one zero byte
+      uint32_t v = 1u << b;
+      pw.col[b] = (v >> 8) ^ g_crc_tab[0][v & 0xff];
+      res.col[b] = 1u << b;                  // identity
+   }
+   for (size_t n = nbytes; n; n >>= 1) {
+      if (n & 1) {
+         for (int b = 0; b < 32; b++) tmp.col[b] = pw.apply(res.col[b]);
+         res = tmp;
+      }
+      op_square(tmp, pw);
+      pw = tmp;
+   }
+   return res;
+}
+static std::mutex g_op_mutex;
+static size_t g_op_len[4] = {0, 0, 0, 0};
+static CrcShiftOp g_op[4];
+static int g_op_next = 0;
+}   // namespace
+
+extern "C" uint32_t zultra_crc32_append(uint32_t crc, uint32_t block_linear_crc, size_t block_len) {
+   CrcShiftOp op;
+   {
+      std::lock_guard<std::mutex> lk(g_op_mutex);
+      int hit = -1;
+      for (int i = 0; i < 4; i++)
+         if (g_op_len[i] == block_len && block_len) hit = i;
+      if (hit < 0) {
+         hit = g_op_next;
+         g_op_next = (g_op_next + 1) & 3;
+         g_op[hit] = crc_shift_op(block_len);
+         g_op_len[hit] = block_len;
+      }
+      op = g_op[hit];
+   }
+   return ~(op.apply(~crc) ^ block_linear_crc);
+}
+
 // Adler-32 (frame.c:74-138): sums modulo 65521, reduced every 5552 bytes.
 static uint32_t adler32_update(uint32_t adler, const uint8_t *p, size_t n) {
    uint32_t a = adler & 0xffff, b = (adler >> 16) & 0xffff;
@@ -414,6 +472,8 @@ struct _zultra_compressor_s {
 
    std::vector<zultra_hip_block_t> blocks;
    std::vector<uint64_t> raw_off;
+   std::vector<uint32_t> crc;
+   bool host_stitch;            // ZULTRA_HIP_HOST_STITCH=1: stitch on the host (A/B checking)
 };
 
 static void *default_zalloc(void *, unsigned int items, unsigned int size) { return malloc((size_t)items * size); }
@@ -441,6 +501,10 @@ static zultra_status_t stream_init_sized(zultra_stream_t *s, unsigned flags, uns
    c->out_pos = c->out_pending = 0;
    c->frame_pos = c->frame_pending = 0;
    c->in = c->out = NULL;
+   {
+      const char *e = getenv("ZULTRA_HIP_HOST_STITCH");
+      c->host_stitch = e && atoi(e) != 0;
+   }
 
    if (!batch_blocks) {
       const char *e = getenv("ZULTRA_HIP_BATCH_BLOCKS");
@@ -522,26 +586,60 @@ static zultra_status_t compress_staged(zultra_stream_t *s, zultra_compressor_t *
       c->blocks[b].prev = prev;
       c->blocks[b].n = n;
       c->raw_off[b] = (uint64_t)b * bs;
-      // checksum once per max-block over its bytes (libzultra.c:279)
-      s->adler = zultra_frame_update_checksum(s->adler, c->in + HISTORY_SIZE + (size_t)b * bs, n, c->flags);
       consumed += n;
    }
    const size_t data_size = (size_t)c->prev + consumed;
    int nsubs = zultra_hip_compress_blocks(c->hip, c->in + base, data_size, 0, c->blocks.data(), count);
    if (nsubs <= 0) return ZULTRA_ERROR_COMPRESSION;
 
-   uint32_t cnt = 0;
-   const zultra_hip_subblock_t *subs = zultra_hip_subblocks(c->hip, &cnt);
-   size_t psize = 0;
-   const uint8_t *payload = zultra_hip_payload(c->hip, &psize);
-   size_t w = zultra_hip_stitch(&c->bitstate, subs, cnt, payload, c->in + HISTORY_SIZE, c->raw_off.data(), bs,
-                                final_last ? (int)count - 1 : -1, c->out, c->out_cap);
-   if (w == (size_t)-1) return ZULTRA_ERROR_DST;
-   if (final_last) {
-      size_t f = zultra_hip_stitch_finish(&c->bitstate, c->out + w, c->out_cap - w);
-      if (f == (size_t)-1) return ZULTRA_ERROR_DST;
-      w += f;
-      c->state |= ST_FINALIZED;
+   // checksum once per max-block over its bytes (libzultra.c:279): CRC-32 comes from the device, Adler-32 is host work
+   if (c->flags & ZULTRA_FLAG_GZIP_FRAMING) {
+      c->crc.resize(count);
+      if (zultra_hip_block_crc32(c->hip, c->crc.data()) != (int)count) return ZULTRA_ERROR_COMPRESSION;
+      for (uint32_t b = 0; b < count; b++) s->adler = zultra_crc32_append(s->adler, c->crc[b], c->blocks[b].n);
+   }
+   else if (c->flags & ZULTRA_FLAG_ZLIB_FRAMING) {
+      for (uint32_t b = 0; b < count; b++)
+         s->adler = zultra_frame_update_checksum(s->adler, c->in + HISTORY_SIZE + (size_t)b * bs, c->blocks[b].n, c->flags);
+   }
+
+   size_t w = 0;
+   if (!c->host_stitch) {
+      // device stitch: descriptors -> plan on the host, bits moved by a kernel, one D2H of the finished bytes
+      uint64_t end_bit = 0;
+      const uint32_t phase = c->bitstate.nacc;
+      const uint32_t pending = c->bitstate.acc & ((1u << phase) - 1);
+      int rc = zultra_hip_stitch_device(c->hip, &c->bitstate, final_last ? (int)count - 1 : -1, &end_bit);
+      if (rc == -2) return ZULTRA_ERROR_DST;
+      if (rc != 0) return ZULTRA_ERROR_COMPRESSION;
+      const size_t total = (size_t)((end_bit + 7) >> 3);
+      if (total > c->out_cap) return ZULTRA_ERROR_DST;
+      if (zultra_hip_stream_read(c->hip, c->out, 0, total) != 0) return ZULTRA_ERROR_COMPRESSION;
+      c->out[0] |= (uint8_t)pending;
+      if (final_last) {
+         w = total;   // the last partial byte is already zero padded (libzultra.c:414-417)
+         c->bitstate.acc = c->bitstate.nacc = 0;
+         c->state |= ST_FINALIZED;
+      }
+      else {
+         w = (size_t)(end_bit >> 3);
+         c->bitstate.acc = (end_bit & 7) ? c->out[w] : 0;
+      }
+   }
+   else {
+      uint32_t cnt = 0;
+      const zultra_hip_subblock_t *subs = zultra_hip_subblocks(c->hip, &cnt);
+      size_t psize = 0;
+      const uint8_t *payload = zultra_hip_payload(c->hip, &psize);
+      w = zultra_hip_stitch(&c->bitstate, subs, cnt, payload, c->in + HISTORY_SIZE, c->raw_off.data(), bs,
+                            final_last ? (int)count - 1 : -1, c->out, c->out_cap);
+      if (w == (size_t)-1) return ZULTRA_ERROR_DST;
+      if (final_last) {
+         size_t f = zultra_hip_stitch_finish(&c->bitstate, c->out + w, c->out_cap - w);
+         if (f == (size_t)-1) return ZULTRA_ERROR_DST;
+         w += f;
+         c->state |= ST_FINALIZED;
+      }
    }
    c->out_pos = 0;
    c->out_pending = w;

@@ -24,6 +24,7 @@
 #include "zh_huffman.h"
 #include "zh_matchfinder.h"
 #include "zh_split.h"
+#include "zh_stitch.h"
 
 static_assert(sizeof(zultra_hip_block_t) == sizeof(zh_block_t), "ABI");
 static_assert(sizeof(zultra_hip_subblock_t) == sizeof(zh_subblock_t), "ABI");
@@ -49,6 +50,13 @@ struct zultra_hip_ctx_s {
    uint8_t *d_payload;
    uint64_t *d_prof;   // optional in-kernel phase stamps (zultra_hip_set_profile)
    int profile;
+   zh_stitch_item_t *d_items;
+   uint32_t *d_stream;        // stitched deflate bits of the last batch
+   size_t stream_cap;         // bytes
+   uint32_t *d_crc, *d_crc_tables;
+   std::vector<zh_stitch_item_t> items;
+   std::vector<uint32_t> crc;
+   int payload_on_host;       // lazily copied
 
    // host mirrors of the last batch
    std::vector<zh_block_t> blocks;
@@ -178,6 +186,10 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_results);
    (void)hipFree(c->d_payload);
    (void)hipFree(c->d_prof);
+   (void)hipFree(c->d_items);
+   (void)hipFree(c->d_stream);
+   (void)hipFree(c->d_crc);
+   (void)hipFree(c->d_crc_tables);
    if (c->h_payload) (void)hipHostFree(c->h_payload);
    for (int i = 0; i < 8; i++)
       if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -195,8 +207,27 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
        zh_alloc(c, &c->d_tok_pos, B * c->tok_stride) || zh_alloc(c, &c->d_tok_info, B * c->tok_stride) ||
        zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_split_tok, B * (ZH_MAX_SPLITS + 1)) || zh_alloc(c, &c->d_split_cnt, B) ||
        zh_alloc(c, &c->d_sub_base, B) || zh_alloc(c, &c->d_best, B * c->best_stride) || zh_alloc(c, &c->d_work, B * ZH_MAX_SPLITS) ||
-       zh_alloc(c, &c->d_results, B * ZH_MAX_SPLITS) || zh_alloc(c, &c->d_payload, B * c->slot_stride))
+       zh_alloc(c, &c->d_results, B * ZH_MAX_SPLITS) || zh_alloc(c, &c->d_payload, B * c->slot_stride) ||
+       zh_alloc(c, &c->d_items, B * ZH_MAX_SPLITS) || zh_alloc(c, &c->d_crc, B) || zh_alloc(c, &c->d_crc_tables, 256 + 1024))
       return -1;
+   c->stream_cap = (size_t)(B * (N + 5 * (N / 65535 + 1) + 8) + 64) & ~(size_t)3;
+   ZH_CHECK(c, hipMalloc((void **)&c->d_stream, c->stream_cap + 16));
+   {
+      // CRC tables: byte table of 0xEDB88320 and the 'append ZH_CRC_SLICE zero bytes' operator, one table per state byte
+      std::vector<uint32_t> t(256 + 1024);
+      for (uint32_t i = 0; i < 256; i++) {
+         uint32_t v = i;
+         for (int k = 0; k < 8; k++) v = (v >> 1) ^ ((v & 1) ? 0xEDB88320u : 0);
+         t[i] = v;
+      }
+      for (int b = 0; b < 4; b++)
+         for (uint32_t i = 0; i < 256; i++) {
+            uint32_t v = i << (8 * b);
+            for (int k = 0; k < ZH_CRC_SLICE; k++) v = (v >> 8) ^ t[v & 0xff];
+            t[256 + 256 * b + i] = v;
+         }
+      ZH_CHECK(c, hipMemcpy(c->d_crc_tables, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+   }
    ZH_CHECK(c, hipHostMalloc((void **)&c->h_payload, B * c->slot_stride, 0));
    (void)N;
    return 0;
@@ -300,10 +331,14 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
              c->d_results, c->profile ? c->d_prof : (uint64_t *)NULL);
    ZH_CHECK(c, hipEventRecord(c->ev[4], st));
 
+   // per-max-block CRC-32 (linear part) for the gzip footer
+   ZH_LAUNCH(zh_crc32_blocks, nblocks, ZH_CRC_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const uint32_t *)c->d_crc_tables, c->d_crc);
    c->results.resize(nsubs);
+   c->crc.resize(nblocks);
    c->payload_size = (size_t)nblocks * c->slot_stride;
+   c->payload_on_host = 0;
    ZH_CHECK(c, hipMemcpyAsync(c->results.data(), c->d_results, nsubs * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
-   ZH_CHECK(c, hipMemcpyAsync(c->h_payload, c->d_payload, c->payload_size, hipMemcpyDeviceToHost, st));
+   ZH_CHECK(c, hipMemcpyAsync(c->crc.data(), c->d_crc, nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
    ZH_CHECK(c, hipEventRecord(c->ev[5], st));
    ZH_CHECK(c, hipStreamSynchronize(st));
    ZH_CHECK(c, hipGetLastError());
@@ -325,10 +360,63 @@ extern "C" const zultra_hip_subblock_t *zultra_hip_subblocks(const zultra_hip_ct
    if (count) *count = c->nsubs;
    return (const zultra_hip_subblock_t *)c->results.data();
 }
-extern "C" const uint8_t *zultra_hip_payload(const zultra_hip_ctx_t *c, size_t *size) {
+extern "C" const uint8_t *zultra_hip_payload(const zultra_hip_ctx_t *cc, size_t *size) {
+   zultra_hip_ctx_t *c = (zultra_hip_ctx_t *)cc;
    if (!c) return NULL;
+   if (!c->payload_on_host && c->nsubs) {   // copied on first request: the device stitcher does not need it on the host
+      if (hipSetDevice(c->device) != hipSuccess) return NULL;
+      if (hipMemcpy(c->h_payload, c->d_payload, c->payload_size, hipMemcpyDeviceToHost) != hipSuccess) return NULL;
+      c->payload_on_host = 1;
+   }
    if (size) *size = c->payload_size;
    return c->h_payload;
+}
+
+extern "C" int zultra_hip_block_crc32(const zultra_hip_ctx_t *c, uint32_t *out) {
+   if (!c || !out) return -1;
+   memcpy(out, c->crc.data(), c->nblocks * sizeof(uint32_t));
+   return (int)c->nblocks;
+}
+
+// Device stitch of the last batch. state->nacc = pending bits (phase) before the batch; on return state->nacc = pending
+// bits after it and *end_bit = total bits from the start of the byte that held the pending bits. The stream buffer
+// holds ceil(end_bit / 8) bytes; its first byte carries only this batch's bits (OR the caller's pending bits in).
+extern "C" int zultra_hip_stitch_device(zultra_hip_ctx_t *c, zultra_hip_bitstate_t *state, int final_block, uint64_t *end_bit) {
+   if (!c || !state || !end_bit || c->nsubs == 0) return -1;
+   c->items.resize(c->nsubs);
+   uint64_t eb = 0;
+   if (zh_stitch_plan(state->nacc & 7u, c->results.data(), c->nsubs, c->max_block, final_block, c->items.data(), &eb) != 0) {
+      snprintf(c->err, sizeof(c->err), "stream assembly overflows the per-block buffer bound (ZULTRA_ERROR_DST)");
+      return -2;
+   }
+   const size_t nbytes = (size_t)((eb + 7) >> 3);
+   if (nbytes + 8 > c->stream_cap) {
+      snprintf(c->err, sizeof(c->err), "stream buffer too small");
+      return -1;
+   }
+   ZH_CHECK(c, hipSetDevice(c->device));
+   hipStream_t st = c->stream;
+   ZH_CHECK(c, hipEventRecord(c->ev[0], st));
+   ZH_CHECK(c, hipMemsetAsync(c->d_stream, 0, (nbytes + 8 + 3) & ~(size_t)3, st));
+   ZH_CHECK(c, hipMemcpyAsync(c->d_items, c->items.data(), c->nsubs * sizeof(zh_stitch_item_t), hipMemcpyHostToDevice, st));
+   ZH_LAUNCH(zh_stitch, c->nsubs, ZH_STITCH_THREADS, st, (const zh_subblock_t *)c->d_results, (const zh_stitch_item_t *)c->d_items,
+             (const zh_block_t *)c->d_blocks, c->cur_data, (const uint8_t *)c->d_payload, c->d_stream);
+   ZH_CHECK(c, hipEventRecord(c->ev[1], st));
+   ZH_CHECK(c, hipStreamSynchronize(st));
+   ZH_CHECK(c, hipGetLastError());
+   (void)hipEventElapsedTime(&c->timing.stitch_ms, c->ev[0], c->ev[1]);
+   state->nacc = (uint32_t)(eb & 7);
+   *end_bit = eb;
+   return 0;
+}
+
+extern "C" const void *zultra_hip_stream_device(const zultra_hip_ctx_t *c) { return c ? c->d_stream : NULL; }
+
+extern "C" int zultra_hip_stream_read(zultra_hip_ctx_t *c, void *out, size_t offset, size_t nbytes) {
+   if (!c || offset + nbytes > c->stream_cap) return -1;
+   ZH_CHECK(c, hipSetDevice(c->device));
+   ZH_CHECK(c, hipMemcpy(out, (const uint8_t *)c->d_stream + offset, nbytes, hipMemcpyDeviceToHost));
+   return 0;
 }
 extern "C" void zultra_hip_last_timing(const zultra_hip_ctx_t *c, zultra_hip_timing_t *t) {
    if (c && t) *t = c->timing;
