@@ -193,6 +193,10 @@ inline uint32_t zh_row_shl(uint32_t v) {
       return l + N < 16 ? g_slot[g_cur + N] : g_slot[g_cur];
    });
 }
+inline uint32_t zh_wave_shr1(uint32_t v, uint32_t feed) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [feed] { return (g_cur & 63) ? g_slot[g_cur - 1] : (uint64_t)feed; });
+}
 inline uint32_t zh_row_min(uint32_t v) {
    using namespace zh_emu;
    return (uint32_t)collect(v, [] {
@@ -258,6 +262,7 @@ struct uint4 {
 };
 inline uint32_t zh_atomic_add_lds(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 inline uint32_t zh_atomic_add_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 

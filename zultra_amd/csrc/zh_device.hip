@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(64) zh_selftest_kernel(uint32_t seed, uint32_t
       for (uint32_t k = 0; k < 64; k++) bref |= (uint64_t)((v[k] & 4) != 0) << k;
       if (b != bref) errors++;
       if (zh_readfirstlane(x) != v[0]) errors++;
+      if (zh_wave_shr1(x, 0xABCD0000u + round) != (lane ? v[lane - 1] : 0xABCD0000u + round)) errors++;
       if (zh_row_shr<1>(x) != v[(lane & 15) >= 1 ? lane - 1 : lane]) errors++;
       if (zh_row_shr<4>(x) != v[(lane & 15) >= 4 ? lane - 4 : lane]) errors++;
       if (zh_row_shl<1>(x) != v[(lane & 15) + 1 < 16 ? lane + 1 : lane]) errors++;

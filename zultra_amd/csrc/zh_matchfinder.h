@@ -15,8 +15,9 @@
 //                  contiguous memory, no pointer chasing (hash chains would serialise on memory latency).
 //   zh_mf_frontier waves pull 64-entry chunks of the sorted array from a workgroup counter (load balance:
 //                  neighbouring entries belong to the same class and have near-equal candidate counts, so
-//                  the lanes of a wave stay busy together); each lane walks its own class backwards, reading
-//                  candidates that the neighbouring lanes read too (coalesced, L2-resident).
+//                  the lanes of a wave stay busy together). The scan is wave-synchronous: lane l's k-th candidate is
+//                  lane l-1's (k-1)-th, so the candidate stream is passed up the lanes with one DPP wave shift per
+//                  step and refilled from one coalesced 64-entry load per 64 steps; the window sits in LDS.
 //
 // HBM traffic per max-block: window read once (L2 serves the re-reads), 2x4 B per window position for the
 // sort ping-pong, 32 B per block position for the rows.
@@ -26,6 +27,9 @@
 
 #define ZH_MF_THREADS 1024
 #define ZH_MF_WAVES (ZH_MF_THREADS / 64)
+#define ZH_MF_HEAD 0x80000000u       // sorted entry: first position of its trigram class
+#define ZH_MF_POS_MASK 0x7fffffffu
+#define ZH_MF_SENTINEL 0xffffffffu   // "no entry": marked, and farther than any legal distance
 
 // ---------------------------------------------------------------------------------------------------------
 // zh_mf_group
@@ -114,6 +118,18 @@ zh_mf_group(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blo
       }
       __syncthreads();
    }
+   // mark the first entry of every trigram class (bit 31): the scan stops after consuming a marked entry
+   __threadfence_block();
+   __syncthreads();
+   for (uint32_t idx = tid; idx < M; idx += ZH_MF_THREADS) {
+      const uint32_t pos = A[idx] & ZH_MF_POS_MASK;
+      bool head = idx == 0;
+      if (!head) {
+         const uint32_t q = A[idx - 1] & ZH_MF_POS_MASK;
+         head = win[pos] != win[q] || win[pos + 1] != win[q + 1] || win[pos + 2] != win[q + 2];
+      }
+      if (head) A[idx] = pos | ZH_MF_HEAD;
+   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -121,6 +137,14 @@ zh_mf_group(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blo
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t zh_trigram(const uint8_t *p) {
    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+
+// 4 bytes at an arbitrary byte offset x of a dword-aligned buffer: two aligned dword reads + funnel shift
+// (the buffer must be readable up to 7 bytes past x).
+__device__ __forceinline__ uint32_t zh_load32_at(const uint32_t *w32, uint32_t x) {
+   const uint32_t lo = w32[x >> 2], hi = w32[(x >> 2) + 1];
+   const uint32_t sh = (x & 3u) * 8u;
+   return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
 }
 
 // LDS_WIN: the whole window (<= ZH_MF_LDS_WINDOW bytes: 64 KiB max-blocks + 32 KiB history) is staged in LDS once
@@ -176,6 +200,10 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       }
    }
 
+   // Wave-synchronous sliding window over the sorted array: the wave owns sorted entries [c, c+64). At step k lane l
+   // looks at entry c+l-1-k, which is what lane l-1 looked at one step earlier: the candidates travel up the lanes with
+   // one DPP wave shift per step and enter at lane 0 from a 64-entry vector fetched with one coalesced load per 64 steps.
+   // No per-candidate memory access except the one LDS byte probe.
    for (;;) {
       uint32_t c = 0;
       if (lane == 0) c = atomicAdd(&next_chunk, 64u);
@@ -183,34 +211,80 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       if (c >= M) break;
 
       const uint32_t t = c + lane;
-      if (t < M) {
-         const uint32_t i = S[t];
-         if (i >= prev) {
-            const uint32_t maxlen = min((uint32_t)ZH_MAX_MATCH, W - i);
-            const uint32_t key = zh_trigram(win + i);
-            uint32_t cur = ZH_MIN_MATCH - 1;
-            uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;   // length | offset<<16
+      const uint32_t own = t < M ? S[t] : ZH_MF_SENTINEL;
+      const uint32_t i = own & ZH_MF_POS_MASK;
+      bool alive = t < M && i >= prev && !(own & ZH_MF_HEAD);   // a class head has no earlier occurrence
+      const uint32_t maxlen = t < M ? min((uint32_t)ZH_MAX_MATCH, W - i) : 0;
+      uint32_t cur = ZH_MIN_MATCH - 1;
+      // what a candidate must match to beat `cur`: byte cur, or (LDS window, cur >= 3) the four bytes cur-3..cur —
+      // a 100x sharper filter than one byte, so the divergent extension below runs for few candidates
+      uint32_t ci = alive ? win[i + cur] : 0;
+      uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;   // length | offset<<16
 
-            for (int64_t j = (int64_t)t - 1; j >= 0 && cur < maxlen; j--) {
-               const uint32_t p = S[j];
-               if (i - p > ZH_MAX_DIST) break;          // i < p only in a foreign class: wraps, breaks
-               if (zh_trigram(win + p) != key) break;    // left the class
-               if (win[p + cur] != win[i + cur]) continue;   // cannot beat the incumbent
-               uint32_t l = ZH_MIN_MATCH;
-               while (l < maxlen && win[p + l] == win[i + l]) l++;
-               if (l > cur) {
-                  m7 = m6; m6 = m5; m5 = m4; m4 = m3; m3 = m2; m2 = m1; m1 = m0;
-                  m0 = l | ((i - p) << 16);   // offset 32768 needs all 16 bits
-                  cur = l;
-               }
-            }
-            uint4 *r = (uint4 *)(rows + (uint64_t)(i - prev) * ZH_NMATCH);
-            uint4 a, b2;
-            a.x = m0; a.y = m1; a.z = m2; a.w = m3;
-            b2.x = m4; b2.y = m5; b2.z = m6; b2.w = m7;
-            r[0] = a;
-            r[1] = b2;
+      uint32_t cand = own;
+      int64_t vbase = (int64_t)c - 64;                            // sorted index of lane 0 of the feed vector
+      uint32_t vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_SENTINEL;
+      int vi = 63;
+      while (zh_ballot(alive)) {
+         // advance: entry c+l-1-k arrives at lane l; lane 0 takes the next entry below the chunk
+         const uint32_t feed = zh_readlane(vec, vi);
+         cand = zh_wave_shr1(cand, feed);
+         if (--vi < 0) {
+            vbase -= 64;
+            vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_SENTINEL;
+            vi = 63;
          }
+         if (alive) {
+            const uint32_t p = cand & ZH_MF_POS_MASK;
+            if (i - p > ZH_MAX_DIST)
+               alive = false;                                    // also catches the sentinel
+            else {
+               bool pass;
+               if (LDS_WIN) {
+                  // one byte probe for everybody (few LDS bank conflicts), the 4-byte probe only for the ~10% that pass it
+                  pass = cur < 3 || win[p + cur] == (ci >> 24);
+                  if (pass && cur >= 3) pass = zh_load32_at(lwin32, p + cur - 3) == ci;
+               }
+               else
+                  pass = win[p + cur] == ci;
+               if (pass) {                                       // only then can it beat the incumbent
+                  uint32_t l = ZH_MIN_MATCH;                    // the class guarantees the first three bytes
+                  if (LDS_WIN) {
+                     // four bytes per probe pair; bytes past the window end are garbage but l is clamped to maxlen
+                     while (l < maxlen) {
+                        const uint32_t x = zh_load32_at(lwin32, p + l) ^ zh_load32_at(lwin32, i + l);
+                        if (x) {
+                           l += (uint32_t)(__ffs((int)x) - 1) >> 3;
+                           break;
+                        }
+                        l += 4;
+                     }
+                     l = min(l, maxlen);
+                  }
+                  else {
+                     while (l < maxlen && win[p + l] == win[i + l]) l++;
+                  }
+                  if (l > cur) {
+                     m7 = m6; m6 = m5; m5 = m4; m4 = m3; m3 = m2; m2 = m1; m1 = m0;
+                     m0 = l | ((i - p) << 16);                    // offset 32768 needs all 16 bits
+                     cur = l;
+                     if (cur >= maxlen)
+                        alive = false;
+                     else
+                        ci = LDS_WIN ? zh_load32_at(lwin32, i + cur - 3) : (uint32_t)win[i + cur];
+                  }
+               }
+               if (cand & ZH_MF_HEAD) alive = false;             // that was the first occurrence of the class
+            }
+         }
+      }
+      if (t < M && i >= prev) {
+         uint4 *r = (uint4 *)(rows + (uint64_t)(i - prev) * ZH_NMATCH);
+         uint4 a, b2;
+         a.x = m0; a.y = m1; a.z = m2; a.w = m3;
+         b2.x = m4; b2.y = m5; b2.z = m6; b2.w = m7;
+         r[0] = a;
+         r[1] = b2;
       }
    }
 }

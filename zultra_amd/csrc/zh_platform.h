@@ -48,6 +48,11 @@ __device__ __forceinline__ uint32_t zh_row_shl(uint32_t v) {
    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x100 + N, 0xF, 0xF, false);
 }
 
+// whole-wave shift by one lane: lane l receives lane l-1's value, lane 0 receives `feed` (DPP wave_shr:1)
+__device__ __forceinline__ uint32_t zh_wave_shr1(uint32_t v, uint32_t feed) {
+   return (uint32_t)__builtin_amdgcn_update_dpp((int)feed, (int)v, 0x138, 0xF, 0xF, false);
+}
+
 // minimum over each 16-lane DPP row, result in every lane of the row (4 DPP steps, no LDS traffic)
 __device__ __forceinline__ uint32_t zh_row_min(uint32_t v) {
    v = min(v, zh_dpp<ZH_DPP_QUAD_XOR1>(v));
