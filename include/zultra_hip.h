@@ -56,6 +56,7 @@ typedef struct zultra_hip_subblock_s {
 typedef struct zultra_hip_timing_s {
    float h2d_ms, matchfinder_ms, tokenize_split_ms, encode_ms, d2h_ms, total_ms;
    float group_ms, frontier_ms, stitch_ms;
+   float init_ms, parse_ms, build_ms, post_ms, emit_ms;   /* parts of encode_ms: zh_sb_init, 4 x zh_parse_tasks, 4 x zh_sb_build, zh_post_tasks, zh_emit_tasks */
 } zultra_hip_timing_t;
 
 /* Number of usable HIP devices (0 if none). */
@@ -94,12 +95,6 @@ void zultra_hip_last_timing(const zultra_hip_ctx_t *ctx, zultra_hip_timing_t *t)
 int zultra_hip_get_matches(zultra_hip_ctx_t *ctx, uint32_t block, uint16_t *out);
 int zultra_hip_get_splits(zultra_hip_ctx_t *ctx, uint32_t block, int *out /* [64] */);
 int zultra_hip_get_parse(zultra_hip_ctx_t *ctx, uint32_t block, uint16_t *out);
-
-/* Diagnostics: when enabled, zh_encode records 16 shader-clock stamps per sub-block (phase boundaries: cost
- * evaluation, tentative codes, 4 x (parse, histogram+codes), literalisation, alternative tables, header, tokens).
- * get_profile copies them out ([sub-block][16], stream order) and returns the number of sub-blocks copied. */
-int zultra_hip_set_profile(zultra_hip_ctx_t *ctx, int enable);
-int zultra_hip_get_profile(zultra_hip_ctx_t *ctx, uint64_t *out, uint32_t max_subblocks);
 
 /*
  * Stitcher (host): appends the framed sub-blocks of a batch to a deflate stream, reproducing libzultra.c:327-398

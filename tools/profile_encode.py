@@ -1,10 +1,8 @@
 #!/usr/bin/env python3
-"""Diagnostics: where does zh_encode spend its shader clocks? Runs one batch with the in-kernel phase profile on
-(zultra_hip_set_profile) and prints per-phase cycle totals plus the critical (longest) sub-block."""
+"""Diagnostics: per-kernel-group device times of one batch (HIP events on the library's stream).
+usage: python tools/profile_encode.py [bytes] [corpus: text|mixed|json]"""
 import os
 import sys
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,32 +11,25 @@ import corpus  # noqa: E402
 import zultra_amd  # noqa: E402
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+kind = sys.argv[2] if len(sys.argv) > 2 else "text"
 bs = 65536
 L = zultra_amd.lib()
-d = corpus.text_like_fast(size, 1000)
+if kind == "text":
+    d = corpus.text_like_fast(size, 1000)
+elif kind == "mixed":
+    import numpy as np
+    d = np.concatenate([corpus.mixed(1 << 22, 5 + k) for k in range((size + (1 << 22) - 1) >> 22)])[:size]
+else:
+    import numpy as np
+    d = np.concatenate([corpus.json_like(1 << 20, 5 + k) for k in range((size + (1 << 20) - 1) >> 20)])[:size]
 nb = (size + bs - 1) // bs
 blocks = [(b * bs - (32768 if b else 0), 32768 if b else 0, min(bs, size - b * bs)) for b in range(nb)]
 ctx = L.context(bs, nb)
-ctx.set_profile(True)
-for it in range(2):
+for it in range(3):
     ctx.compress_blocks(d, blocks)
-print("timing", ctx.timing())
-P = ctx.profile().astype(np.int64)
+t = ctx.timing()
 subs, _, cnt = ctx.subblocks()
-sizes = np.array([s.size for s in subs])
-dyn = np.array([s.is_dynamic for s in subs])
-names = ["cost_eval", "tentative_codes", "parse0", "hist+codes0", "parse1", "hist+codes1", "parse2", "hist+codes2", "parse3",
-         "hist+codes3", "literalize", "alt_tables", "header+masks", "tokens"]
-D = np.diff(P[:, :15], axis=1)
-D = np.where(dyn[:, None] == 1, D, 0)
-tot = D.sum(axis=0)
-print("sub-blocks %d (dynamic %d), size min/mean/max %d/%d/%d" % (cnt, dyn.sum(), sizes.min(), sizes.mean(), sizes.max()))
-print("%-16s %14s %7s %12s" % ("phase", "sum cycles", "share", "cyc/byte"))
-for k, nme in enumerate(names):
-    print("%-16s %14d %6.1f%% %12.2f" % (nme, tot[k], 100.0 * tot[k] / tot.sum(), tot[k] / sizes[dyn == 1].sum()))
-print("pass-3 parse: step-loop clocks %d of %d (%.1f%%)" % (P[:, 15].sum(), D[:, 8].sum(), 100.0 * P[:, 15].sum() / D[:, 8].sum()))
-life = P[:, 14] - P[:, 0]
-worst = int(np.argmax(life))
-print("longest sub-block: size %d, %d cycles; phases:" % (sizes[worst], life[worst]), dict(zip(names, D[worst].tolist())))
-span = P[:, 14].max() - P[:, 0].min()
-print("kernel span in shader clocks: %d ; sum of lifetimes / span = %.1f waves busy on average" % (span, life.sum() / span))
+print("%s %d bytes, %d max-blocks, %d sub-blocks (%d dynamic)" % (kind, size, nb, cnt, sum(s.is_dynamic for s in subs)))
+for k, v in t.items():
+    print("  %-20s %9.3f ms" % (k, v))
+print("  kernels only: %.1f MB/s" % (size / ((t["matchfinder_ms"] + t["tokenize_split_ms"] + t["encode_ms"]) * 1e-3) / 1e6))

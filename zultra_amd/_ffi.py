@@ -51,7 +51,7 @@ class SubBlock(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [(k, C.c_float) for k in ("h2d_ms", "matchfinder_ms", "tokenize_split_ms", "encode_ms", "d2h_ms", "total_ms",
-                                         "group_ms", "frontier_ms", "stitch_ms")]
+                                         "group_ms", "frontier_ms", "stitch_ms", "init_ms", "parse_ms", "build_ms", "post_ms", "emit_ms")]
 
 
 class BitState(C.Structure):
@@ -69,7 +69,7 @@ EXPORTS = [
     "zultra_hip_device_count", "zultra_hip_selftest", "zultra_hip_create", "zultra_hip_destroy", "zultra_hip_last_error",
     "zultra_hip_data_capacity", "zultra_hip_compress_blocks", "zultra_hip_subblocks", "zultra_hip_payload",
     "zultra_hip_last_timing", "zultra_hip_get_matches", "zultra_hip_get_splits", "zultra_hip_get_parse",
-    "zultra_hip_stitch", "zultra_hip_stitch_finish", "zultra_hip_set_profile", "zultra_hip_get_profile",
+    "zultra_hip_stitch", "zultra_hip_stitch_finish",
     "zultra_hip_stitch_device", "zultra_hip_stream_device", "zultra_hip_stream_read", "zultra_hip_block_crc32", "zultra_crc32_append",
 ]
 
@@ -281,17 +281,6 @@ class HipContext:
         t = Timing()
         self.lib.L.zultra_hip_last_timing(self.h, C.byref(t))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
-
-    def set_profile(self, enable=True):
-        self.lib.L.zultra_hip_set_profile.argtypes = [C.c_void_p, C.c_int]
-        return self.lib.L.zultra_hip_set_profile(self.h, 1 if enable else 0)
-
-    def profile(self, max_subblocks=1 << 20):
-        """-> uint64 array [nsub, 16] of shader-clock stamps (see zultra_hip_set_profile)."""
-        buf = np.zeros((max_subblocks, 16), dtype=np.uint64)
-        self.lib.L.zultra_hip_get_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
-        n = self.lib.L.zultra_hip_get_profile(self.h, buf.ctypes.data, max_subblocks)
-        return buf[:max(n, 0)]
 
     def matches(self, block):
         n = self._blocks[block][2]

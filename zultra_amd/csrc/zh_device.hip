@@ -9,6 +9,9 @@
 //   d_tok_info B * N * 2
 //   d_best     B * N * 4        final parse per position
 //   d_payload  B * (N + 4224)   per-sub-block bit strings (slot of sub-block k of a block starts at its offset + 64k)
+//   d_bars     B * N / 8        barrier bitmap of every max-block (zh_parse.h)
+//   d_states   B * 64 * 1.4 KB  per-sub-block coder state between the kernels of stage 3
+//   d_taskmap, d_hist_part, d_task_bits   per task (T = B * (N / 2048 + 64)): owner, 320-counter histogram, bit count
 //   small: ntok, split boundaries, counts, work items, results
 #include <zh_platform.h>
 
@@ -23,6 +26,7 @@
 #include "zh_encode.h"
 #include "zh_huffman.h"
 #include "zh_matchfinder.h"
+#include "zh_parse.h"
 #include "zh_split.h"
 #include "zh_stitch.h"
 
@@ -48,8 +52,12 @@ struct zultra_hip_ctx_s {
    zh_work_t *d_work;
    zh_subblock_t *d_results;
    uint8_t *d_payload;
-   uint64_t *d_prof;   // optional in-kernel phase stamps (zultra_hip_set_profile)
-   int profile;
+   uint64_t *d_bars;
+   uint64_t bar_stride, max_tasks;
+   zh_sbstate_t *d_states;
+   uint2 *d_taskmap;
+   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;
+   hipEvent_t ev2[16];
    zh_stitch_item_t *d_items;
    uint32_t *d_stream;        // stitched deflate bits of the last batch
    size_t stream_cap;         // bytes
@@ -186,7 +194,14 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_work);
    (void)hipFree(c->d_results);
    (void)hipFree(c->d_payload);
-   (void)hipFree(c->d_prof);
+   (void)hipFree(c->d_bars);
+   (void)hipFree(c->d_states);
+   (void)hipFree(c->d_taskmap);
+   (void)hipFree(c->d_ntasks);
+   (void)hipFree(c->d_hist_part);
+   (void)hipFree(c->d_task_bits);
+   for (int i = 0; i < 16; i++)
+      if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
    (void)hipFree(c->d_items);
    (void)hipFree(c->d_stream);
    (void)hipFree(c->d_crc);
@@ -203,6 +218,12 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    ZH_CHECK(c, hipSetDevice(c->device));
    ZH_CHECK(c, hipStreamCreate(&c->stream));
    for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->ev[i]));
+   for (int i = 0; i < 16; i++) ZH_CHECK(c, hipEventCreate(&c->ev2[i]));
+   c->bar_stride = c->tok_stride / 64;
+   c->max_tasks = B * (N / ZH_TASK + ZH_MAX_SPLITS);
+   if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * ZH_MAX_SPLITS) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
+       zh_alloc(c, &c->d_ntasks, 1) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+      return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
        zh_alloc(c, &c->d_tok_pos, B * c->tok_stride) || zh_alloc(c, &c->d_tok_info, B * c->tok_stride) ||
@@ -306,9 +327,9 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)c->d_sort_a, c->sort_stride, c->d_match, c->match_stride);
    ZH_CHECK(c, hipEventRecord(c->ev[2], st));
 
-   // stage 2: greedy token chain + splitter
+   // stage 2: greedy token chain (+ barrier bitmap) and splitter
    ZH_LAUNCH(zh_tokenize, nblocks, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const zh_match_t *)c->d_match, c->match_stride,
-             c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok);
+             c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok, c->d_bars, c->bar_stride);
    ZH_LAUNCH(zh_split, nblocks, 64, st, (const zh_block_t *)c->d_blocks, (const uint32_t *)c->d_tok_pos, (const uint16_t *)c->d_tok_info,
              c->tok_stride, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt);
    c->split_cnt.resize(nblocks);
@@ -317,26 +338,45 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    ZH_CHECK(c, hipEventRecord(c->ev[3], st));
    ZH_CHECK(c, hipStreamSynchronize(st));
    uint32_t nsubs = 0;
+   uint64_t total_n = 0;
    for (uint32_t b = 0; b < nblocks; b++) {
       c->sub_base[b] = nsubs;
       nsubs += c->split_cnt[b];
+      total_n += blocks[b].n;
    }
    ZH_CHECK(c, hipMemcpyAsync(c->d_sub_base, c->sub_base.data(), nblocks * sizeof(uint32_t), hipMemcpyHostToDevice, st));
 
-   // stage 3: one wave per sub-block
+   // stage 3: sub-block coder, one kernel per step over the whole batch (zh_encode.h)
+   const uint32_t task_grid = (uint32_t)(total_n / ZH_TASK) + nsubs;   // >= number of tasks; surplus waves exit at once
+   c->payload_size = (size_t)nblocks * c->slot_stride;
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, sizeof(uint32_t), st));
+   ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, c->payload_size, st));   // token bits are ORed into the slots
    ZH_LAUNCH(zh_plan_subblocks, (nblocks + 63) / 64, 64, st, (const zh_block_t *)c->d_blocks, nblocks, (const uint32_t *)c->d_tok_pos,
              c->tok_stride, (const uint32_t *)c->d_ntok, (const uint32_t *)c->d_split_tok, (const uint32_t *)c->d_split_cnt,
-             (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work);
-   ZH_LAUNCH(zh_encode, nsubs, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const zh_match_t *)c->d_match, c->match_stride,
-             (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_best, c->best_stride, c->d_payload,
-             c->d_results, c->profile ? c->d_prof : (uint64_t *)NULL);
+             (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work, c->d_taskmap, c->d_ntasks);
+   ZH_LAUNCH(zh_sb_init, nsubs, 64, st, (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_states);
+   ZH_CHECK(c, hipEventRecord(c->ev2[0], st));
+   for (int pass = 0; pass <= 3; pass++) {
+      ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const zh_match_t *)c->d_match,
+                c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap,
+                (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride, c->d_hist_part, pass);
+      ZH_CHECK(c, hipEventRecord(c->ev2[1 + 2 * pass], st));
+      ZH_LAUNCH(zh_sb_build, nsubs, 64, st, (const zh_work_t *)c->d_work, c->d_states, (const uint32_t *)c->d_hist_part, c->d_payload, pass);
+      ZH_CHECK(c, hipEventRecord(c->ev2[2 + 2 * pass], st));
+   }
+   ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const uint64_t *)c->d_bars, c->bar_stride,
+             (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states,
+             c->d_best, c->best_stride, c->d_task_bits);
+   ZH_CHECK(c, hipEventRecord(c->ev2[9], st));
+   ZH_LAUNCH(zh_emit_tasks, task_grid, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const uint64_t *)c->d_bars, c->bar_stride,
+             (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states,
+             (const uint32_t *)c->d_best, c->best_stride, (const uint32_t *)c->d_task_bits, c->d_payload, c->d_results);
    ZH_CHECK(c, hipEventRecord(c->ev[4], st));
 
    // per-max-block CRC-32 (linear part) for the gzip footer
    ZH_LAUNCH(zh_crc32_blocks, nblocks, ZH_CRC_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const uint32_t *)c->d_crc_tables, c->d_crc);
    c->results.resize(nsubs);
    c->crc.resize(nblocks);
-   c->payload_size = (size_t)nblocks * c->slot_stride;
    c->payload_on_host = 0;
    ZH_CHECK(c, hipMemcpyAsync(c->results.data(), c->d_results, nsubs * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
    ZH_CHECK(c, hipMemcpyAsync(c->crc.data(), c->d_crc, nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -353,6 +393,19 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    (void)hipEventElapsedTime(&c->timing.encode_ms, c->ev[3], c->ev[4]);
    (void)hipEventElapsedTime(&c->timing.d2h_ms, c->ev[4], c->ev[5]);
    (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[5]);
+   {
+      float t = 0;
+      (void)hipEventElapsedTime(&c->timing.init_ms, c->ev[3], c->ev2[0]);
+      c->timing.parse_ms = c->timing.build_ms = 0;
+      for (int pass = 0; pass <= 3; pass++) {
+         (void)hipEventElapsedTime(&t, c->ev2[2 * pass], c->ev2[1 + 2 * pass]);
+         c->timing.parse_ms += t;
+         (void)hipEventElapsedTime(&t, c->ev2[1 + 2 * pass], c->ev2[2 + 2 * pass]);
+         c->timing.build_ms += t;
+      }
+      (void)hipEventElapsedTime(&c->timing.post_ms, c->ev2[8], c->ev2[9]);
+      (void)hipEventElapsedTime(&c->timing.emit_ms, c->ev2[9], c->ev[4]);
+   }
    return (int)nsubs;
 }
 
@@ -421,24 +474,6 @@ extern "C" int zultra_hip_stream_read(zultra_hip_ctx_t *c, void *out, size_t off
 }
 extern "C" void zultra_hip_last_timing(const zultra_hip_ctx_t *c, zultra_hip_timing_t *t) {
    if (c && t) *t = c->timing;
-}
-
-extern "C" int zultra_hip_set_profile(zultra_hip_ctx_t *c, int enable) {
-   if (!c) return -1;
-   if (enable && !c->d_prof) {
-      ZH_CHECK(c, hipSetDevice(c->device));
-      ZH_CHECK(c, hipMalloc((void **)&c->d_prof, (size_t)c->max_blocks * ZH_MAX_SPLITS * 16 * sizeof(uint64_t)));
-   }
-   c->profile = enable;
-   return 0;
-}
-
-extern "C" int zultra_hip_get_profile(zultra_hip_ctx_t *c, uint64_t *out, uint32_t max_subblocks) {
-   if (!c || !c->d_prof) return -1;
-   uint32_t n = c->nsubs < max_subblocks ? c->nsubs : max_subblocks;
-   ZH_CHECK(c, hipSetDevice(c->device));
-   ZH_CHECK(c, hipMemcpy(out, c->d_prof, (size_t)n * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-   return (int)n;
 }
 
 extern "C" int zultra_hip_get_matches(zultra_hip_ctx_t *c, uint32_t block, uint16_t *out) {

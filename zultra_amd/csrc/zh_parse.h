@@ -1,0 +1,364 @@
+// zh_parse.h — stage 3a of the hot path: the backward optimal parse (reference src/blockdeflate.c:254-323,
+// zultra_optimize_matches_lwd) as a GPU-wide data-parallel kernel, plus the histogram of the chosen parse
+// (blockdeflate.c:371-400).
+//
+// What makes the parse parallel. The recurrence cost[i] = min(literal + cost[i+1], min_k len(k) + dist + cost[i+k])
+// is serial in i, but it only ever reads cost[j] for j <= i + (longest match starting at i). Call position q a
+// *barrier* when every match that starts before q ends at or before q. Then (1) no position left of q reads a cost
+// right of q, so the choices left of q depend on cost[q] only through an additive constant — restarting the recurrence
+// with cost[q] = 0 reproduces the reference's choices bit for bit (all comparisons are between sums that share the
+// constant); and (2) every parse, greedy or optimal, has a token boundary at q (a token starting before q cannot
+// jump over it). zh_tokenize computes the barrier bitmap of each max-block with one running prefix-max of
+// (position + longest length). On text a barrier falls every ~35 positions; on highly repetitive data they are rare
+// and the parse degrades gracefully to one serial chain per run.
+//
+// Work decomposition (no serial dependency anywhere between the units):
+//   task  = the positions of one sub-block between the barriers nearest to multiples of ZH_TASK; one wave per task,
+//           grid = all tasks of all sub-blocks of the batch (tens of thousands of waves: fills 256 CUs many times over).
+//   piece = a barrier-to-barrier run of >= ZH_PIECE positions inside a task; each 16-lane DPP row of the wave owns
+//           one piece at a time, so a wave advances FOUR independent recurrences per step.
+// Every forward walk over the chosen parse (histogram, literalisation, bit counting, emission) is a walk over tasks
+// too, because a task starts on a token boundary.
+//
+// One recurrence step for a row (position p, lane s of the row prices length k = 3+s):
+//   candidates collapse to one per length: with the slots ordered longest first, the slots able to provide length k
+//   are a prefix, and among them only the cheapest distance can win; the reference's evaluation order (slot ascending,
+//   length descending, strict improvement) makes the winner the minimum of (cost, slot, -k). Per position a 16-byte
+//   record, built with all 64 lanes in parallel when a tile is staged, holds the bitmap of slot lengths and the
+//   running minima of (distance price, slot) per slot; lane s finds "how many slots reach k" with one shift+popcount
+//   and picks its byte. One row-wise DPP min-reduction yields the row's best match, which is compared with the literal.
+//   Lengths 19..39 and slots stored with length >= 40 (tried at full length only, blockdeflate.c:286-297) take a
+//   second, rarely executed section.
+#pragma once
+#include <zh_platform.h>
+#include "zh_common.h"
+#include "zh_split.h"
+
+#define ZH_TASK 2048        // target positions per task
+#define ZH_PIECE 128        // target positions per piece
+#define ZH_MAXPIECES 64
+#define ZH_NSYM (ZH_NLIT + ZH_NDIST)
+#define ZH_KEY_BIAS (1u << 22)   // candidate costs enter the 23-bit key field relative to cost[p+1], biased by this
+
+// sub-block work item produced by zh_plan_subblocks
+struct zh_work_t {
+   uint32_t block, start, size;   // start = absolute window offset
+   uint32_t tok0, tok1;           // greedy token range
+   uint32_t out_cap;              // slot capacity in bytes (multiple of 4)
+   uint64_t out_off;              // byte offset of the bit slot inside the batch payload (multiple of 4)
+   uint32_t index;                // position of this sub-block in stream order (= index of this item)
+   uint32_t task_base, ntasks;    // its tasks are [task_base, task_base + ntasks) in the batch's task list
+   uint32_t pad;
+};
+
+// per-sub-block coder state, lives in HBM between the kernels of the pipeline
+struct zh_sbstate_t {
+   uint8_t lit_len[ZH_NLIT], dist_len[ZH_NDIST];          // code lengths in force (0 = unused symbol)
+   uint16_t lit_code[ZH_NLIT], dist_code[ZH_NDIST];
+   uint8_t pre_lit_len[ZH_NLIT], pre_dist_len[ZH_NDIST];  // lengths after the last parse pass, before the RLE-friendly
+                                                           // alternative: the prices literalisation uses (:923 vs :926-945)
+   uint32_t is_dynamic, failed, hdr_bits;
+   int32_t static_cost, dynamic_cost;
+   uint32_t pad[3];
+};
+
+// first barrier at or after block-relative position r, limited to rend (returns rend if there is none before it)
+__device__ inline uint32_t zh_first_barrier(const uint64_t *bar, uint32_t r, uint32_t rend) {
+   if (r >= rend) return rend;
+   uint32_t w = r >> 6;
+   const uint32_t wend = (rend + 63) >> 6;
+   uint64_t m = bar[w] & (~0ull << (r & 63));
+   while (!m) {
+      if (++w >= wend) return rend;
+      m = bar[w];
+   }
+   const uint32_t q = w * 64 + (uint32_t)zh_ctz64(m);
+   return q < rend ? q : rend;
+}
+
+// boundary j of a sub-block's task list (window positions): 0 -> start, ntasks -> end
+__device__ inline uint32_t zh_task_boundary(const uint64_t *bar, uint32_t prev, uint32_t start, uint32_t end, uint32_t j, uint32_t ntasks) {
+   if (j == 0) return start;
+   if (j >= ntasks) return end;
+   return prev + zh_first_barrier(bar, start + j * ZH_TASK - prev, end - prev);
+}
+
+// ---- forward walk over the chosen parse of [t0, t1): histogram into LDS counters (blockdeflate.c:371-400) ----------
+__device__ inline void zh_walk_histogram_wave(uint32_t *hist /* ZH_NSYM, zeroed */, const uint8_t *win, uint32_t prev, uint32_t t0, uint32_t t1,
+                                              const uint32_t *best) {
+   const uint32_t lane = zh_lane();
+   uint32_t carry = 0;
+   for (uint32_t base = t0; base < t1; base += 64) {
+      const uint32_t limit = min(64u, t1 - base);
+      const uint32_t pos = base + lane;
+      uint32_t b = 0, byte = 0;
+      if (pos < t1) {
+         b = best[pos - prev];
+         byte = win[pos];
+      }
+      const uint32_t len = b & 0xffffu;
+      const uint64_t mask = zh_chain_mask(len, carry, limit);
+      if ((mask >> lane) & 1ull) {
+         if (len >= ZH_MIN_MATCH) {
+            atomicAdd(&hist[257 + zh_len_idx(len)], 1u);
+            atomicAdd(&hist[ZH_NLIT + zh_dist_sym(b >> 16)], 1u);
+         }
+         else
+            atomicAdd(&hist[byte], 1u);
+      }
+   }
+   zh_sync();
+}
+
+// ---- the parse kernel ---------------------------------------------------------------------------------------------
+struct zh_parse_ws_t {
+   union {
+      int32_t ring[4][512];          // per row: cost[p & 511] of its current piece (the reference's cost[], blockdeflate.c:255)
+      uint32_t hist[ZH_NSYM];        // after the parse: histogram of the task
+   };
+   uint4 rec[4][16];                 // per staged position: x = bitmap of short slot lengths 3..34, y/z = running minima
+                                     // (distance price << 3 | slot) per short slot, w = see ZH_REC_* below
+   uint32_t tile[4][16][ZH_NMATCH];  // per staged position and slot: len(9) | distance price(5) << 9 | offset << 16
+   uint32_t bt[4][16];               // winning key per staged position (all ones = literal)
+   uint32_t bnd[ZH_MAXPIECES + 1];   // piece boundaries of the task
+   uint8_t litprice[ZH_NLIT];        // code lengths with the 9-bit fill (blockdeflate.c:873-876)
+   uint8_t lencost[256];             // price of length e+3 incl. extra bits (blockdeflate.c:216-219,263-264)
+   uint8_t distcost[ZH_NDIST];       // price of a distance symbol incl. extra bits (blockdeflate.c:127-136)
+};
+// rec.w: bits 0..4 bitmap of lengths 35..39 | 5..7 their count | 8..11 number of long slots | 12..17 longest short
+// length clamped to the sub-block end | 18..22 literal price
+#define ZH_REC_NHI(w) (((w) >> 5) & 7u)
+#define ZH_REC_NLONG(w) (((w) >> 8) & 15u)
+#define ZH_REC_KMAX(w) (((w) >> 12) & 63u)
+#define ZH_REC_LIT(w) (((w) >> 18) & 31u)
+
+struct zh_tile_regs_t {
+   uint4 a, b;      // the 8 match slots of this lane's position
+   uint32_t byte;
+};
+
+__global__ void __launch_bounds__(64)
+zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match,
+               uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
+               const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total, const zh_sbstate_t *__restrict__ states,
+               uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass) {
+   __shared__ zh_parse_ws_t ws;
+   const uint32_t gt = blockIdx.x;
+   if (gt >= *ntasks_total) return;
+   const uint2 tm = taskmap[gt];
+   const zh_work_t wk = work[tm.x];
+   const zh_sbstate_t *st = states + tm.x;
+   if (st->failed) return;
+   if (!st->is_dynamic && pass > 0) return;   // static sub-blocks are parsed once (blockdeflate.c:836-858)
+
+   const zh_block_t blk = blocks[wk.block];
+   const uint8_t *win = data + blk.win_off;
+   const uint32_t prev = blk.prev;
+   const uint4 *rows = (const uint4 *)(match + (uint64_t)wk.block * match_stride);   // row r = pos - prev: 2 x uint4
+   const uint64_t *bar = bars + (uint64_t)wk.block * bar_stride;
+   uint32_t *best = best_all + (uint64_t)wk.block * best_stride;
+   const uint32_t lane = zh_lane(), row = lane >> 4, s = lane & 15;
+   const uint32_t sb_end = wk.start + wk.size;
+
+   // ---- prices of the codes in force; unused symbols price at 9 / 6 bits (blockdeflate.c:873-881) ---------------
+   for (uint32_t k = lane; k < ZH_NLIT; k += 64) {
+      const uint32_t l = st->lit_len[k];
+      ws.litprice[k] = (uint8_t)(l ? l : 9u);
+   }
+   if (lane < ZH_NDIST) {
+      const uint32_t l = st->dist_len[lane];
+      ws.distcost[lane] = (uint8_t)((l ? l : 6u) + (uint32_t)zh_dist_xbits((int)lane));
+   }
+   zh_sync();
+   for (uint32_t e = lane; e < 256; e += 64) {
+      const int idx = zh_len_idx(e + 3);
+      ws.lencost[e] = (uint8_t)(ws.litprice[257 + idx] + zh_lenidx_xbits(idx));
+   }
+   // ---- task range and its pieces ------------------------------------------------------------------------------
+   const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y, wk.ntasks);
+   const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
+   uint32_t np = 0;
+   if (t1 > t0) {
+      const uint32_t len = t1 - t0;
+      const uint32_t ps = max((uint32_t)ZH_PIECE, (len + ZH_MAXPIECES - 1) / ZH_MAXPIECES);
+      np = (len + ps - 1) / ps;
+      if (lane < np) ws.bnd[lane] = lane == 0 ? t0 : prev + zh_first_barrier(bar, t0 + lane * ps - prev, t1 - prev);
+      if (lane == 0) ws.bnd[np] = t1;
+   }
+   zh_sync();
+   const uint32_t lc0 = ws.lencost[s], lc1 = ws.lencost[16 + s], lc2 = ws.lencost[32 + (s & 7)];
+
+   // ---- row scheduler state (uniform within a row) ---------------------------------------------------------------
+   int32_t next_piece = (int32_t)np - 1;   // wave-uniform: pieces are handed out from the task's end
+   uint32_t p_lo = 0, p_hi = 0;            // what is left of the row's piece: [p_lo, p_hi)
+   uint32_t n_lo = 0, n_cnt = 0;           // the prefetched tile: positions n_lo + 0..n_cnt-1
+   bool n_top = false;                     // the prefetched tile is the top of its piece (recurrence restarts there)
+   int32_t cost_next = 0;
+   zh_tile_regs_t regs;
+
+   // picks the row's next tile (popping a new piece if the current one is used up) and issues its loads
+#define ZH_NEXT_TILE()                                                                                         \
+   do {                                                                                                        \
+      n_top = false;                                                                                           \
+      for (uint32_t r_ = 0; r_ < 4; r_++) {                                                                    \
+         const bool need_ = zh_readlane((uint32_t)(p_hi <= p_lo), (int)(r_ * 16)) != 0;                        \
+         if (need_) {                                                                                          \
+            uint32_t lo_ = 0, hi_ = 0;                                                                         \
+            while (next_piece >= 0 && hi_ <= lo_) {                                                            \
+               lo_ = ws.bnd[next_piece];                                                                       \
+               hi_ = ws.bnd[next_piece + 1];                                                                   \
+               next_piece--;                                                                                   \
+            }                                                                                                  \
+            if (row == r_ && hi_ > lo_) {                                                                      \
+               p_lo = lo_;                                                                                     \
+               p_hi = hi_;                                                                                     \
+               n_top = true;                                                                                   \
+            }                                                                                                  \
+         }                                                                                                     \
+      }                                                                                                        \
+      n_cnt = min(16u, p_hi > p_lo ? p_hi - p_lo : 0u);                                                        \
+      n_lo = p_hi - n_cnt;                                                                                     \
+      p_hi = n_lo;                                                                                             \
+      {                                                                                                        \
+         const bool ok_ = s < n_cnt;                                                                           \
+         const uint32_t pos_ = ok_ ? n_lo + s : wk.start;   /* clamped: the loads are always legal */          \
+         const uint4 a_ = rows[(uint64_t)(pos_ - prev) * 2], b_ = rows[(uint64_t)(pos_ - prev) * 2 + 1];       \
+         const uint32_t y_ = win[pos_];                                                                        \
+         const uint4 z_ = {0, 0, 0, 0};                                                                        \
+         regs.a = ok_ ? a_ : z_;                                                                               \
+         regs.b = ok_ ? b_ : z_;                                                                               \
+         regs.byte = y_;                                                                                       \
+      }                                                                                                        \
+   } while (0)
+
+   if (np) ZH_NEXT_TILE();
+
+   while (np) {
+      const uint32_t c_lo = n_lo, c_cnt = n_cnt;
+      const bool c_top = n_top;
+      if (!zh_ballot(c_cnt != 0)) break;
+
+      // ---- stage the tile: every lane digests the 8 slots of its own position ------------------------------------
+      {
+         const uint32_t raw[ZH_NMATCH] = {regs.a.x, regs.a.y, regs.a.z, regs.a.w, regs.b.x, regs.b.y, regs.b.z, regs.b.w};
+         uint32_t mask_lo = 0, mask_hi = 0, nlong = 0, nshort = 0, kmax = 0, run = 0xFFu;
+         uint64_t pm = 0;
+#pragma unroll
+         for (uint32_t m = 0; m < ZH_NMATCH; m++) {
+            const uint32_t len = raw[m] & 0xffffu, off = raw[m] >> 16;
+            const bool valid = len >= ZH_MIN_MATCH;
+            const uint32_t oc = valid ? (uint32_t)ws.distcost[zh_dist_sym(off)] : 0u;
+            if (s < c_cnt) ws.tile[row][s][m] = valid ? (len | (oc << 9) | (off << 16)) : 0u;
+            if (valid) {
+               if (len >= ZH_LEAVE_ALONE)
+                  nlong++;
+               else {
+                  if (nshort == 0) kmax = len;
+                  const uint32_t bit = len - ZH_MIN_MATCH;
+                  if (bit < 32)
+                     mask_lo |= 1u << bit;
+                  else
+                     mask_hi |= 1u << (bit - 32);
+                  run = min(run, (oc << 3) | m);
+                  pm |= (uint64_t)run << (8 * nshort);
+                  nshort++;
+               }
+            }
+         }
+         if (s < c_cnt) {
+            const uint32_t room = sb_end - (c_lo + s);   // end clamp (blockdeflate.c:283-284); a no-op away from the sub-block end
+            uint4 r;
+            r.x = mask_lo;
+            r.y = (uint32_t)pm;
+            r.z = (uint32_t)(pm >> 32);
+            r.w = mask_hi | ((uint32_t)__popc(mask_hi) << 5) | (nlong << 8) | (min(kmax, room) << 12) | ((uint32_t)ws.litprice[regs.byte] << 18);
+            ws.rec[row][s] = r;
+         }
+      }
+      if (c_top && s == 0) ws.ring[row][(c_lo + c_cnt) & 511] = 0;   // cost[piece end] = 0
+      if (c_top) cost_next = 0;
+      zh_sync();
+      ZH_NEXT_TILE();   // the next tile's loads complete while this one is priced
+
+      // ---- price the tile: one position per row per step ------------------------------------------------------------
+      const uint32_t steps = max(max(zh_readlane(c_cnt, 0), zh_readlane(c_cnt, 16)), max(zh_readlane(c_cnt, 32), zh_readlane(c_cnt, 48)));
+      for (uint32_t t = 0; t < steps; t++) {
+         const bool act = t < c_cnt;
+         const uint32_t a = act ? c_cnt - 1 - t : 0;
+         const uint32_t p = c_lo + a;
+         uint4 R = ws.rec[row][a];
+         if (!act) R.w = 0;
+         const uint32_t kmax = ZH_REC_KMAX(R.w), nlong = ZH_REC_NLONG(R.w), nhi = ZH_REC_NHI(R.w);
+         const uint32_t base = (uint32_t)cost_next - ZH_KEY_BIAS;   // key cost = candidate cost - base (fits 23 bits)
+         uint32_t key = 0xFFFFFFFFu;
+         if (3 + s <= kmax) {
+            const uint32_t sel = (uint32_t)__popc(R.x >> s) + nhi - 1u;            // index of the last short slot reaching 3+s
+            const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
+            const uint32_t c = lc0 + (b >> 3) + (uint32_t)ws.ring[row][(p + 3 + s) & 511] - base;
+            key = (c << 9) | ((b & 7u) << 6) | (36u - s);                          // 39 - k
+         }
+         // rarely needed: lengths 19..39, and slots stored with length >= 40
+         if (zh_ballot(kmax > 18u || nlong != 0)) {
+            if (19 + s <= kmax) {
+               const uint32_t sel = (uint32_t)__popc(R.x >> (16 + s)) + nhi - 1u;
+               const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
+               const uint32_t c = lc1 + (b >> 3) + (uint32_t)ws.ring[row][(p + 19 + s) & 511] - base;
+               key = min(key, (c << 9) | ((b & 7u) << 6) | (20u - s));
+            }
+            if (s < 5 && 35 + s <= kmax) {
+               const uint32_t sel = (uint32_t)__popc((R.w & 31u) >> s) - 1u;
+               const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
+               const uint32_t c = lc2 + (b >> 3) + (uint32_t)ws.ring[row][(p + 35 + s) & 511] - base;
+               key = min(key, (c << 9) | ((b & 7u) << 6) | (4u - s));
+            }
+            if (s < nlong) {                                                        // long slot s: full (clamped) length only
+               const uint32_t e = ws.tile[row][a][s];
+               const uint32_t mlen = min(e & 511u, sb_end - p);
+               uint32_t enc = mlen - ZH_MIN_MATCH;                                  // wraps below 3, then saturates (:289, :216-219)
+               if (enc > 255) enc = 255;
+               const uint32_t c = (uint32_t)ws.lencost[enc] + ((e >> 9) & 31u) + (uint32_t)ws.ring[row][(p + mlen) & 511] - base;
+               key = min(key, (c << 9) | (s << 6));
+            }
+         }
+         const uint32_t rkey = zh_row_min(key);   // every lane of a row now holds that row's best match candidate
+         // literal first; a match must be strictly cheaper (:292,:307). An absent candidate (all ones) prices at 2^23-1.
+         const uint32_t lit = ZH_REC_LIT(R.w) + ZH_KEY_BIAS, mc = rkey >> 9;
+         const bool take = mc < lit;
+         const int32_t c = (int32_t)(base + (take ? mc : lit));
+         if (act) {
+            if (s == 0) {
+               ws.ring[row][p & 511] = c;
+               ws.bt[row][a] = take ? rkey : 0xFFFFFFFFu;
+            }
+            cost_next = c;
+         }
+      }
+      zh_sync();
+      // ---- flush: decode the winning (slot, length) of each position and store the parse --------------------------
+      if (s < c_cnt) {
+         const uint32_t kk = ws.bt[row][s];
+         uint32_t pick = 0;
+         if (kk != 0xFFFFFFFFu) {
+            const uint32_t m = (kk >> 6) & 7u;
+            const uint32_t e = ws.tile[row][s][m];
+            const uint32_t nlong = ZH_REC_NLONG(ws.rec[row][s].w);
+            const uint32_t len = (m < nlong) ? min(e & 511u, sb_end - (c_lo + s)) : (39u - (kk & 63u));
+            pick = len | (e & 0xffff0000u);
+         }
+         best[(c_lo + s) - prev] = pick;
+      }
+      zh_sync();
+   }
+#undef ZH_NEXT_TILE
+
+   // ---- histogram of the task's parse; the per-sub-block sum is taken by zh_sb_build -------------------------------
+   if (st->is_dynamic) {
+      __threadfence_block();
+      zh_sync();
+      for (uint32_t k = lane; k < ZH_NSYM; k += 64) ws.hist[k] = 0;
+      zh_sync();
+      zh_walk_histogram_wave(ws.hist, win, prev, t0, t1, best);
+      uint32_t *hp = hist_part + (uint64_t)gt * ZH_NSYM;
+      for (uint32_t k = lane; k < ZH_NSYM; k += 64) hp[k] = ws.hist[k];
+   }
+}

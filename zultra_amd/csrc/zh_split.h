@@ -37,10 +37,24 @@ __device__ inline uint64_t zh_chain_mask(uint32_t len, uint32_t &carry, uint32_t
    return mask;
 }
 
+// inclusive running maximum over the 64 lanes
+__device__ inline uint32_t zh_wave_incl_max(uint32_t v) {
+   const int lane = (int)zh_lane();
+#pragma unroll
+   for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t y = zh_shfl(v, (lane - d) & 63);
+      if (lane >= d) v = max(v, y);
+   }
+   return v;
+}
+
+// Also produces the barrier bitmap of the max-block (zh_parse.h): bit r of bars is set when every match that starts
+// at a block position < r ends at or before r, i.e. when the running maximum of (r' + max(longest length at r', 1))
+// over r' < r equals r. Position 0 is a barrier by definition.
 __global__ void __launch_bounds__(64)
 zh_tokenize(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
             const zh_match_t *__restrict__ match, uint64_t match_stride, uint32_t *tok_pos, uint16_t *tok_info,
-            uint64_t tok_stride, uint32_t *ntok_out) {
+            uint64_t tok_stride, uint32_t *ntok_out, uint64_t *bars, uint64_t bar_stride) {
    const zh_block_t blk = blocks[blockIdx.x];
    const uint8_t *win = data + blk.win_off;
    const uint32_t *rows = (const uint32_t *)(match + (uint64_t)blockIdx.x * match_stride);
@@ -48,7 +62,9 @@ zh_tokenize(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blo
    uint16_t *ti = tok_info + (uint64_t)blockIdx.x * tok_stride;
    const uint32_t lane = zh_lane();
    const uint32_t n = blk.n;
+   uint64_t *bar = bars + (uint64_t)blockIdx.x * bar_stride;
    uint32_t ntok = 0, carry = 0;
+   uint32_t reach_before = 0;   // running maximum over all earlier tiles
 
    for (uint32_t base = 0; base < n; base += 64) {
       const uint32_t limit = min(64u, n - base);
@@ -59,6 +75,14 @@ zh_tokenize(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blo
          byte = win[blk.prev + r];
       }
       const uint32_t len = m0 & 0xffffu;
+      {
+         const uint32_t incl = zh_wave_incl_max(r < n ? r + max(len, 1u) : 0u);
+         const uint32_t up = zh_shfl(incl, (int)((lane - 1) & 63));
+         const uint32_t excl = lane ? max(reach_before, up) : reach_before;
+         const uint64_t bm = zh_ballot(r < n && excl <= r);
+         if (lane == 0) bar[base >> 6] = bm;
+         reach_before = max(reach_before, zh_readlane(incl, 63));
+      }
       uint64_t mask = zh_chain_mask(len, carry, limit);
       if ((mask >> lane) & 1ull) {
          uint32_t idx = ntok + (uint32_t)zh_popc64(mask & ((1ull << lane) - 1));
