@@ -136,6 +136,7 @@ int zultra_hip_stream_read(zultra_hip_ctx_t *ctx, void *out, size_t offset, size
  * exactly as zultra_frame_update_checksum(crc, block, len, GZIP) would (reference src/frame.c:324-354,473-480). */
 int zultra_hip_block_crc32(const zultra_hip_ctx_t *ctx, uint32_t *out);
 uint32_t zultra_crc32_append(uint32_t crc, uint32_t block_linear_crc, size_t block_len);
+uint32_t zultra_crc32_append_many(uint32_t crc, const uint32_t *block_linear_crc, const uint32_t *block_len, uint32_t nblocks);
 
 #ifdef __cplusplus
 }

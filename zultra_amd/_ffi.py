@@ -70,7 +70,7 @@ EXPORTS = [
     "zultra_hip_data_capacity", "zultra_hip_compress_blocks", "zultra_hip_subblocks", "zultra_hip_payload",
     "zultra_hip_last_timing", "zultra_hip_get_matches", "zultra_hip_get_splits", "zultra_hip_get_parse",
     "zultra_hip_stitch", "zultra_hip_stitch_finish",
-    "zultra_hip_stitch_device", "zultra_hip_stream_device", "zultra_hip_stream_read", "zultra_hip_block_crc32", "zultra_crc32_append",
+    "zultra_hip_stitch_device", "zultra_hip_stream_device", "zultra_hip_stream_read", "zultra_hip_block_crc32", "zultra_crc32_append", "zultra_crc32_append_many",
 ]
 
 
@@ -167,6 +167,14 @@ class Lib:
         self.L.zultra_crc32_append.restype = C.c_uint32
         return self.L.zultra_crc32_append(crc, int(block_linear_crc), block_len)
 
+    def crc32_append_many(self, crc, block_linear_crcs, block_lens):
+        a = np.ascontiguousarray(block_linear_crcs, dtype=np.uint32)
+        n = np.ascontiguousarray(block_lens, dtype=np.uint32)
+        f = self.L.zultra_crc32_append_many
+        f.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        f.restype = C.c_uint32
+        return f(crc, a.ctypes.data, n.ctypes.data, len(a))
+
     def stream(self, flags, max_block=0):
         return Stream(self, flags, max_block)
 
@@ -240,6 +248,7 @@ class HipContext:
         self.max_block = max_block
         self._data = None
         self._blocks = None
+        self._blocks_src = self._blocks_arr = None
 
     def close(self):
         if self.h:
@@ -254,8 +263,12 @@ class HipContext:
 
     def compress_blocks(self, data, blocks, data_on_device=False, data_size=None):
         """data: uint8 array (host) or an integer device pointer; blocks: list of (win_off, prev, n)."""
-        arr = (Block * len(blocks))(*[Block(int(o), int(p), int(n)) for (o, p, n) in blocks])
-        self._blocks = list(blocks)
+        if blocks is self._blocks_src:   # same list object as last time: reuse the marshalled descriptors
+            arr = self._blocks_arr
+        else:
+            arr = (Block * len(blocks))(*[Block(int(o), int(p), int(n)) for (o, p, n) in blocks])
+            self._blocks_src, self._blocks_arr = blocks, arr
+            self._blocks = list(blocks)
         if data_on_device:
             ptr, size = int(data), int(data_size)
         else:
@@ -270,6 +283,12 @@ class HipContext:
         cnt = C.c_uint32()
         p = self.lib.L.zultra_hip_subblocks(self.h, C.byref(cnt))
         return [p[i] for i in range(cnt.value)], p, cnt.value
+
+    def subblocks_raw(self):
+        """-> (pointer to zultra_hip_subblock_t[count], count) without building Python objects."""
+        cnt = C.c_uint32()
+        p = self.lib.L.zultra_hip_subblocks(self.h, C.byref(cnt))
+        return p, cnt.value
 
     def subblock_bits(self, sb):
         size = C.c_size_t()

@@ -112,6 +112,11 @@ extern "C" uint32_t zultra_crc32_append(uint32_t crc, uint32_t block_linear_crc,
    return ~(op.apply(~crc) ^ block_linear_crc);
 }
 
+extern "C" uint32_t zultra_crc32_append_many(uint32_t crc, const uint32_t *block_linear_crc, const uint32_t *block_len, uint32_t nblocks) {
+   for (uint32_t b = 0; b < nblocks; b++) crc = zultra_crc32_append(crc, block_linear_crc[b], block_len[b]);
+   return crc;
+}
+
 // Adler-32 (frame.c:74-138): sums modulo 65521, reduced every 5552 bytes.
 static uint32_t adler32_update(uint32_t adler, const uint8_t *p, size_t n) {
    uint32_t a = adler & 0xffff, b = (adler >> 16) & 0xffff;
@@ -415,7 +420,7 @@ static uint32_t clamp_block(uint32_t n) {
 }
 
 // device bytes one max-block of a batch costs (see the layout comment in zh_device.hip)
-static uint64_t per_block_device_bytes(uint32_t bs) { return (uint64_t)bs * 56 + 400000; }
+static uint64_t per_block_device_bytes(uint32_t bs) { return (uint64_t)bs * 64 + 900000; }
 
 static zultra_hip_ctx_t *ctx_acquire(uint32_t bs, uint32_t want_blocks) {
    const int dev = zh_pick_device();

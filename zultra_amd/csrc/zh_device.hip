@@ -3,7 +3,8 @@
 // HBM layout of one context (B = max_blocks, N = max_block_size, W = N + 32768):
 //   d_data     W + (B-1)*N      input bytes when the caller hands over host memory (read in place otherwise)
 //   d_blocks   B * 16           max-block descriptors
-//   d_sort_a/b B * W * 4  each  trigram-sorted window positions (ping-pong of the 3-pass radix sort)
+//   d_sort_a/b B * W * 4  each  window positions grouped by trigram / 4-gram hash (ping-pong of the 2-pass radix sorts)
+//   d_prev3    B * W * 4        previous occurrence of the trigram at every window position
 //   d_match    B * N * 32       match rows, 8 x {u16 length, u16 offset} per block position
 //   d_tok_pos  B * N * 4        greedy token chain: position / packed symbols
 //   d_tok_info B * N * 2
@@ -43,7 +44,7 @@ struct zultra_hip_ctx_s {
 
    uint8_t *d_data;
    zh_block_t *d_blocks;
-   uint32_t *d_sort_a, *d_sort_b;
+   uint32_t *d_sort_a, *d_sort_b, *d_prev3;
    zh_match_t *d_match;
    uint32_t *d_tok_pos;
    uint16_t *d_tok_info;
@@ -183,6 +184,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_blocks);
    (void)hipFree(c->d_sort_a);
    (void)hipFree(c->d_sort_b);
+   (void)hipFree(c->d_prev3);
    (void)hipFree(c->d_match);
    (void)hipFree(c->d_tok_pos);
    (void)hipFree(c->d_tok_info);
@@ -222,7 +224,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->bar_stride = c->tok_stride / 64;
    c->max_tasks = B * (N / ZH_TASK + ZH_MAX_SPLITS);
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * ZH_MAX_SPLITS) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
-       zh_alloc(c, &c->d_ntasks, 1) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+       zh_alloc(c, &c->d_prev3, B * c->sort_stride) || zh_alloc(c, &c->d_ntasks, 1) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
@@ -317,14 +319,14 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
 
    // stage 1: match rows
    ZH_LAUNCH(zh_mf_group, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, c->d_sort_a, c->d_sort_b,
-             c->sort_stride);
+             c->d_prev3, c->sort_stride);
    ZH_CHECK(c, hipEventRecord(c->ev[6], st));
    if (c->W <= ZH_MF_LDS_WINDOW)
       ZH_LAUNCH(zh_mf_frontier<true>, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks,
-                (const uint32_t *)c->d_sort_a, c->sort_stride, c->d_match, c->match_stride);
+                (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3, c->sort_stride, c->d_match, c->match_stride);
    else
       ZH_LAUNCH(zh_mf_frontier<false>, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks,
-                (const uint32_t *)c->d_sort_a, c->sort_stride, c->d_match, c->match_stride);
+                (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3, c->sort_stride, c->d_match, c->match_stride);
    ZH_CHECK(c, hipEventRecord(c->ev[2], st));
 
    // stage 2: greedy token chain (+ barrier bitmap) and splitter

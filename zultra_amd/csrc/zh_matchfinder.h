@@ -6,21 +6,26 @@
 // The reference's rows have a closed form: for block position i, scan the earlier window
 // positions p from nearest to farthest; whenever the match length L(p) = min(LCP(i,p), 258, windowEnd-i)
 // is >= 3 and strictly longer than everything seen so far, p is a row entry; entries farther than 32768 are
-// dropped; the 8 longest survive, longest first. No suffix array is needed for that — only "all earlier
-// occurrences of my first three bytes, nearest first", which is what these two kernels build and scan:
-//
-//   zh_mf_group    one workgroup per max-block: stable LSD radix sort (3 passes x 8 bits, the three bytes
-//                  themselves are the digits) of the window positions by their trigram. Afterwards every
-//                  trigram class is a contiguous run of positions in ascending order — candidate lists are
-//                  contiguous memory, no pointer chasing (hash chains would serialise on memory latency).
-//   zh_mf_frontier waves pull 64-entry chunks of the sorted array from a workgroup counter (load balance:
+// dropped; the 8 longest survive, longest first. No suffix array is needed for that. Two facts bound the work:
+//   * the nearest entry is the previous occurrence of the trigram at i; it has length exactly 3 unless its 4th byte
+//     matches too;
+//   * every other entry is longer than 3, i.e. an earlier occurrence of the 4-gram at i.
+// So two grouped orders of the window positions are built, each with a stable 2-pass LSD radix sort on a 15-bit
+// multiplicative hash (collisions only add candidates that fail the byte compare):
+//   zh_mf_group    one workgroup per max-block.
+//                  trigram order  -> prev3[pos] = previous occurrence of the same trigram (one array lookup later);
+//                  4-gram order   -> every 4-gram class is a contiguous ascending run: candidate lists are contiguous
+//                                    memory, no pointer chasing (hash chains would serialise on memory latency).
+//                  For windows of <= 128 Ki positions the hash rides in the upper 15 bits of the 32-bit element, so
+//                  only the first pass touches the window bytes (a linear, coalesced read).
+//   zh_mf_frontier waves pull 64-entry chunks of the 4-gram order from a workgroup counter (load balance:
 //                  neighbouring entries belong to the same class and have near-equal candidate counts, so
 //                  the lanes of a wave stay busy together). The scan is wave-synchronous: lane l's k-th candidate is
 //                  lane l-1's (k-1)-th, so the candidate stream is passed up the lanes with one DPP wave shift per
 //                  step and refilled from one coalesced 64-entry load per 64 steps; the window sits in LDS.
 //
-// HBM traffic per max-block: window read once (L2 serves the re-reads), 2x4 B per window position for the
-// sort ping-pong, 32 B per block position for the rows.
+// HBM traffic per max-block: window read twice linearly, 4 x 2 x 4 B per window position for the sort ping-pong,
+// 4 B per position for prev3, 32 B per block position for the rows.
 #pragma once
 #include <zh_platform.h>
 #include "zh_common.h"
@@ -31,22 +36,28 @@
 #define ZH_MF_POS_MASK 0x7fffffffu
 #define ZH_MF_SENTINEL 0xffffffffu   // "no entry": marked, and farther than any legal distance
 
+#define ZH_MF_HASH_BITS 15
+#define ZH_MF_NONE 0xffffffffu       // prev3: no earlier occurrence
+#define ZH_MF_PACK_SHIFT 17          // packed element: hash << 17 | position (windows of <= 128 Ki positions)
+#define ZH_MF_PACK_MAXW (1u << ZH_MF_PACK_SHIFT)
+
+// unaligned little-endian loads from global memory
+__device__ __forceinline__ uint32_t zh_ld24(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+__device__ __forceinline__ uint32_t zh_ld32(const uint8_t *p) { return zh_ld24(p) | ((uint32_t)p[3] << 24); }
+template <int GRAM>
+__device__ __forceinline__ uint32_t zh_mf_hash(const uint8_t *p) {
+   const uint32_t v = GRAM == 3 ? zh_ld24(p) : zh_ld32(p);
+   return (v * 0x9E3779B1u) >> (32 - ZH_MF_HASH_BITS);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // zh_mf_group
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(ZH_MF_THREADS)
-zh_mf_group(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, uint32_t *sort_a,
-            uint32_t *sort_b, uint64_t sort_stride) {
-   __shared__ uint32_t hist[ZH_MF_WAVES * 256];
-   __shared__ uint32_t wave_tot[ZH_MF_WAVES];
-
-   const zh_block_t blk = blocks[blockIdx.x];
-   const uint8_t *win = data + blk.win_off;
-   const uint32_t W = blk.prev + blk.n;
-   const uint32_t M = W >= 3 ? W - 2 : 0;   // positions that start a trigram
-   uint32_t *A = sort_a + (uint64_t)blockIdx.x * sort_stride;
-   uint32_t *B = sort_b + (uint64_t)blockIdx.x * sort_stride;
-
+// One stable counting pass over M elements: wave w owns the contiguous slice [w*seg, (w+1)*seg), so element order
+// within a digit is preserved. PASS 0 reads the identity permutation and hashes the window; PASS 1 orders by the high
+// hash bits. hist = ZH_MF_WAVES x 256 counters in LDS.
+template <int GRAM, bool PACKED, int PASS>
+__device__ inline void zh_mf_sort_pass(const uint8_t *win, uint32_t M, const uint32_t *src, uint32_t *dst, uint32_t *hist, uint32_t *wave_tot) {
    const uint32_t tid = threadIdx.x;
    const uint32_t lane = tid & 63, wave = tid >> 6;
    const uint32_t seg = (((M + ZH_MF_WAVES - 1) / ZH_MF_WAVES) + 63) & ~63u;
@@ -54,82 +65,152 @@ zh_mf_group(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blo
    const uint32_t hi = min(M, lo + seg);
    const uint64_t lt_mask = (1ull << lane) - 1;
 
-   for (int pass = 0; pass < 3; pass++) {
-      const uint32_t *src = (pass == 1) ? A : B;          // pass 0 reads the identity permutation
-      uint32_t *dst = (pass == 1) ? B : A;                // final order lands in A
-      const uint32_t boff = 2 - (uint32_t)pass;            // least significant digit first
+   for (uint32_t k = tid; k < ZH_MF_WAVES * 256; k += ZH_MF_THREADS) hist[k] = 0;
+   __syncthreads();
 
-      for (uint32_t k = tid; k < ZH_MF_WAVES * 256; k += ZH_MF_THREADS) hist[k] = 0;
-      __syncthreads();
+   // element and digit of slice index idx
+#define ZH_MF_FETCH(idx, e, d)                                                                      \
+   do {                                                                                             \
+      if (PASS == 0) {                                                                              \
+         const uint32_t h_ = zh_mf_hash<GRAM>(win + (idx));                                         \
+         e = PACKED ? ((h_ << ZH_MF_PACK_SHIFT) | (idx)) : (idx);                                   \
+         d = h_ & 0xffu;                                                                            \
+      }                                                                                             \
+      else {                                                                                        \
+         e = src[idx];                                                                              \
+         d = (PACKED ? (e >> ZH_MF_PACK_SHIFT) : zh_mf_hash<GRAM>(win + e)) >> 8;                   \
+      }                                                                                             \
+   } while (0)
 
-      // per-wave digit histogram of the wave's contiguous slice
-      for (uint32_t base = lo; base < hi; base += 64) {
-         uint32_t idx = base + lane;
-         if (idx < hi) {
-            uint32_t pos = pass ? src[idx] : idx;
-            atomicAdd(&hist[wave * 256 + win[pos + boff]], 1u);
-         }
+   // per-wave digit histogram of the wave's contiguous slice; four independent fetches in flight per lane
+   for (uint32_t base = lo; base < hi; base += 256) {
+      uint32_t e[4], d[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+         const uint32_t idx = base + u * 64 + lane;
+         e[u] = 0;
+         d[u] = 0xffffffffu;
+         if (idx < hi) ZH_MF_FETCH(idx, e[u], d[u]);
       }
-      __syncthreads();
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++)
+         if (d[u] != 0xffffffffu) atomicAdd(&hist[wave * 256 + d[u]], 1u);
+   }
+   __syncthreads();
 
-      // exclusive scan in (digit, wave) order: entry e = digit*16 + wave; each thread owns 4 entries
-      {
-         uint32_t v[4], s = 0;
-         for (int q = 0; q < 4; q++) {
-            uint32_t e = tid * 4 + (uint32_t)q;
-            v[q] = hist[(e & 15) * 256 + (e >> 4)];
-            s += v[q];
-         }
-         uint32_t ex = zh_wave_excl_sum(s);
-         if (lane == 63) wave_tot[wave] = ex + s;
-         __syncthreads();
-         uint32_t pre = 0;
-         for (uint32_t w2 = 0; w2 < wave; w2++) pre += wave_tot[w2];
-         ex += pre;
-         for (int q = 0; q < 4; q++) {
-            uint32_t e = tid * 4 + (uint32_t)q;
-            hist[(e & 15) * 256 + (e >> 4)] = ex;
-            ex += v[q];
-         }
+   // exclusive scan in (digit, wave) order: entry e = digit*16 + wave; each thread owns 4 entries
+   {
+      uint32_t v[4], s = 0;
+      for (int q = 0; q < 4; q++) {
+         const uint32_t e = tid * 4 + (uint32_t)q;
+         v[q] = hist[(e & 15) * 256 + (e >> 4)];
+         s += v[q];
       }
+      uint32_t ex = zh_wave_excl_sum(s);
+      if (lane == 63) wave_tot[wave] = ex + s;
       __syncthreads();
+      uint32_t pre = 0;
+      for (uint32_t w2 = 0; w2 < wave; w2++) pre += wave_tot[w2];
+      ex += pre;
+      for (int q = 0; q < 4; q++) {
+         const uint32_t e = tid * 4 + (uint32_t)q;
+         hist[(e & 15) * 256 + (e >> 4)] = ex;
+         ex += v[q];
+      }
+   }
+   __syncthreads();
 
-      // stable scatter: each wave walks its slice in order, 64 positions per step
-      for (uint32_t base = lo; base < hi; base += 64) {
-         uint32_t idx = base + lane;
-         bool valid = idx < hi;
-         uint32_t pos = 0, d = 0;
-         if (valid) {
-            pos = pass ? src[idx] : idx;
-            d = win[pos + boff];
-         }
-         uint32_t slot = valid ? hist[wave * 256 + d] : 0;
+   // stable scatter: each wave walks its slice in order, 64 elements per step; the fetches of four steps are issued together
+   for (uint32_t base4 = lo; base4 < hi; base4 += 256) {
+      uint32_t e4[4], d4[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+         const uint32_t idx = base4 + u * 64 + lane;
+         e4[u] = 0;
+         d4[u] = 0;
+         if (idx < hi) ZH_MF_FETCH(idx, e4[u], d4[u]);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+         const uint32_t idx = base4 + u * 64 + lane;
+         const bool valid = idx < hi;
+         const uint32_t e = e4[u], d = d4[u];
+         const uint32_t slot = valid ? hist[wave * 256 + d] : 0;
          uint64_t peers = zh_ballot(valid);
          for (int bit = 0; bit < 8; bit++) {
-            bool one = (d >> bit) & 1u;
-            uint64_t m = zh_ballot(valid && one);
+            const bool one = (d >> bit) & 1u;
+            const uint64_t m = zh_ballot(valid && one);
             peers &= one ? m : ~m;
          }
          if (valid) {
-            dst[slot + (uint32_t)zh_popc64(peers & lt_mask)] = pos;
+            dst[slot + (uint32_t)zh_popc64(peers & lt_mask)] = e;
             if ((peers & lt_mask) == 0) hist[wave * 256 + d] = slot + (uint32_t)zh_popc64(peers);
          }
          zh_ballot(true);   // orders the counter update before the next step's read (lock-step anyway on the GPU)
       }
-      __syncthreads();
    }
-   // mark the first entry of every trigram class (bit 31): the scan stops after consuming a marked entry
+#undef ZH_MF_FETCH
    __threadfence_block();
    __syncthreads();
-   for (uint32_t idx = tid; idx < M; idx += ZH_MF_THREADS) {
-      const uint32_t pos = A[idx] & ZH_MF_POS_MASK;
+}
+
+template <bool PACKED>
+__device__ inline void zh_mf_group_body(const uint8_t *win, uint32_t W, uint32_t *A, uint32_t *B, uint32_t *prev3, uint32_t *hist, uint32_t *wave_tot) {
+   const uint32_t tid = threadIdx.x;
+   const uint32_t M3 = W >= 3 ? W - 2 : 0;   // positions that start a trigram
+   const uint32_t M4 = W >= 4 ? W - 3 : 0;   // positions that start a 4-gram
+   const uint32_t pmask = PACKED ? (ZH_MF_PACK_MAXW - 1) : 0xffffffffu;
+
+   // ---- trigram order -> previous occurrence of every trigram ------------------------------------------------
+   zh_mf_sort_pass<3, PACKED, 0>(win, M3, nullptr, A, hist, wave_tot);
+   zh_mf_sort_pass<3, PACKED, 1>(win, M3, A, B, hist, wave_tot);
+   for (uint32_t idx = tid; idx < M3; idx += ZH_MF_THREADS) {
+      const uint32_t e = B[idx], pos = e & pmask;
+      const uint32_t h = PACKED ? (e >> ZH_MF_PACK_SHIFT) : zh_mf_hash<3>(win + pos);
+      const uint32_t tri = zh_ld24(win + pos);
+      uint32_t found = ZH_MF_NONE;
+      for (uint32_t j = idx; j > 0;) {      // the hash bucket is ascending in position: walk back to the nearest equal trigram
+         j--;
+         const uint32_t eq = B[j], q = eq & pmask;
+         if ((PACKED ? (eq >> ZH_MF_PACK_SHIFT) : zh_mf_hash<3>(win + q)) != h) break;
+         if (zh_ld24(win + q) == tri) {
+            found = q;
+            break;
+         }
+      }
+      prev3[pos] = found;
+   }
+   __syncthreads();
+
+   // ---- 4-gram order, class heads marked -------------------------------------------------------------------------
+   zh_mf_sort_pass<4, PACKED, 0>(win, M4, nullptr, A, hist, wave_tot);
+   zh_mf_sort_pass<4, PACKED, 1>(win, M4, A, B, hist, wave_tot);
+   for (uint32_t idx = tid; idx < M4; idx += ZH_MF_THREADS) {
+      const uint32_t e = B[idx], pos = e & pmask;
       bool head = idx == 0;
       if (!head) {
-         const uint32_t q = A[idx - 1] & ZH_MF_POS_MASK;
-         head = win[pos] != win[q] || win[pos + 1] != win[q + 1] || win[pos + 2] != win[q + 2];
+         const uint32_t eq = B[idx - 1];
+         head = PACKED ? ((eq >> ZH_MF_PACK_SHIFT) != (e >> ZH_MF_PACK_SHIFT)) : (zh_mf_hash<4>(win + (eq & pmask)) != zh_mf_hash<4>(win + pos));
       }
-      if (head) A[idx] = pos | ZH_MF_HEAD;
+      A[idx] = pos | (head ? ZH_MF_HEAD : 0u);   // the scan stops after consuming a marked entry
    }
+}
+
+__global__ void __launch_bounds__(ZH_MF_THREADS)
+zh_mf_group(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, uint32_t *sort_a,
+            uint32_t *sort_b, uint32_t *prev3_all, uint64_t sort_stride) {
+   __shared__ uint32_t hist[ZH_MF_WAVES * 256];
+   __shared__ uint32_t wave_tot[ZH_MF_WAVES];
+   const zh_block_t blk = blocks[blockIdx.x];
+   const uint8_t *win = data + blk.win_off;
+   const uint32_t W = blk.prev + blk.n;
+   uint32_t *A = sort_a + (uint64_t)blockIdx.x * sort_stride;
+   uint32_t *B = sort_b + (uint64_t)blockIdx.x * sort_stride;
+   uint32_t *prev3 = prev3_all + (uint64_t)blockIdx.x * sort_stride;
+   if (W <= ZH_MF_PACK_MAXW)
+      zh_mf_group_body<true>(win, W, A, B, prev3, hist, wave_tot);
+   else
+      zh_mf_group_body<false>(win, W, A, B, prev3, hist, wave_tot);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -154,7 +235,7 @@ __device__ __forceinline__ uint32_t zh_load32_at(const uint32_t *w32, uint32_t x
 template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
 zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
-               const uint32_t *__restrict__ sorted, uint64_t sort_stride, zh_match_t *match,
+               const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ prev3_all, uint64_t sort_stride, zh_match_t *match,
                uint64_t match_stride) {
    __shared__ uint32_t next_chunk;
    __shared__ uint32_t lwin32[LDS_WIN ? (ZH_MF_LDS_WINDOW / 4 + 4) : 1];
@@ -163,8 +244,9 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
    const uint8_t *gwin = data + blk.win_off;
    const uint32_t prev = blk.prev;
    const uint32_t W = blk.prev + blk.n;
-   const uint32_t M = W >= 3 ? W - 2 : 0;
+   const uint32_t M = W >= 4 ? W - 3 : 0;                           // entries of the 4-gram order
    const uint32_t *S = sorted + (uint64_t)blockIdx.x * sort_stride;
+   const uint32_t *prev3 = prev3_all + (uint64_t)blockIdx.x * sort_stride;
    zh_match_t *rows = match + (uint64_t)blockIdx.x * match_stride;   // row r = block position prev + r
    const uint32_t lane = threadIdx.x & 63;
    const uint8_t *win = gwin;
@@ -185,25 +267,29 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
    if (threadIdx.x == 0) next_chunk = 0;
    __syncthreads();
 
-   // the last two window positions cannot start a match (matchfinder.c:71: LCP bounded by the window end)
-   if (threadIdx.x < 2 && W >= 1) {
-      uint32_t i = W - 1 - threadIdx.x;
-      if (W >= 1 + threadIdx.x && i >= prev) {
-         uint2 *r = (uint2 *)(rows + (uint64_t)(i - prev) * ZH_NMATCH);
-         uint2 z;
-         z.x = 0;
-         z.y = 0;
-         r[0] = z;
+   // The last three window positions are not in the 4-gram order. W-1 and W-2 cannot start a match (matchfinder.c:71:
+   // LCP bounded by the window end); W-3 can only have the length-3 match with the previous occurrence of its trigram.
+   if (threadIdx.x < 3 && W >= 1 + threadIdx.x) {
+      const uint32_t i = W - 1 - threadIdx.x;
+      if (i >= prev) {
+         uint32_t m0 = 0;
+         if (threadIdx.x == 2) {
+            const uint32_t p3 = prev3[i];
+            if (p3 != ZH_MF_NONE && i - p3 <= ZH_MAX_DIST) m0 = ZH_MIN_MATCH | ((i - p3) << 16);
+         }
+         uint4 *r = (uint4 *)(rows + (uint64_t)(i - prev) * ZH_NMATCH);
+         uint4 a, z;
+         a.x = m0; a.y = 0; a.z = 0; a.w = 0;
+         z.x = 0; z.y = 0; z.z = 0; z.w = 0;
+         r[0] = a;
          r[1] = z;
-         r[2] = z;
-         r[3] = z;
       }
    }
 
    // Wave-synchronous sliding window over the sorted array: the wave owns sorted entries [c, c+64). At step k lane l
    // looks at entry c+l-1-k, which is what lane l-1 looked at one step earlier: the candidates travel up the lanes with
    // one DPP wave shift per step and enter at lane 0 from a 64-entry vector fetched with one coalesced load per 64 steps.
-   // No per-candidate memory access except the one LDS byte probe.
+   // No per-candidate memory access except the LDS probes.
    for (;;) {
       uint32_t c = 0;
       if (lane == 0) c = atomicAdd(&next_chunk, 64u);
@@ -213,72 +299,109 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       const uint32_t t = c + lane;
       const uint32_t own = t < M ? S[t] : ZH_MF_SENTINEL;
       const uint32_t i = own & ZH_MF_POS_MASK;
-      bool alive = t < M && i >= prev && !(own & ZH_MF_HEAD);   // a class head has no earlier occurrence
-      const uint32_t maxlen = t < M ? min((uint32_t)ZH_MAX_MATCH, W - i) : 0;
-      uint32_t cur = ZH_MIN_MATCH - 1;
-      // what a candidate must match to beat `cur`: byte cur, or (LDS window, cur >= 3) the four bytes cur-3..cur —
-      // a 100x sharper filter than one byte, so the divergent extension below runs for few candidates
-      uint32_t ci = alive ? win[i + cur] : 0;
+      const bool mine = t < M && i >= prev;
+      const uint32_t maxlen = t < M ? min((uint32_t)ZH_MAX_MATCH, W - i) : 0;   // >= 4
       uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;   // length | offset<<16
+      uint32_t cur = ZH_MIN_MATCH - 1;
+      bool alive = false;
+      const uint32_t first4 = mine ? (LDS_WIN ? zh_load32_at(lwin32, i) : zh_ld32(win + i)) : 0;
+      if (mine) {
+         // nearest occurrence of the trigram: without it there is no match at all; if its 4th byte differs it is the
+         // (only) length-3 entry, otherwise it is the first member of the 4-gram class met below
+         const uint32_t p3 = prev3[i];
+         if (p3 != ZH_MF_NONE && i - p3 <= ZH_MAX_DIST) {
+            alive = !(own & ZH_MF_HEAD);   // a class head has no earlier 4-gram occurrence
+            const uint32_t q4 = LDS_WIN ? zh_load32_at(lwin32, p3) : zh_ld32(win + p3);
+            if (q4 != first4) {
+               m0 = ZH_MIN_MATCH | ((i - p3) << 16);
+               cur = ZH_MIN_MATCH;
+            }
+         }
+      }
+      // what a candidate must match to beat `cur`: the four bytes ending at position max(cur, 3) — for cur <= 3 that is
+      // the 4-gram itself (class membership; hash collisions fail here)
+      uint32_t fo = max(cur, 3u) - 3u;
+      uint32_t ci = first4;
 
       uint32_t cand = own;
       int64_t vbase = (int64_t)c - 64;                            // sorted index of lane 0 of the feed vector
       uint32_t vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_SENTINEL;
       int vi = 63;
+
+      // one candidate against the lane's state; `probe` = the byte at p + fo + 3 if it was fetched while `fo` still had
+      // the value `probe_fo` (two candidates are probed per iteration so that their LDS latencies overlap)
+#define ZH_MF_CONSIDER(CAND, PROBE, PROBE_FO)                                                                     \
+      if (alive) {                                                                                                \
+         const uint32_t p = (CAND) & ZH_MF_POS_MASK;                                                              \
+         if (i - p > ZH_MAX_DIST)                                                                                 \
+            alive = false; /* also catches the sentinel */                                                        \
+         else {                                                                                                   \
+            bool pass;                                                                                            \
+            if (LDS_WIN) {                                                                                        \
+               /* one byte probe for everybody (few LDS bank conflicts), the 4-byte probe only for those that pass it */ \
+               const uint32_t pb = (PROBE_FO) == fo ? (PROBE) : (uint32_t)win[p + fo + 3];                        \
+               pass = pb == (ci >> 24);                                                                           \
+               if (pass) pass = zh_load32_at(lwin32, p + fo) == ci;                                               \
+            }                                                                                                     \
+            else                                                                                                  \
+               pass = zh_ld32(win + p + fo) == ci;                                                                \
+            if (pass) { /* only then can it beat the incumbent */                                                 \
+               uint32_t l = 0; /* a colliding class member may differ in the first bytes */                       \
+               if (LDS_WIN) {                                                                                     \
+                  /* four bytes per probe pair; bytes past the window end are garbage but l is clamped to maxlen */ \
+                  while (l < maxlen) {                                                                            \
+                     const uint32_t x = zh_load32_at(lwin32, p + l) ^ zh_load32_at(lwin32, i + l);                \
+                     if (x) {                                                                                     \
+                        l += (uint32_t)(__ffs((int)x) - 1) >> 3;                                                  \
+                        break;                                                                                    \
+                     }                                                                                            \
+                     l += 4;                                                                                      \
+                  }                                                                                               \
+                  l = min(l, maxlen);                                                                             \
+               }                                                                                                  \
+               else {                                                                                             \
+                  while (l < maxlen && win[p + l] == win[i + l]) l++;                                             \
+               }                                                                                                  \
+               if (l > cur) {                                                                                     \
+                  m7 = m6; m6 = m5; m5 = m4; m4 = m3; m3 = m2; m2 = m1; m1 = m0;                                  \
+                  m0 = l | ((i - p) << 16); /* offset 32768 needs all 16 bits */                                  \
+                  cur = l;                                                                                        \
+                  if (cur >= maxlen)                                                                              \
+                     alive = false;                                                                               \
+                  else {                                                                                          \
+                     fo = cur - 3;                                                                                \
+                     ci = LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo);                         \
+                  }                                                                                               \
+               }                                                                                                  \
+            }                                                                                                     \
+            if ((CAND) & ZH_MF_HEAD) alive = false; /* that was the first entry of the class */                   \
+         }                                                                                                        \
+      }
+
       while (zh_ballot(alive)) {
-         // advance: entry c+l-1-k arrives at lane l; lane 0 takes the next entry below the chunk
-         const uint32_t feed = zh_readlane(vec, vi);
-         cand = zh_wave_shr1(cand, feed);
-         if (--vi < 0) {
+         // advance twice: entries c+l-1-2k and c+l-2-2k arrive at lane l; lane 0 takes the next entries below the chunk
+         const uint32_t c1 = zh_wave_shr1(cand, zh_readlane(vec, vi));
+         const uint32_t c2 = zh_wave_shr1(c1, zh_readlane(vec, vi - 1));
+         cand = c2;
+         vi -= 2;
+         if (vi < 0) {
             vbase -= 64;
             vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_SENTINEL;
             vi = 63;
          }
-         if (alive) {
-            const uint32_t p = cand & ZH_MF_POS_MASK;
-            if (i - p > ZH_MAX_DIST)
-               alive = false;                                    // also catches the sentinel
-            else {
-               bool pass;
-               if (LDS_WIN) {
-                  // one byte probe for everybody (few LDS bank conflicts), the 4-byte probe only for the ~10% that pass it
-                  pass = cur < 3 || win[p + cur] == (ci >> 24);
-                  if (pass && cur >= 3) pass = zh_load32_at(lwin32, p + cur - 3) == ci;
-               }
-               else
-                  pass = win[p + cur] == ci;
-               if (pass) {                                       // only then can it beat the incumbent
-                  uint32_t l = ZH_MIN_MATCH;                    // the class guarantees the first three bytes
-                  if (LDS_WIN) {
-                     // four bytes per probe pair; bytes past the window end are garbage but l is clamped to maxlen
-                     while (l < maxlen) {
-                        const uint32_t x = zh_load32_at(lwin32, p + l) ^ zh_load32_at(lwin32, i + l);
-                        if (x) {
-                           l += (uint32_t)(__ffs((int)x) - 1) >> 3;
-                           break;
-                        }
-                        l += 4;
-                     }
-                     l = min(l, maxlen);
-                  }
-                  else {
-                     while (l < maxlen && win[p + l] == win[i + l]) l++;
-                  }
-                  if (l > cur) {
-                     m7 = m6; m6 = m5; m5 = m4; m4 = m3; m3 = m2; m2 = m1; m1 = m0;
-                     m0 = l | ((i - p) << 16);                    // offset 32768 needs all 16 bits
-                     cur = l;
-                     if (cur >= maxlen)
-                        alive = false;
-                     else
-                        ci = LDS_WIN ? zh_load32_at(lwin32, i + cur - 3) : (uint32_t)win[i + cur];
-                  }
-               }
-               if (cand & ZH_MF_HEAD) alive = false;             // that was the first occurrence of the class
-            }
+         uint32_t pb1 = 0, pb2 = 0;
+         const uint32_t fo0 = fo;
+         if (LDS_WIN && alive) {
+            // both byte probes are issued before either is used; a candidate beyond reach probes the lane's own position
+            const uint32_t q1 = c1 & ZH_MF_POS_MASK, q2 = c2 & ZH_MF_POS_MASK;
+            pb1 = win[(i - q1 > ZH_MAX_DIST ? i : q1) + fo + 3];
+            pb2 = win[(i - q2 > ZH_MAX_DIST ? i : q2) + fo + 3];
          }
+         ZH_MF_CONSIDER(c1, pb1, fo0)
+         ZH_MF_CONSIDER(c2, pb2, fo0)
       }
-      if (t < M && i >= prev) {
+#undef ZH_MF_CONSIDER
+      if (mine) {
          uint4 *r = (uint4 *)(rows + (uint64_t)(i - prev) * ZH_NMATCH);
          uint4 a, b2;
          a.x = m0; a.y = m1; a.z = m2; a.w = m3;

@@ -238,42 +238,35 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       const bool c_top = n_top;
       if (!zh_ballot(c_cnt != 0)) break;
 
-      // ---- stage the tile: every lane digests the 8 slots of its own position ------------------------------------
+      // ---- stage the tile: every lane digests the 8 slots of its own position (branch-free: lanes beyond the tile's
+      //      count digest zeros into their own, unused, record) ---------------------------------------------------------
       {
          const uint32_t raw[ZH_NMATCH] = {regs.a.x, regs.a.y, regs.a.z, regs.a.w, regs.b.x, regs.b.y, regs.b.z, regs.b.w};
-         uint32_t mask_lo = 0, mask_hi = 0, nlong = 0, nshort = 0, kmax = 0, run = 0xFFu;
-         uint64_t pm = 0;
+         uint32_t nlong = 0, nshort = 0, kmax = 0, run = 0xFFu;
+         uint64_t pm = 0, lmask = 0;
 #pragma unroll
          for (uint32_t m = 0; m < ZH_NMATCH; m++) {
             const uint32_t len = raw[m] & 0xffffu, off = raw[m] >> 16;
             const bool valid = len >= ZH_MIN_MATCH;
-            const uint32_t oc = valid ? (uint32_t)ws.distcost[zh_dist_sym(off)] : 0u;
-            if (s < c_cnt) ws.tile[row][s][m] = valid ? (len | (oc << 9) | (off << 16)) : 0u;
-            if (valid) {
-               if (len >= ZH_LEAVE_ALONE)
-                  nlong++;
-               else {
-                  if (nshort == 0) kmax = len;
-                  const uint32_t bit = len - ZH_MIN_MATCH;
-                  if (bit < 32)
-                     mask_lo |= 1u << bit;
-                  else
-                     mask_hi |= 1u << (bit - 32);
-                  run = min(run, (oc << 3) | m);
-                  pm |= (uint64_t)run << (8 * nshort);
-                  nshort++;
-               }
-            }
+            const bool is_long = len >= ZH_LEAVE_ALONE;
+            const bool is_short = valid && !is_long;
+            const uint32_t oc = (uint32_t)ws.distcost[zh_dist_sym(valid ? off : 1u)];
+            ws.tile[row][s][m] = valid ? (len | (oc << 9) | (off << 16)) : 0u;
+            nlong += is_long ? 1u : 0u;
+            kmax = max(kmax, is_short ? len : 0u);               // the first short slot is the longest
+            lmask |= is_short ? (1ull << (len - ZH_MIN_MATCH)) : 0ull;
+            run = is_short ? min(run, (oc << 3) | m) : run;
+            pm |= is_short ? ((uint64_t)run << (8 * nshort)) : 0ull;
+            nshort += is_short ? 1u : 0u;
          }
-         if (s < c_cnt) {
-            const uint32_t room = sb_end - (c_lo + s);   // end clamp (blockdeflate.c:283-284); a no-op away from the sub-block end
-            uint4 r;
-            r.x = mask_lo;
-            r.y = (uint32_t)pm;
-            r.z = (uint32_t)(pm >> 32);
-            r.w = mask_hi | ((uint32_t)__popc(mask_hi) << 5) | (nlong << 8) | (min(kmax, room) << 12) | ((uint32_t)ws.litprice[regs.byte] << 18);
-            ws.rec[row][s] = r;
-         }
+         const uint32_t room = sb_end - (c_lo + s);   // end clamp (blockdeflate.c:283-284); a no-op away from the sub-block end
+         const uint32_t mask_hi = (uint32_t)(lmask >> 32);
+         uint4 r;
+         r.x = (uint32_t)lmask;
+         r.y = (uint32_t)pm;
+         r.z = (uint32_t)(pm >> 32);
+         r.w = mask_hi | ((uint32_t)__popc(mask_hi) << 5) | (nlong << 8) | (min(kmax, room) << 12) | ((uint32_t)ws.litprice[regs.byte & 0xffu] << 18);
+         ws.rec[row][s] = r;
       }
       if (c_top && s == 0) ws.ring[row][(c_lo + c_cnt) & 511] = 0;   // cost[piece end] = 0
       if (c_top) cost_next = 0;

@@ -54,11 +54,16 @@ __device__ __forceinline__ uint32_t zh_wave_shr1(uint32_t v, uint32_t feed) {
 }
 
 // minimum over each 16-lane DPP row, result in every lane of the row (4 DPP steps, no LDS traffic)
+// `old` = the identity of min: lets the compiler fold each step into one v_min_u32_dpp
+template <int CTRL>
+__device__ __forceinline__ uint32_t zh_dpp_min(uint32_t v) {
+   return min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, CTRL, 0xF, 0xF, false));
+}
 __device__ __forceinline__ uint32_t zh_row_min(uint32_t v) {
-   v = min(v, zh_dpp<ZH_DPP_QUAD_XOR1>(v));
-   v = min(v, zh_dpp<ZH_DPP_QUAD_XOR2>(v));
-   v = min(v, zh_dpp<ZH_DPP_ROW_HALF_MIRROR>(v));
-   v = min(v, zh_dpp<ZH_DPP_ROW_MIRROR>(v));
+   v = zh_dpp_min<ZH_DPP_QUAD_XOR1>(v);
+   v = zh_dpp_min<ZH_DPP_QUAD_XOR2>(v);
+   v = zh_dpp_min<ZH_DPP_ROW_HALF_MIRROR>(v);
+   v = zh_dpp_min<ZH_DPP_ROW_MIRROR>(v);
    return v;
 }
 __device__ __forceinline__ uint32_t zh_row_sum(uint32_t v) {

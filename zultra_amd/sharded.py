@@ -49,11 +49,26 @@ def _plan_bits(lib, subs_arr, count, max_block, phase):
     return w, st.nacc
 
 
+_pinned = {}
+
+
+def _to_host(torch, t):
+    """Device tensor -> numpy through a reused pinned staging buffer (pageable D2H is several times slower)."""
+    if t.device.type != "cuda":
+        return t.numpy()
+    n = t.numel()
+    buf = _pinned.get("buf")
+    if buf is None or buf.numel() < n:
+        buf = _pinned["buf"] = torch.empty(max(n, 1 << 20) * 5 // 4, dtype=torch.uint8, pin_memory=True)
+    buf[:n].copy_(t)
+    return buf[:n].numpy()
+
+
 def assemble(lib, ctx, max_block, dist, torch, device, is_stream_end_rank, nblocks_local):
     """Stitch this rank's last batch on its GPU at its true bit offset and gather the stream on rank 0.
     Returns (stream bytes as a uint8 numpy array on rank 0 / None elsewhere, info dict)."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    subs, p, cnt = ctx.subblocks()
+    p, cnt = ctx.subblocks_raw()
     rec = C.sizeof(SubBlock)
     mine = np.zeros((cnt, rec), dtype=np.uint8)
     C.memmove(mine.ctypes.data, p, cnt * rec)
@@ -83,7 +98,7 @@ def assemble(lib, ctx, max_block, dist, torch, device, is_stream_end_rank, nbloc
     local = _stream_tensor(ctx, torch, device, nbytes)
 
     if world == 1:
-        return local.cpu().numpy(), {"shard_bytes": nbytes, "start_phase": 0}
+        return _to_host(torch, local), {"shard_bytes": nbytes, "start_phase": 0}
 
     # (3) variable-length gather of the stitched bytes to rank 0 (RCCL over xGMI on the GPU box)
     lt = torch.zeros(world, dtype=torch.int64, device=device)
