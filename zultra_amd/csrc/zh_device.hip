@@ -318,9 +318,20 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    ZH_CHECK(c, hipEventRecord(c->ev[1], st));
 
    // stage 1: match rows
-   ZH_LAUNCH(zh_mf_group, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, c->d_sort_a, c->d_sort_b,
-             c->d_prev3, c->sort_stride);
+   const int mf_stop = getenv("ZH_MF_STOP") ? atoi(getenv("ZH_MF_STOP")) : 0;   // timing experiments only
+   if (c->W <= ZH_MF_LDS_WINDOW)
+      ZH_LAUNCH(zh_mf_group<true>, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, c->d_sort_a, c->d_sort_b,
+                c->d_prev3, c->sort_stride, mf_stop);
+   else
+      ZH_LAUNCH(zh_mf_group<false>, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, c->d_sort_a, c->d_sort_b,
+                c->d_prev3, c->sort_stride, mf_stop);
    ZH_CHECK(c, hipEventRecord(c->ev[6], st));
+   if (mf_stop) {   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
+      ZH_CHECK(c, hipStreamSynchronize(st));
+      (void)hipEventElapsedTime(&c->timing.group_ms, c->ev[1], c->ev[6]);
+      snprintf(c->err, sizeof(c->err), "ZH_MF_STOP set: stopped after zh_mf_group");
+      return -1;
+   }
    if (c->W <= ZH_MF_LDS_WINDOW)
       ZH_LAUNCH(zh_mf_frontier<true>, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks,
                 (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3, c->sort_stride, c->d_match, c->match_stride);

@@ -50,14 +50,35 @@ __device__ __forceinline__ uint32_t zh_mf_hash(const uint8_t *p) {
    return (v * 0x9E3779B1u) >> (32 - ZH_MF_HASH_BITS);
 }
 
+// LDS_WIN: the whole window (<= ZH_MF_LDS_WINDOW bytes: 64 KiB max-blocks + 32 KiB history) is staged in LDS once
+// per workgroup with coalesced dword loads, so the scattered byte reads hit the 160 KiB LDS instead of L1/L2.
+#define ZH_MF_LDS_WINDOW 98304
+__device__ inline void zh_stage_window(uint32_t *lwin32, const uint8_t *gwin, uint32_t W) {
+   uint8_t *lw = (uint8_t *)lwin32;
+   if ((((uintptr_t)gwin) & 3u) == 0) {
+      const uint32_t *g32 = (const uint32_t *)gwin;
+      const uint32_t nw = W >> 2;
+      for (uint32_t k = threadIdx.x; k < nw; k += ZH_MF_THREADS) lwin32[k] = g32[k];
+      for (uint32_t k = (nw << 2) + threadIdx.x; k < W; k += ZH_MF_THREADS) lw[k] = gwin[k];
+   }
+   else {
+      for (uint32_t k = threadIdx.x; k < W; k += ZH_MF_THREADS) lw[k] = gwin[k];
+   }
+   __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // zh_mf_group
 // ---------------------------------------------------------------------------------------------------------
 // One stable counting pass over M elements: wave w owns the contiguous slice [w*seg, (w+1)*seg), so element order
 // within a digit is preserved. PASS 0 reads the identity permutation and hashes the window; PASS 1 orders by the high
 // hash bits. hist = ZH_MF_WAVES x 256 counters in LDS.
-template <int GRAM, bool PACKED, int PASS>
-__device__ inline void zh_mf_sort_pass(const uint8_t *win, uint32_t M, const uint32_t *src, uint32_t *dst, uint32_t *hist, uint32_t *wave_tot) {
+// MODE 0/1/2: the trigram's bytes 2/1/0 are the digits (exact order, three passes, elements are positions);
+// MODE 3/4: low / high byte of the 15-bit 4-gram hash (elements carry the hash when PACKED).
+// Modes 0 and 3 read the identity permutation and the window linearly (win); the others gather through gwin.
+template <int MODE, bool PACKED>
+__device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, uint32_t M, const uint32_t *src, uint32_t *dst, uint32_t *hist,
+                                       uint32_t *wave_tot) {
    const uint32_t tid = threadIdx.x;
    const uint32_t lane = tid & 63, wave = tid >> 6;
    const uint32_t seg = (((M + ZH_MF_WAVES - 1) / ZH_MF_WAVES) + 63) & ~63u;
@@ -71,14 +92,22 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, uint32_t M, const uin
    // element and digit of slice index idx
 #define ZH_MF_FETCH(idx, e, d)                                                                      \
    do {                                                                                             \
-      if (PASS == 0) {                                                                              \
-         const uint32_t h_ = zh_mf_hash<GRAM>(win + (idx));                                         \
+      if (MODE == 0) {                                                                              \
+         e = (idx);                                                                                 \
+         d = win[(idx) + 2];                                                                        \
+      }                                                                                             \
+      else if (MODE == 1 || MODE == 2) {                                                            \
+         e = src[idx];                                                                              \
+         d = gwin[e + (MODE == 1 ? 1 : 0)];                                                         \
+      }                                                                                             \
+      else if (MODE == 3) {                                                                         \
+         const uint32_t h_ = zh_mf_hash<4>(win + (idx));                                            \
          e = PACKED ? ((h_ << ZH_MF_PACK_SHIFT) | (idx)) : (idx);                                   \
          d = h_ & 0xffu;                                                                            \
       }                                                                                             \
       else {                                                                                        \
          e = src[idx];                                                                              \
-         d = (PACKED ? (e >> ZH_MF_PACK_SHIFT) : zh_mf_hash<GRAM>(win + e)) >> 8;                   \
+         d = (PACKED ? (e >> ZH_MF_PACK_SHIFT) : zh_mf_hash<4>(gwin + e)) >> 8;                     \
       }                                                                                             \
    } while (0)
 
@@ -154,63 +183,101 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, uint32_t M, const uin
    __syncthreads();
 }
 
+// `win` is read linearly (global memory); `gwin` is the copy used for scattered reads (LDS when the window fits)
 template <bool PACKED>
-__device__ inline void zh_mf_group_body(const uint8_t *win, uint32_t W, uint32_t *A, uint32_t *B, uint32_t *prev3, uint32_t *hist, uint32_t *wave_tot) {
+__device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin, uint32_t W, uint32_t first_needed, uint32_t *A, uint32_t *B, uint32_t *prev3,
+                                        uint32_t *hist, uint32_t *wave_tot, int stop) {
    const uint32_t tid = threadIdx.x;
    const uint32_t M3 = W >= 3 ? W - 2 : 0;   // positions that start a trigram
    const uint32_t M4 = W >= 4 ? W - 3 : 0;   // positions that start a 4-gram
    const uint32_t pmask = PACKED ? (ZH_MF_PACK_MAXW - 1) : 0xffffffffu;
 
-   // ---- trigram order -> previous occurrence of every trigram ------------------------------------------------
-   zh_mf_sort_pass<3, PACKED, 0>(win, M3, nullptr, A, hist, wave_tot);
-   zh_mf_sort_pass<3, PACKED, 1>(win, M3, A, B, hist, wave_tot);
-   for (uint32_t idx = tid; idx < M3; idx += ZH_MF_THREADS) {
-      const uint32_t e = B[idx], pos = e & pmask;
-      const uint32_t h = PACKED ? (e >> ZH_MF_PACK_SHIFT) : zh_mf_hash<3>(win + pos);
-      const uint32_t tri = zh_ld24(win + pos);
-      uint32_t found = ZH_MF_NONE;
-      for (uint32_t j = idx; j > 0;) {      // the hash bucket is ascending in position: walk back to the nearest equal trigram
-         j--;
-         const uint32_t eq = B[j], q = eq & pmask;
-         if ((PACKED ? (eq >> ZH_MF_PACK_SHIFT) : zh_mf_hash<3>(win + q)) != h) break;
-         if (zh_ld24(win + q) == tri) {
-            found = q;
-            break;
+   // ---- exact trigram order -> previous occurrence of every trigram -------------------------------------------
+   if (stop == 1) return;
+   zh_mf_sort_pass<0, PACKED>(win, gwin, M3, nullptr, A, hist, wave_tot);
+   if (stop == 2) return;
+   zh_mf_sort_pass<1, PACKED>(win, gwin, M3, A, B, hist, wave_tot);
+   zh_mf_sort_pass<2, PACKED>(win, gwin, M3, B, A, hist, wave_tot);
+   if (stop == 3) return;
+   {
+      // only block positions need it (history positions get no rows); four entries per thread keep the loads overlapped
+      const uint32_t *__restrict__ Ar = A;
+      uint32_t *__restrict__ P3 = prev3;
+      for (uint32_t idx0 = tid; idx0 < M3; idx0 += 4 * ZH_MF_THREADS) {
+         uint32_t pos[4], q[4];
+#pragma unroll
+         for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t idx = idx0 + u * ZH_MF_THREADS;
+            pos[u] = idx < M3 ? Ar[idx] : 0u;
+            q[u] = (idx < M3 && idx > 0) ? Ar[idx - 1] : ZH_MF_NONE;
+         }
+#pragma unroll
+         for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t idx = idx0 + u * ZH_MF_THREADS;
+            if (idx < M3 && pos[u] >= first_needed) {
+               // same class => the nearest earlier occurrence (classes ascend in position)
+               const bool same = q[u] != ZH_MF_NONE && zh_ld24(gwin + q[u]) == zh_ld24(gwin + pos[u]);
+               P3[pos[u]] = same ? q[u] : ZH_MF_NONE;
+            }
          }
       }
-      prev3[pos] = found;
    }
    __syncthreads();
+   if (stop == 4) return;
 
    // ---- 4-gram order, class heads marked -------------------------------------------------------------------------
-   zh_mf_sort_pass<4, PACKED, 0>(win, M4, nullptr, A, hist, wave_tot);
-   zh_mf_sort_pass<4, PACKED, 1>(win, M4, A, B, hist, wave_tot);
-   for (uint32_t idx = tid; idx < M4; idx += ZH_MF_THREADS) {
-      const uint32_t e = B[idx], pos = e & pmask;
-      bool head = idx == 0;
-      if (!head) {
-         const uint32_t eq = B[idx - 1];
-         head = PACKED ? ((eq >> ZH_MF_PACK_SHIFT) != (e >> ZH_MF_PACK_SHIFT)) : (zh_mf_hash<4>(win + (eq & pmask)) != zh_mf_hash<4>(win + pos));
+   zh_mf_sort_pass<3, PACKED>(win, gwin, M4, nullptr, A, hist, wave_tot);
+   zh_mf_sort_pass<4, PACKED>(win, gwin, M4, A, B, hist, wave_tot);
+   if (stop == 5) return;
+   {
+      const uint32_t *__restrict__ Br = B;
+      uint32_t *__restrict__ Aw = A;
+      for (uint32_t idx0 = tid; idx0 < M4; idx0 += 4 * ZH_MF_THREADS) {
+         uint32_t e[4], eq[4];
+#pragma unroll
+         for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t idx = idx0 + u * ZH_MF_THREADS;
+            e[u] = idx < M4 ? Br[idx] : 0u;
+            eq[u] = (idx < M4 && idx > 0) ? Br[idx - 1] : 0u;
+         }
+#pragma unroll
+         for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t idx = idx0 + u * ZH_MF_THREADS;
+            if (idx < M4) {
+               const uint32_t pos = e[u] & pmask;
+               bool head = idx == 0;
+               if (!head)
+                  head = PACKED ? ((eq[u] >> ZH_MF_PACK_SHIFT) != (e[u] >> ZH_MF_PACK_SHIFT))
+                                : (zh_mf_hash<4>(gwin + (eq[u] & pmask)) != zh_mf_hash<4>(gwin + pos));
+               Aw[idx] = pos | (head ? ZH_MF_HEAD : 0u);   // the scan stops after consuming a marked entry
+            }
+         }
       }
-      A[idx] = pos | (head ? ZH_MF_HEAD : 0u);   // the scan stops after consuming a marked entry
    }
 }
 
+template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
 zh_mf_group(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, uint32_t *sort_a,
-            uint32_t *sort_b, uint32_t *prev3_all, uint64_t sort_stride) {
+            uint32_t *sort_b, uint32_t *prev3_all, uint64_t sort_stride, int stop) {
    __shared__ uint32_t hist[ZH_MF_WAVES * 256];
    __shared__ uint32_t wave_tot[ZH_MF_WAVES];
+   __shared__ uint32_t lwin32[LDS_WIN ? (ZH_MF_LDS_WINDOW / 4 + 4) : 1];
    const zh_block_t blk = blocks[blockIdx.x];
    const uint8_t *win = data + blk.win_off;
    const uint32_t W = blk.prev + blk.n;
    uint32_t *A = sort_a + (uint64_t)blockIdx.x * sort_stride;
    uint32_t *B = sort_b + (uint64_t)blockIdx.x * sort_stride;
    uint32_t *prev3 = prev3_all + (uint64_t)blockIdx.x * sort_stride;
+   const uint8_t *gwin = win;
+   if (LDS_WIN) {
+      zh_stage_window(lwin32, win, W);
+      gwin = (const uint8_t *)lwin32;
+   }
    if (W <= ZH_MF_PACK_MAXW)
-      zh_mf_group_body<true>(win, W, A, B, prev3, hist, wave_tot);
+      zh_mf_group_body<true>(win, gwin, W, blk.prev, A, B, prev3, hist, wave_tot, stop);
    else
-      zh_mf_group_body<false>(win, W, A, B, prev3, hist, wave_tot);
+      zh_mf_group_body<false>(win, gwin, W, blk.prev, A, B, prev3, hist, wave_tot, stop);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -228,9 +295,6 @@ __device__ __forceinline__ uint32_t zh_load32_at(const uint32_t *w32, uint32_t x
    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
 }
 
-// LDS_WIN: the whole window (<= ZH_MF_LDS_WINDOW bytes: 64 KiB max-blocks + 32 KiB history) is staged in LDS once
-// per workgroup with coalesced dword loads, so the byte probes of the scan hit the 160 KiB LDS instead of L1/L2.
-#define ZH_MF_LDS_WINDOW 98304
 
 template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
@@ -239,6 +303,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
                uint64_t match_stride) {
    __shared__ uint32_t next_chunk;
    __shared__ uint32_t lwin32[LDS_WIN ? (ZH_MF_LDS_WINDOW / 4 + 4) : 1];
+   __shared__ uint32_t mring[8 * ZH_MF_THREADS];   // per thread: ring of the last 8 accepted matches, [slot][thread]
 
    const zh_block_t blk = blocks[blockIdx.x];
    const uint8_t *gwin = data + blk.win_off;
@@ -252,17 +317,8 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
    const uint8_t *win = gwin;
 
    if (LDS_WIN) {
-      uint8_t *lw = (uint8_t *)lwin32;
-      if ((((uintptr_t)gwin) & 3u) == 0) {
-         const uint32_t *g32 = (const uint32_t *)gwin;
-         const uint32_t nw = W >> 2;
-         for (uint32_t k = threadIdx.x; k < nw; k += ZH_MF_THREADS) lwin32[k] = g32[k];
-         for (uint32_t k = (nw << 2) + threadIdx.x; k < W; k += ZH_MF_THREADS) lw[k] = gwin[k];
-      }
-      else {
-         for (uint32_t k = threadIdx.x; k < W; k += ZH_MF_THREADS) lw[k] = gwin[k];
-      }
-      win = lw;
+      zh_stage_window(lwin32, gwin, W);
+      win = (const uint8_t *)lwin32;
    }
    if (threadIdx.x == 0) next_chunk = 0;
    __syncthreads();
@@ -301,7 +357,8 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       const uint32_t i = own & ZH_MF_POS_MASK;
       const bool mine = t < M && i >= prev;
       const uint32_t maxlen = t < M ? min((uint32_t)ZH_MAX_MATCH, W - i) : 0;   // >= 4
-      uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0, m7 = 0;   // length | offset<<16
+      uint32_t nm = 0;                       // matches accepted so far; the last 8 sit in mring (length | offset<<16)
+      uint32_t *myring = mring + threadIdx.x;
       uint32_t cur = ZH_MIN_MATCH - 1;
       bool alive = false;
       const uint32_t first4 = mine ? (LDS_WIN ? zh_load32_at(lwin32, i) : zh_ld32(win + i)) : 0;
@@ -313,7 +370,8 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
             alive = !(own & ZH_MF_HEAD);   // a class head has no earlier 4-gram occurrence
             const uint32_t q4 = LDS_WIN ? zh_load32_at(lwin32, p3) : zh_ld32(win + p3);
             if (q4 != first4) {
-               m0 = ZH_MIN_MATCH | ((i - p3) << 16);
+               myring[0] = ZH_MIN_MATCH | ((i - p3) << 16);
+               nm = 1;
                cur = ZH_MIN_MATCH;
             }
          }
@@ -328,53 +386,36 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       uint32_t vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_SENTINEL;
       int vi = 63;
 
-      // one candidate against the lane's state; `probe` = the byte at p + fo + 3 if it was fetched while `fo` still had
-      // the value `probe_fo` (two candidates are probed per iteration so that their LDS latencies overlap)
-#define ZH_MF_CONSIDER(CAND, PROBE, PROBE_FO)                                                                     \
-      if (alive) {                                                                                                \
-         const uint32_t p = (CAND) & ZH_MF_POS_MASK;                                                              \
-         if (i - p > ZH_MAX_DIST)                                                                                 \
-            alive = false; /* also catches the sentinel */                                                        \
+      // A candidate can only beat `cur` if its bytes fo..fo+3 equal ci; one LDS byte probe (the last of the four) weeds out
+      // most, the 4-byte probe nearly all of the rest, the survivors get their true match length from byte 0 (a hash
+      // collision, or an entry of a neighbouring class met after the class head, fails there). Both probes of an
+      // iteration are issued before either is used; a probe taken before `cur` grew stays a valid pre-filter.
+#define ZH_MF_VERIFY(Q, D)                                                                                        \
+      if ((LDS_WIN ? zh_load32_at(lwin32, (Q) + fo) : zh_ld32(win + (Q) + fo)) == ci) {                           \
+         uint32_t l = 0;                                                                                          \
+         if (LDS_WIN) {                                                                                           \
+            /* four bytes per probe pair; bytes past the window end are garbage but l is clamped to maxlen */     \
+            while (l < maxlen) {                                                                                  \
+               const uint32_t x = zh_load32_at(lwin32, (Q) + l) ^ zh_load32_at(lwin32, i + l);                    \
+               if (x) {                                                                                           \
+                  l += (uint32_t)(__ffs((int)x) - 1) >> 3;                                                        \
+                  break;                                                                                          \
+               }                                                                                                  \
+               l += 4;                                                                                            \
+            }                                                                                                     \
+            l = min(l, maxlen);                                                                                   \
+         }                                                                                                        \
          else {                                                                                                   \
-            bool pass;                                                                                            \
-            if (LDS_WIN) {                                                                                        \
-               /* one byte probe for everybody (few LDS bank conflicts), the 4-byte probe only for those that pass it */ \
-               const uint32_t pb = (PROBE_FO) == fo ? (PROBE) : (uint32_t)win[p + fo + 3];                        \
-               pass = pb == (ci >> 24);                                                                           \
-               if (pass) pass = zh_load32_at(lwin32, p + fo) == ci;                                               \
+            while (l < maxlen && win[(Q) + l] == win[i + l]) l++;                                                 \
+         }                                                                                                        \
+         if (l > cur) {                                                                                           \
+            myring[(nm & 7u) * ZH_MF_THREADS] = l | ((D) << 16); /* offset 32768 needs all 16 bits */            \
+            nm++;                                                                                                 \
+            cur = l;                                                                                              \
+            if (cur < maxlen) {                                                                                   \
+               fo = cur - 3;                                                                                      \
+               ci = LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo);                               \
             }                                                                                                     \
-            else                                                                                                  \
-               pass = zh_ld32(win + p + fo) == ci;                                                                \
-            if (pass) { /* only then can it beat the incumbent */                                                 \
-               uint32_t l = 0; /* a colliding class member may differ in the first bytes */                       \
-               if (LDS_WIN) {                                                                                     \
-                  /* four bytes per probe pair; bytes past the window end are garbage but l is clamped to maxlen */ \
-                  while (l < maxlen) {                                                                            \
-                     const uint32_t x = zh_load32_at(lwin32, p + l) ^ zh_load32_at(lwin32, i + l);                \
-                     if (x) {                                                                                     \
-                        l += (uint32_t)(__ffs((int)x) - 1) >> 3;                                                  \
-                        break;                                                                                    \
-                     }                                                                                            \
-                     l += 4;                                                                                      \
-                  }                                                                                               \
-                  l = min(l, maxlen);                                                                             \
-               }                                                                                                  \
-               else {                                                                                             \
-                  while (l < maxlen && win[p + l] == win[i + l]) l++;                                             \
-               }                                                                                                  \
-               if (l > cur) {                                                                                     \
-                  m7 = m6; m6 = m5; m5 = m4; m4 = m3; m3 = m2; m2 = m1; m1 = m0;                                  \
-                  m0 = l | ((i - p) << 16); /* offset 32768 needs all 16 bits */                                  \
-                  cur = l;                                                                                        \
-                  if (cur >= maxlen)                                                                              \
-                     alive = false;                                                                               \
-                  else {                                                                                          \
-                     fo = cur - 3;                                                                                \
-                     ci = LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo);                         \
-                  }                                                                                               \
-               }                                                                                                  \
-            }                                                                                                     \
-            if ((CAND) & ZH_MF_HEAD) alive = false; /* that was the first entry of the class */                   \
          }                                                                                                        \
       }
 
@@ -389,23 +430,28 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
             vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_SENTINEL;
             vi = 63;
          }
-         uint32_t pb1 = 0, pb2 = 0;
-         const uint32_t fo0 = fo;
-         if (LDS_WIN && alive) {
-            // both byte probes are issued before either is used; a candidate beyond reach probes the lane's own position
+         if (alive) {
             const uint32_t q1 = c1 & ZH_MF_POS_MASK, q2 = c2 & ZH_MF_POS_MASK;
-            pb1 = win[(i - q1 > ZH_MAX_DIST ? i : q1) + fo + 3];
-            pb2 = win[(i - q2 > ZH_MAX_DIST ? i : q2) + fo + 3];
+            const uint32_t d1 = i - q1, d2 = i - q2;
+            const bool ok1 = d1 <= ZH_MAX_DIST, ok2 = d2 <= ZH_MAX_DIST;     // false for the sentinel too
+            const uint32_t pb1 = win[(ok1 ? q1 : i) + fo + 3], pb2 = win[(ok2 ? q2 : i) + fo + 3];
+            const uint32_t tgt = ci >> 24;
+            if (ok1 && pb1 == tgt) { ZH_MF_VERIFY(q1, d1) }
+            if (ok2 && pb2 == tgt && cur < maxlen) { ZH_MF_VERIFY(q2, d2) }
+            // the class ends at its head; beyond 32 KiB everything else is farther still; 258 (or the window end) cannot be beaten
+            alive = ok1 && ok2 && !((c1 | c2) & ZH_MF_HEAD) && cur < maxlen;
          }
-         ZH_MF_CONSIDER(c1, pb1, fo0)
-         ZH_MF_CONSIDER(c2, pb2, fo0)
       }
-#undef ZH_MF_CONSIDER
+#undef ZH_MF_VERIFY
       if (mine) {
+         // rows are longest first: the ring read backwards from the last accepted match
+         uint32_t m[8];
+#pragma unroll
+         for (uint32_t k = 0; k < 8; k++) m[k] = (k < nm) ? myring[((nm - 1 - k) & 7u) * ZH_MF_THREADS] : 0u;
          uint4 *r = (uint4 *)(rows + (uint64_t)(i - prev) * ZH_NMATCH);
          uint4 a, b2;
-         a.x = m0; a.y = m1; a.z = m2; a.w = m3;
-         b2.x = m4; b2.y = m5; b2.z = m6; b2.w = m7;
+         a.x = m[0]; a.y = m[1]; a.z = m[2]; a.w = m[3];
+         b2.x = m[4]; b2.y = m[5]; b2.z = m[6]; b2.w = m[7];
          r[0] = a;
          r[1] = b2;
       }
