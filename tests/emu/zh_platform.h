@@ -314,6 +314,11 @@ inline hipError_t hipStreamCreate(hipStream_t *s) {
    *s = nullptr;
    return 0;
 }
+#define hipStreamNonBlocking 1
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
+   *s = nullptr;
+   return 0;
+}
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline const char *hipGetErrorString(hipError_t) { return "emu"; }
@@ -327,6 +332,7 @@ inline hipError_t hipEventDestroy(hipEvent_t e) {
 }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) {
    *ms = 0.f;
    return 0;

@@ -59,6 +59,15 @@ struct zultra_hip_ctx_s {
    uint2 *d_taskmap;
    uint32_t *d_ntasks, *d_hist_part, *d_task_bits;
    hipEvent_t ev2[16];
+   // sub-batch pipelining: a batch runs as up to ZH_MAX_LANES contiguous runs of max-blocks, each on its own stream
+   int nlanes;
+   hipStream_t lane_stream[4];
+   hipEvent_t lane_ev[4][24];
+   hipEvent_t ev_input;
+   zh_subblock_t *d_results_compact;
+   // pinned host mirrors: async copies to pageable memory would block the host and serialise the runs
+   uint32_t *h_split_cnt, *h_sub_base, *h_crc;
+   zh_subblock_t *h_results;
    zh_stitch_item_t *d_items;
    uint32_t *d_stream;        // stitched deflate bits of the last batch
    size_t stream_cap;         // bytes
@@ -204,6 +213,17 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_task_bits);
    for (int i = 0; i < 16; i++)
       if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
+   for (int k = 0; k < 4; k++) {
+      for (int i = 0; i < 24; i++)
+         if (c->lane_ev[k][i]) (void)hipEventDestroy(c->lane_ev[k][i]);
+      if (c->lane_stream[k]) (void)hipStreamDestroy(c->lane_stream[k]);
+   }
+   if (c->ev_input) (void)hipEventDestroy(c->ev_input);
+   if (c->h_split_cnt) (void)hipHostFree(c->h_split_cnt);
+   if (c->h_sub_base) (void)hipHostFree(c->h_sub_base);
+   if (c->h_crc) (void)hipHostFree(c->h_crc);
+   if (c->h_results) (void)hipHostFree(c->h_results);
+   (void)hipFree(c->d_results_compact);
    (void)hipFree(c->d_items);
    (void)hipFree(c->d_stream);
    (void)hipFree(c->d_crc);
@@ -221,10 +241,26 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    ZH_CHECK(c, hipStreamCreate(&c->stream));
    for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->ev[i]));
    for (int i = 0; i < 16; i++) ZH_CHECK(c, hipEventCreate(&c->ev2[i]));
+   {
+      const char *e = getenv("ZULTRA_HIP_STREAMS");
+      c->nlanes = e ? atoi(e) : 2;
+      if (c->nlanes < 1) c->nlanes = 1;
+      if (c->nlanes > 4) c->nlanes = 4;
+      for (int k = 0; k < c->nlanes; k++) {
+         ZH_CHECK(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
+         for (int i = 0; i < 24; i++) ZH_CHECK(c, hipEventCreate(&c->lane_ev[k][i]));
+      }
+      ZH_CHECK(c, hipEventCreate(&c->ev_input));
+      if (zh_alloc(c, &c->d_results_compact, B * ZH_MAX_SPLITS)) return -1;
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_split_cnt, B * sizeof(uint32_t), 0));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_sub_base, B * sizeof(uint32_t), 0));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_crc, B * sizeof(uint32_t), 0));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_results, B * ZH_MAX_SPLITS * sizeof(zh_subblock_t), 0));
+   }
    c->bar_stride = c->tok_stride / 64;
    c->max_tasks = B * (N / ZH_TASK + ZH_MAX_SPLITS);
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * ZH_MAX_SPLITS) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
-       zh_alloc(c, &c->d_prev3, B * c->sort_stride) || zh_alloc(c, &c->d_ntasks, 1) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+       zh_alloc(c, &c->d_prev3, B * c->sort_stride) || zh_alloc(c, &c->d_ntasks, 4) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
@@ -302,123 +338,183 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       return -1;
    }
    ZH_CHECK(c, hipSetDevice(c->device));
-   hipStream_t st = c->stream;
    c->nblocks = nblocks;
    c->nsubs = 0;
    c->blocks.assign((const zh_block_t *)blocks, (const zh_block_t *)blocks + nblocks);
+   c->split_cnt.resize(nblocks);
+   c->sub_base.resize(nblocks);
+   c->crc.resize(nblocks);
+   c->payload_size = (size_t)nblocks * c->slot_stride;
+   c->payload_on_host = 0;
+   memset((void *)&c->timing, 0, sizeof(c->timing));
 
-   ZH_CHECK(c, hipEventRecord(c->ev[0], st));
+   // The batch is cut into `lanes` contiguous runs of max-blocks, each driven through the whole kernel sequence on its
+   // own stream. Max-blocks are independent, every per-block buffer is addressed as base + block * stride, so a run
+   // simply sees base pointers advanced to its first block. The single-wave, latency-bound kernels of one run
+   // (zh_split, zh_sb_build, ...) then overlap with the wide kernels of the others.
+   const int lanes = (nblocks >= 64u * (uint32_t)c->nlanes) ? c->nlanes : 1;
+   const int mf_stop = getenv("ZH_MF_STOP") ? atoi(getenv("ZH_MF_STOP")) : 0;   // timing experiments only
+   const uint64_t tasks_per_block = c->max_tasks / c->max_blocks;
+   hipStream_t st0 = c->lane_stream[0];
+
+   ZH_CHECK(c, hipEventRecord(c->lane_ev[0][0], st0));
    if (data_on_device)
       c->cur_data = (const uint8_t *)data;
    else {
-      ZH_CHECK(c, hipMemcpyAsync(c->d_data, data, data_size, hipMemcpyHostToDevice, st));
+      ZH_CHECK(c, hipMemcpyAsync(c->d_data, data, data_size, hipMemcpyHostToDevice, st0));
       c->cur_data = c->d_data;
    }
-   ZH_CHECK(c, hipMemcpyAsync(c->d_blocks, blocks, nblocks * sizeof(zh_block_t), hipMemcpyHostToDevice, st));
-   ZH_CHECK(c, hipEventRecord(c->ev[1], st));
+   ZH_CHECK(c, hipMemcpyAsync(c->d_blocks, blocks, nblocks * sizeof(zh_block_t), hipMemcpyHostToDevice, st0));
+   ZH_CHECK(c, hipEventRecord(c->ev_input, st0));
 
-   // stage 1: match rows
-   const int mf_stop = getenv("ZH_MF_STOP") ? atoi(getenv("ZH_MF_STOP")) : 0;   // timing experiments only
-   if (c->W <= ZH_MF_LDS_WINDOW)
-      ZH_LAUNCH(zh_mf_group<true>, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, c->d_sort_a, c->d_sort_b,
-                c->d_prev3, c->sort_stride, mf_stop);
-   else
-      ZH_LAUNCH(zh_mf_group<false>, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, c->d_sort_a, c->d_sort_b,
-                c->d_prev3, c->sort_stride, mf_stop);
-   ZH_CHECK(c, hipEventRecord(c->ev[6], st));
-   if (mf_stop) {   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
-      ZH_CHECK(c, hipStreamSynchronize(st));
-      (void)hipEventElapsedTime(&c->timing.group_ms, c->ev[1], c->ev[6]);
+   // ---- stages 1 and 2 of every run: match rows, token chain + barrier bitmap, splitter ----------------------------
+   for (int k = 0; k < lanes; k++) {
+      hipStream_t st = c->lane_stream[k];
+      hipEvent_t *ev = c->lane_ev[k];
+      const uint32_t b0 = (uint32_t)(((uint64_t)nblocks * k) / lanes), b1 = (uint32_t)(((uint64_t)nblocks * (k + 1)) / lanes);
+      const uint32_t nb = b1 - b0;
+      const zh_block_t *blk = c->d_blocks + b0;
+      if (k) {
+         ZH_CHECK(c, hipStreamWaitEvent(st, c->ev_input, 0));
+         // stagger the runs by one stage: this run's wide matchfinder kernels start when the previous run reaches its
+         // narrow ones (token chain, splitter), so narrow and wide kernels of different runs share the chip
+         ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k - 1][3], 0));
+      }
+      ZH_CHECK(c, hipEventRecord(ev[1], st));
+      if (c->W <= ZH_MF_LDS_WINDOW)
+         ZH_LAUNCH(zh_mf_group<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a + b0 * c->sort_stride, c->d_sort_b + b0 * c->sort_stride,
+                   c->d_prev3 + b0 * c->sort_stride, c->sort_stride, mf_stop);
+      else
+         ZH_LAUNCH(zh_mf_group<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a + b0 * c->sort_stride, c->d_sort_b + b0 * c->sort_stride,
+                   c->d_prev3 + b0 * c->sort_stride, c->sort_stride, mf_stop);
+      ZH_CHECK(c, hipEventRecord(ev[2], st));
+      if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
+      if (c->W <= ZH_MF_LDS_WINDOW)
+         ZH_LAUNCH(zh_mf_frontier<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)(c->d_sort_a + b0 * c->sort_stride),
+                   (const uint32_t *)(c->d_prev3 + b0 * c->sort_stride), c->sort_stride, c->d_match + b0 * c->match_stride, c->match_stride);
+      else
+         ZH_LAUNCH(zh_mf_frontier<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)(c->d_sort_a + b0 * c->sort_stride),
+                   (const uint32_t *)(c->d_prev3 + b0 * c->sort_stride), c->sort_stride, c->d_match + b0 * c->match_stride, c->match_stride);
+      ZH_CHECK(c, hipEventRecord(ev[3], st));
+      ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)(c->d_match + b0 * c->match_stride), c->match_stride,
+                c->d_tok_pos + b0 * c->tok_stride, c->d_tok_info + b0 * c->tok_stride, c->tok_stride, c->d_ntok + b0, c->d_bars + b0 * c->bar_stride,
+                c->bar_stride);
+      ZH_LAUNCH(zh_split, nb, 64, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride),
+                c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0);
+      ZH_CHECK(c, hipMemcpyAsync(c->h_split_cnt + b0, c->d_split_cnt + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipEventRecord(ev[4], st));
+   }
+   if (mf_stop) {
+      for (int k = 0; k < lanes; k++) ZH_CHECK(c, hipStreamSynchronize(c->lane_stream[k]));
+      (void)hipEventElapsedTime(&c->timing.group_ms, c->lane_ev[0][1], c->lane_ev[0][2]);
       snprintf(c->err, sizeof(c->err), "ZH_MF_STOP set: stopped after zh_mf_group");
       return -1;
    }
-   if (c->W <= ZH_MF_LDS_WINDOW)
-      ZH_LAUNCH(zh_mf_frontier<true>, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks,
-                (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3, c->sort_stride, c->d_match, c->match_stride);
-   else
-      ZH_LAUNCH(zh_mf_frontier<false>, nblocks, ZH_MF_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks,
-                (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3, c->sort_stride, c->d_match, c->match_stride);
-   ZH_CHECK(c, hipEventRecord(c->ev[2], st));
 
-   // stage 2: greedy token chain (+ barrier bitmap) and splitter
-   ZH_LAUNCH(zh_tokenize, nblocks, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const zh_match_t *)c->d_match, c->match_stride,
-             c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok, c->d_bars, c->bar_stride);
-   ZH_LAUNCH(zh_split, nblocks, 64, st, (const zh_block_t *)c->d_blocks, (const uint32_t *)c->d_tok_pos, (const uint16_t *)c->d_tok_info,
-             c->tok_stride, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt);
-   c->split_cnt.resize(nblocks);
-   c->sub_base.resize(nblocks);
-   ZH_CHECK(c, hipMemcpyAsync(c->split_cnt.data(), c->d_split_cnt, nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-   ZH_CHECK(c, hipEventRecord(c->ev[3], st));
-   ZH_CHECK(c, hipStreamSynchronize(st));
+   // ---- stage 3 of every run: the sub-block coder, one kernel per step over the run (zh_encode.h) -------------------
    uint32_t nsubs = 0;
-   uint64_t total_n = 0;
-   for (uint32_t b = 0; b < nblocks; b++) {
-      c->sub_base[b] = nsubs;
-      nsubs += c->split_cnt[b];
-      total_n += blocks[b].n;
-   }
-   ZH_CHECK(c, hipMemcpyAsync(c->d_sub_base, c->sub_base.data(), nblocks * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+   uint32_t lane_sub0[4], lane_nsubs[4];
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 4 * sizeof(uint32_t), st0));
+   ZH_CHECK(c, hipEventRecord(c->ev2[0], st0));
+   for (int k = 0; k < lanes; k++) {
+      hipStream_t st = c->lane_stream[k];
+      hipEvent_t *ev = c->lane_ev[k];
+      const uint32_t b0 = (uint32_t)(((uint64_t)nblocks * k) / lanes), b1 = (uint32_t)(((uint64_t)nblocks * (k + 1)) / lanes);
+      const uint32_t nb = b1 - b0;
+      const zh_block_t *blk = c->d_blocks + b0;
+      ZH_CHECK(c, hipEventSynchronize(ev[4]));   // split counts of this run are on the host; later runs keep the GPU busy meanwhile
+      uint32_t ns = 0;
+      uint64_t total_n = 0;
+      for (uint32_t b = b0; b < b1; b++) {
+         c->split_cnt[b] = c->h_split_cnt[b];
+         c->h_sub_base[b] = c->sub_base[b] = ns;   // sub-block indices are local to the run
+         ns += c->split_cnt[b];
+         total_n += blocks[b].n;
+      }
+      lane_sub0[k] = nsubs;
+      lane_nsubs[k] = ns;
+      nsubs += ns;
+      // per-sub-block and per-task buffers of the run start at its worst-case offset
+      const uint64_t s0 = (uint64_t)b0 * ZH_MAX_SPLITS, t0 = (uint64_t)b0 * tasks_per_block;
+      zh_work_t *work = c->d_work + s0;
+      zh_sbstate_t *states = c->d_states + s0;
+      uint2 *taskmap = c->d_taskmap + t0;
+      uint32_t *ntasks = c->d_ntasks + k;
+      uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM;
+      uint32_t *task_bits = c->d_task_bits + t0;
+      uint8_t *payload = c->d_payload + (uint64_t)b0 * c->slot_stride;
+      uint32_t *best = c->d_best + b0 * c->best_stride;
+      const uint64_t *bars = c->d_bars + b0 * c->bar_stride;
+      const zh_match_t *match = c->d_match + b0 * c->match_stride;
+      const uint32_t task_grid = (uint32_t)(total_n / ZH_TASK) + ns;   // >= number of tasks; surplus waves exit at once
 
-   // stage 3: sub-block coder, one kernel per step over the whole batch (zh_encode.h)
-   const uint32_t task_grid = (uint32_t)(total_n / ZH_TASK) + nsubs;   // >= number of tasks; surplus waves exit at once
-   c->payload_size = (size_t)nblocks * c->slot_stride;
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, sizeof(uint32_t), st));
-   ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, c->payload_size, st));   // token bits are ORed into the slots
-   ZH_LAUNCH(zh_plan_subblocks, (nblocks + 63) / 64, 64, st, (const zh_block_t *)c->d_blocks, nblocks, (const uint32_t *)c->d_tok_pos,
-             c->tok_stride, (const uint32_t *)c->d_ntok, (const uint32_t *)c->d_split_tok, (const uint32_t *)c->d_split_cnt,
-             (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work, c->d_taskmap, c->d_ntasks);
-   ZH_LAUNCH(zh_sb_init, nsubs, 64, st, (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_states);
-   ZH_CHECK(c, hipEventRecord(c->ev2[0], st));
-   for (int pass = 0; pass <= 3; pass++) {
-      ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const zh_match_t *)c->d_match,
-                c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap,
-                (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride, c->d_hist_part, pass);
-      ZH_CHECK(c, hipEventRecord(c->ev2[1 + 2 * pass], st));
-      ZH_LAUNCH(zh_sb_build, nsubs, 64, st, (const zh_work_t *)c->d_work, c->d_states, (const uint32_t *)c->d_hist_part, c->d_payload, pass);
-      ZH_CHECK(c, hipEventRecord(c->ev2[2 + 2 * pass], st));
+      if (k) ZH_CHECK(c, hipStreamWaitEvent(st, c->ev2[0], 0));         // task counters cleared
+      ZH_CHECK(c, hipMemcpyAsync(c->d_sub_base + b0, c->h_sub_base + b0, nb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+      ZH_CHECK(c, hipMemsetAsync(payload, 0, (size_t)nb * c->slot_stride, st));   // token bits are ORed into the slots
+      ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), c->tok_stride,
+                (const uint32_t *)(c->d_ntok + b0), (const uint32_t *)(c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1)),
+                (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
+      ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
+      ZH_CHECK(c, hipEventRecord(ev[5], st));
+      for (int pass = 0; pass <= 3; pass++) {
+         ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+                   (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass);
+         ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));
+         ZH_LAUNCH(zh_sb_build, ns, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass);
+         ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));
+      }
+      ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
+                (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, task_bits);
+      ZH_CHECK(c, hipEventRecord(ev[14], st));
+      ZH_LAUNCH(zh_emit_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
+                (const uint32_t *)ntasks, (const zh_sbstate_t *)states, (const uint32_t *)best, c->best_stride, (const uint32_t *)task_bits, payload,
+                c->d_results + s0);
+      ZH_CHECK(c, hipEventRecord(ev[15], st));
+      // per-max-block CRC-32 (linear part) for the gzip footer
+      ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0);
+      ZH_CHECK(c, hipMemcpyAsync(c->h_results + lane_sub0[k], c->d_results + s0, ns * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipMemcpyAsync(c->h_crc + b0, c->d_crc + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipEventRecord(ev[16], st));
    }
-   ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const uint64_t *)c->d_bars, c->bar_stride,
-             (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states,
-             c->d_best, c->best_stride, c->d_task_bits);
-   ZH_CHECK(c, hipEventRecord(c->ev2[9], st));
-   ZH_LAUNCH(zh_emit_tasks, task_grid, 64, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const uint64_t *)c->d_bars, c->bar_stride,
-             (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states,
-             (const uint32_t *)c->d_best, c->best_stride, (const uint32_t *)c->d_task_bits, c->d_payload, c->d_results);
-   ZH_CHECK(c, hipEventRecord(c->ev[4], st));
-
-   // per-max-block CRC-32 (linear part) for the gzip footer
-   ZH_LAUNCH(zh_crc32_blocks, nblocks, ZH_CRC_THREADS, st, c->cur_data, (const zh_block_t *)c->d_blocks, (const uint32_t *)c->d_crc_tables, c->d_crc);
-   c->results.resize(nsubs);
-   c->crc.resize(nblocks);
-   c->payload_on_host = 0;
-   ZH_CHECK(c, hipMemcpyAsync(c->results.data(), c->d_results, nsubs * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
-   ZH_CHECK(c, hipMemcpyAsync(c->crc.data(), c->d_crc, nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-   ZH_CHECK(c, hipEventRecord(c->ev[5], st));
-   ZH_CHECK(c, hipStreamSynchronize(st));
+   for (int k = 0; k < lanes; k++) ZH_CHECK(c, hipStreamSynchronize(c->lane_stream[k]));
    ZH_CHECK(c, hipGetLastError());
+   // sub-block descriptors in batch coordinates
+   c->results.assign(c->h_results, c->h_results + nsubs);
+   memcpy(c->crc.data(), c->h_crc, nblocks * sizeof(uint32_t));
+   for (int k = 0; k < lanes; k++) {
+      const uint32_t b0 = (uint32_t)(((uint64_t)nblocks * k) / lanes);
+      for (uint32_t i = 0; i < lane_nsubs[k]; i++) {
+         zh_subblock_t &r = c->results[lane_sub0[k] + i];
+         r.block += b0;
+         r.bits_off += (uint64_t)b0 * c->slot_stride;
+      }
+   }
    c->nsubs = nsubs;
 
-   (void)hipEventElapsedTime(&c->timing.h2d_ms, c->ev[0], c->ev[1]);
-   (void)hipEventElapsedTime(&c->timing.matchfinder_ms, c->ev[1], c->ev[2]);
-   (void)hipEventElapsedTime(&c->timing.group_ms, c->ev[1], c->ev[6]);
-   (void)hipEventElapsedTime(&c->timing.frontier_ms, c->ev[6], c->ev[2]);
-   (void)hipEventElapsedTime(&c->timing.tokenize_split_ms, c->ev[2], c->ev[3]);
-   (void)hipEventElapsedTime(&c->timing.encode_ms, c->ev[3], c->ev[4]);
-   (void)hipEventElapsedTime(&c->timing.d2h_ms, c->ev[4], c->ev[5]);
-   (void)hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[5]);
-   {
+   // device time per kernel group, summed over the runs (they overlap in wall time); total = first launch to last completion
+   for (int k = 0; k < lanes; k++) {
+      hipEvent_t *ev = c->lane_ev[k];
       float t = 0;
-      (void)hipEventElapsedTime(&c->timing.init_ms, c->ev[3], c->ev2[0]);
-      c->timing.parse_ms = c->timing.build_ms = 0;
+      auto add = [&](float &acc, hipEvent_t a, hipEvent_t b) {
+         if (hipEventElapsedTime(&t, a, b) == hipSuccess) acc += t;
+      };
+      add(c->timing.group_ms, ev[1], ev[2]);
+      add(c->timing.frontier_ms, ev[2], ev[3]);
+      add(c->timing.tokenize_split_ms, ev[3], ev[4]);
+      add(c->timing.init_ms, ev[4], ev[5]);
       for (int pass = 0; pass <= 3; pass++) {
-         (void)hipEventElapsedTime(&t, c->ev2[2 * pass], c->ev2[1 + 2 * pass]);
-         c->timing.parse_ms += t;
-         (void)hipEventElapsedTime(&t, c->ev2[1 + 2 * pass], c->ev2[2 + 2 * pass]);
-         c->timing.build_ms += t;
+         add(c->timing.parse_ms, ev[5 + 2 * pass], ev[6 + 2 * pass]);
+         add(c->timing.build_ms, ev[6 + 2 * pass], ev[7 + 2 * pass]);
       }
-      (void)hipEventElapsedTime(&c->timing.post_ms, c->ev2[8], c->ev2[9]);
-      (void)hipEventElapsedTime(&c->timing.emit_ms, c->ev2[9], c->ev[4]);
+      add(c->timing.post_ms, ev[13], ev[14]);
+      add(c->timing.emit_ms, ev[14], ev[15]);
+      add(c->timing.d2h_ms, ev[15], ev[16]);
+      float tot = 0;
+      if (hipEventElapsedTime(&tot, c->lane_ev[0][0], ev[16]) == hipSuccess && tot > c->timing.total_ms) c->timing.total_ms = tot;
    }
+   (void)hipEventElapsedTime(&c->timing.h2d_ms, c->lane_ev[0][0], c->ev_input);
+   c->timing.matchfinder_ms = c->timing.group_ms + c->timing.frontier_ms;
+   c->timing.encode_ms = c->timing.init_ms + c->timing.parse_ms + c->timing.build_ms + c->timing.post_ms + c->timing.emit_ms;
    return (int)nsubs;
 }
 
@@ -466,7 +562,8 @@ extern "C" int zultra_hip_stitch_device(zultra_hip_ctx_t *c, zultra_hip_bitstate
    ZH_CHECK(c, hipEventRecord(c->ev[0], st));
    ZH_CHECK(c, hipMemsetAsync(c->d_stream, 0, (nbytes + 8 + 3) & ~(size_t)3, st));
    ZH_CHECK(c, hipMemcpyAsync(c->d_items, c->items.data(), c->nsubs * sizeof(zh_stitch_item_t), hipMemcpyHostToDevice, st));
-   ZH_LAUNCH(zh_stitch, c->nsubs, ZH_STITCH_THREADS, st, (const zh_subblock_t *)c->d_results, (const zh_stitch_item_t *)c->d_items,
+   ZH_CHECK(c, hipMemcpyAsync(c->d_results_compact, c->results.data(), c->nsubs * sizeof(zh_subblock_t), hipMemcpyHostToDevice, st));
+   ZH_LAUNCH(zh_stitch, c->nsubs, ZH_STITCH_THREADS, st, (const zh_subblock_t *)c->d_results_compact, (const zh_stitch_item_t *)c->d_items,
              (const zh_block_t *)c->d_blocks, c->cur_data, (const uint8_t *)c->d_payload, c->d_stream);
    ZH_CHECK(c, hipEventRecord(c->ev[1], st));
    ZH_CHECK(c, hipStreamSynchronize(st));
