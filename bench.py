@@ -28,6 +28,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def committed_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json, written by
+    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    k = t.get("kernels", {}).get(kernel)
+    if not k:
+        return None, os.path.basename(files[-1])
+    return int(k["hbm_bytes_per_launch"]), os.path.basename(files[-1])
+
+
 def find_enwik8():
     for p in (os.environ.get("ZULTRA_ENWIK8"), os.path.join(ROOT, "data", "enwik8"), "/data/enwik8", os.path.expanduser("~/enwik8")):
         if p and os.path.exists(p) and os.path.getsize(p) == 100_000_000:
@@ -73,6 +88,8 @@ def main():
     ap.add_argument("--block", type=int, default=65536)
     ap.add_argument("--cpu-sample", type=int, default=32 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for rocprofv3 passes: only the steps (no round-trip / ratio / CPU extras that would add dispatches), then the PMC calibration probe")
     args = ap.parse_args()
 
     import torch
@@ -166,13 +183,21 @@ def main():
                    "zh_tokenize+zh_split": avg["tokenize_split_ms"], "zh_plan_subblocks+zh_sb_init": avg["init_ms"],
                    "zh_parse_tasks": avg["parse_ms"], "zh_sb_build": avg["build_ms"], "zh_post_tasks": avg["post_ms"],
                    "zh_emit_tasks": avg["emit_ms"], "zh_stitch": avg["stitch_ms"]}
-        launches = {k: 1 for k in kernels}
-        launches["zh_parse_tasks"] = launches["zh_sb_build"] = 4   # one launch per optimal-parse pass
+        # the library runs a batch as `runs` staggered runs of max-blocks on separate streams (ZULTRA_HIP_STREAMS, default 2):
+        # every kernel is launched once per run (the parse / code-rebuild pair once per pass and run) over 1/runs of the batch
+        runs = max(1, min(4, int(os.environ.get("ZULTRA_HIP_STREAMS", "2"))))
+        if nblocks < 64 * runs:
+            runs = 1
+        launches = {k: runs for k in kernels}
+        launches["zh_parse_tasks"] = launches["zh_sb_build"] = 4 * runs
+        launches["zh_stitch"] = 1
         dom = max(kernels, key=lambda k: kernels[k])
         out_bytes = len(body) / world
-        alg_bytes = n + out_bytes   # 1 B read + r B written per input byte, per launch over the batch
+        # 1 B read + r B written per input byte; one launch covers 1/runs of the batch
+        alg_bytes = (n + out_bytes) / (runs if dom != "zh_stitch" else 1)
         launch_ms = kernels[dom] / launches[dom]
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+        traffic, traffic_src = committed_traffic(dom)
         line = {
             "metric": "input MB/s, gzip 64 KiB max-blocks, enwik8-sized text, bit-exact vs CPU zultra",
             "value": round(total_in / (dt / args.steps) / 1e6, 3), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
@@ -186,10 +211,15 @@ def main():
             "kernel_only_MBps": round(n / (sum(kernels.values()) * 1e-3) / 1e6, 3),
             "compressed_bytes_per_gpu": int(out_bytes),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(launch_ms, 3),
                          "launches_per_step": launches[dom]},
         }
+        if args.profile_run:
+            L.traffic_probe(256 << 20)
+            print(json.dumps(line), flush=True)
+            ctx.close()
+            return
         # outside the timed region: the stream must inflate to the input, and match zlib-9 ratio expectations
         import zlib
         hdr = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 2, 255])
@@ -206,7 +236,7 @@ def main():
             d = zlib.decompressobj(-15)
             first = d.decompress(body, n)   # rank 0's shard must come back exactly
             line["inflate_roundtrip_ok"] = bool(first == shard.tobytes())
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
             sample = shard[: min(args.cpu_sample, n)]
             cb, ref_out = cpu_baseline(sample, flags, bs)
             line["cpu_baseline"] = cb

@@ -66,6 +66,10 @@ int zultra_hip_device_count(void);
  * against plain LDS arithmetic. Returns 0 when they agree, a positive count of mismatches, negative on HIP errors. */
 int zultra_hip_selftest(void);
 
+/* Diagnostics: a streaming 4-byte-per-lane copy of `nbytes`, used to calibrate the rocprofv3 FETCH_SIZE / WRITE_SIZE
+ * counters for this access width (profiles/, tools/pmc_traffic.py). Returns 0 on success. */
+int zultra_hip_traffic_probe(size_t nbytes);
+
 /* Create a context on `device` able to take batches of up to max_blocks max-blocks of up to max_block_size bytes
  * (clamped like libzultra.c:87-92). All device memory is allocated here and released by zultra_hip_destroy
  * (the reference allocates in zultra_stream_init and frees in zultra_stream_end, libzultra.c:82-166,521-565).

@@ -24,8 +24,8 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 E = Lib(build_emu.build())
 bs = 32768
-t = corpus.text_like(60000, 5)
-data = np.concatenate([t[:30000], corpus.noise(36000, 3), t[30000:52000]])   # 88000 B: 3 max-blocks, the middle one stored
+t = corpus.text_like(40000, 5)
+data = np.concatenate([t[:30000], corpus.noise(6000, 3), t[30000:31000]])   # 37000 B: 2 max-blocks (one per rank), a stored sub-block across the cut
 n = len(data)
 nb = (n + bs - 1) // bs
 lo, hi = sharded.shard_range(nb, rank, world)

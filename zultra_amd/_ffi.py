@@ -66,7 +66,7 @@ EXPORTS = [
     "zultra_frame_update_checksum", "zultra_frame_get_footer_size", "zultra_frame_encode_footer",
     "zultra_dictionary_load", "zultra_dictionary_free",
     # include/zultra_hip.h
-    "zultra_hip_device_count", "zultra_hip_selftest", "zultra_hip_create", "zultra_hip_destroy", "zultra_hip_last_error",
+    "zultra_hip_device_count", "zultra_hip_selftest", "zultra_hip_traffic_probe", "zultra_hip_create", "zultra_hip_destroy", "zultra_hip_last_error",
     "zultra_hip_data_capacity", "zultra_hip_compress_blocks", "zultra_hip_subblocks", "zultra_hip_payload",
     "zultra_hip_last_timing", "zultra_hip_get_matches", "zultra_hip_get_splits", "zultra_hip_get_parse",
     "zultra_hip_stitch", "zultra_hip_stitch_finish",
@@ -137,6 +137,10 @@ class Lib:
     # ---- libzultra.h -------------------------------------------------------------------------------------
     def device_count(self):
         return self.L.zultra_hip_device_count()
+
+    def traffic_probe(self, nbytes):
+        self.L.zultra_hip_traffic_probe.argtypes = [C.c_size_t]
+        return self.L.zultra_hip_traffic_probe(nbytes)
 
     def memory_bound(self, n, flags, max_block=0):
         return self.L.zultra_memory_bound(n, flags, max_block)

@@ -174,6 +174,30 @@ extern "C" int zultra_hip_selftest(void) {
    return (int)bad;
 }
 
+// ---- PMC calibration probe ---------------------------------------------------------------------------------------
+// A streaming dword copy of a known size, in the access width the hot kernels use (4 B per lane). Run under
+// rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE it tells how many bytes the counters report per byte moved for this width
+// (MI355X_MICROARCH.md: only 16 B/lane streams are calibrated; other widths must be calibrated in place).
+__global__ void __launch_bounds__(256) zh_probe_copy_dword(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, size_t nwords) {
+   for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < nwords; k += (size_t)gridDim.x * 256) dst[k] = src[k] + 1u;
+}
+
+extern "C" int zultra_hip_traffic_probe(size_t nbytes) {
+   uint32_t *a = NULL, *b = NULL;
+   const size_t nwords = nbytes / 4;
+   if (hipMalloc((void **)&a, nwords * 4) != hipSuccess) return -1;
+   if (hipMalloc((void **)&b, nwords * 4) != hipSuccess) {
+      (void)hipFree(a);
+      return -1;
+   }
+   (void)hipMemset(a, 1, nwords * 4);
+   ZH_LAUNCH(zh_probe_copy_dword, 256 * 16, 256, 0, (const uint32_t *)a, b, nwords);
+   const hipError_t e = hipDeviceSynchronize();
+   (void)hipFree(a);
+   (void)hipFree(b);
+   return e == hipSuccess ? 0 : -2;
+}
+
 extern "C" int zultra_hip_device_count(void) {
    int n = 0;
    if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -34,8 +34,12 @@
 #include "zh_common.h"
 #include "zh_split.h"
 
+#ifndef ZH_TASK
 #define ZH_TASK 2048        // target positions per task
+#endif
+#ifndef ZH_PIECE
 #define ZH_PIECE 128        // target positions per piece
+#endif
 #define ZH_MAXPIECES 64
 #define ZH_NSYM (ZH_NLIT + ZH_NDIST)
 #define ZH_KEY_BIAS (1u << 22)   // candidate costs enter the 23-bit key field relative to cost[p+1], biased by this
