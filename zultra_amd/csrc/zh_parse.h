@@ -42,7 +42,10 @@
 #endif
 #define ZH_MAXPIECES 64
 #define ZH_NSYM (ZH_NLIT + ZH_NDIST)
-#define ZH_KEY_BIAS (1u << 22)   // candidate costs enter the 23-bit key field relative to cost[p+1], biased by this
+// Costs are kept modulo 2^16: within the 258 positions a step can look ahead, two costs differ by less than 258 x 15 bits
+// (either can be reached from the other by literals), so candidate costs relative to cost[p+1], biased by 2^14, stay
+// inside 15 bits and compare exactly like the reference's 32-bit sums.
+#define ZH_KEY_BIAS (1u << 14)
 
 // sub-block work item produced by zh_plan_subblocks
 struct zh_work_t {
@@ -117,7 +120,7 @@ __device__ inline void zh_walk_histogram_wave(uint32_t *hist /* ZH_NSYM, zeroed 
 // ---- the parse kernel ---------------------------------------------------------------------------------------------
 struct zh_parse_ws_t {
    union {
-      int32_t ring[4][512];          // per row: cost[p & 511] of its current piece (the reference's cost[], blockdeflate.c:255)
+      uint16_t ring[4][512];         // per row: cost[p & 511] mod 2^16 of its current piece (the reference's cost[], blockdeflate.c:255)
       uint32_t hist[ZH_NSYM];        // after the parse: histogram of the task
    };
    uint4 rec[4][16];                 // per staged position: x = bitmap of short slot lengths 3..34, y/z = running minima
@@ -197,7 +200,7 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
    uint32_t p_lo = 0, p_hi = 0;            // what is left of the row's piece: [p_lo, p_hi)
    uint32_t n_lo = 0, n_cnt = 0;           // the prefetched tile: positions n_lo + 0..n_cnt-1
    bool n_top = false;                     // the prefetched tile is the top of its piece (recurrence restarts there)
-   int32_t cost_next = 0;
+   uint32_t cost_next = 0;                 // cost[p+1] mod 2^16
    zh_tile_regs_t regs;
 
    // picks the row's next tile (popping a new piece if the current one is used up) and issues its loads
@@ -286,12 +289,12 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          uint4 R = ws.rec[row][a];
          if (!act) R.w = 0;
          const uint32_t kmax = ZH_REC_KMAX(R.w), nlong = ZH_REC_NLONG(R.w), nhi = ZH_REC_NHI(R.w);
-         const uint32_t base = (uint32_t)cost_next - ZH_KEY_BIAS;   // key cost = candidate cost - base (fits 23 bits)
+         const uint32_t base = cost_next - ZH_KEY_BIAS;   // key cost = (candidate cost - base) mod 2^16, below 2^15
          uint32_t key = 0xFFFFFFFFu;
          if (3 + s <= kmax) {
             const uint32_t sel = (uint32_t)__popc(R.x >> s) + nhi - 1u;            // index of the last short slot reaching 3+s
             const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
-            const uint32_t c = lc0 + (b >> 3) + (uint32_t)ws.ring[row][(p + 3 + s) & 511] - base;
+            const uint32_t c = (lc0 + (b >> 3) + (uint32_t)ws.ring[row][(p + 3 + s) & 511] - base) & 0xffffu;
             key = (c << 9) | ((b & 7u) << 6) | (36u - s);                          // 39 - k
          }
          // rarely needed: lengths 19..39, and slots stored with length >= 40
@@ -299,13 +302,13 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
             if (19 + s <= kmax) {
                const uint32_t sel = (uint32_t)__popc(R.x >> (16 + s)) + nhi - 1u;
                const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
-               const uint32_t c = lc1 + (b >> 3) + (uint32_t)ws.ring[row][(p + 19 + s) & 511] - base;
+               const uint32_t c = (lc1 + (b >> 3) + (uint32_t)ws.ring[row][(p + 19 + s) & 511] - base) & 0xffffu;
                key = min(key, (c << 9) | ((b & 7u) << 6) | (20u - s));
             }
             if (s < 5 && 35 + s <= kmax) {
                const uint32_t sel = (uint32_t)__popc((R.w & 31u) >> s) - 1u;
                const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
-               const uint32_t c = lc2 + (b >> 3) + (uint32_t)ws.ring[row][(p + 35 + s) & 511] - base;
+               const uint32_t c = (lc2 + (b >> 3) + (uint32_t)ws.ring[row][(p + 35 + s) & 511] - base) & 0xffffu;
                key = min(key, (c << 9) | ((b & 7u) << 6) | (4u - s));
             }
             if (s < nlong) {                                                        // long slot s: full (clamped) length only
@@ -313,18 +316,19 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
                const uint32_t mlen = min(e & 511u, sb_end - p);
                uint32_t enc = mlen - ZH_MIN_MATCH;                                  // wraps below 3, then saturates (:289, :216-219)
                if (enc > 255) enc = 255;
-               const uint32_t c = (uint32_t)ws.lencost[enc] + ((e >> 9) & 31u) + (uint32_t)ws.ring[row][(p + mlen) & 511] - base;
+               const uint32_t c = ((uint32_t)ws.lencost[enc] + ((e >> 9) & 31u) + (uint32_t)ws.ring[row][(p + mlen) & 511] - base) & 0xffffu;
                key = min(key, (c << 9) | (s << 6));
             }
          }
          const uint32_t rkey = zh_row_min(key);   // every lane of a row now holds that row's best match candidate
-         // literal first; a match must be strictly cheaper (:292,:307). An absent candidate (all ones) prices at 2^23-1.
+         // literal first; a match must be strictly cheaper (:292,:307). An absent candidate (all ones) prices at 2^23-1,
+         // above any literal (5 bits + bias).
          const uint32_t lit = ZH_REC_LIT(R.w) + ZH_KEY_BIAS, mc = rkey >> 9;
          const bool take = mc < lit;
-         const int32_t c = (int32_t)(base + (take ? mc : lit));
+         const uint32_t c = (base + (take ? mc : lit)) & 0xffffu;
          if (act) {
             if (s == 0) {
-               ws.ring[row][p & 511] = c;
+               ws.ring[row][p & 511] = (uint16_t)c;
                ws.bt[row][a] = take ? rkey : 0xFFFFFFFFu;
             }
             cost_next = c;
