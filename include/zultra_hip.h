@@ -135,6 +135,21 @@ int zultra_hip_stitch_device(zultra_hip_ctx_t *ctx, zultra_hip_bitstate_t *state
 const void *zultra_hip_stream_device(const zultra_hip_ctx_t *ctx);
 int zultra_hip_stream_read(zultra_hip_ctx_t *ctx, void *out, size_t offset, size_t nbytes);
 
+/*
+ * Many small independent inputs ("files", BASELINE.json configuration 5: 4 KiB records, each its own stream). A files
+ * context takes inputs below 8192 bytes — the splitter never cuts those (blockdeflate.c:646), so a batch needs no host
+ * decision and its whole kernel sequence is replayed from one captured hipGraph. zultra_hip_compress_files runs
+ * stages 1-3 with every input as a max-block without history, then lays the raw deflate streams end to end in the
+ * device stream buffer (zultra_hip_stream_read): input i occupies bytes file_off[i] .. file_off[i+1]. Each equals what
+ * zultra_memory_compress(input i, ZULTRA_FLAG_RAW_DEFLATE) produces; gzip framing = 10-byte header + these bytes +
+ * CRC-32 (zultra_hip_block_crc32 / zultra_crc32_append) + ISIZE. zultra_hip_stitch_files does the assembly alone for a
+ * batch already compressed with zultra_hip_compress_blocks. Returns the number of inputs, or a negative error.
+ */
+zultra_hip_ctx_t *zultra_hip_create_files(int device, uint32_t max_file_size, uint32_t max_files);
+int zultra_hip_compress_files(zultra_hip_ctx_t *ctx, const void *data, size_t data_size, int data_on_device, const uint64_t *offsets,
+                              const uint32_t *sizes, uint32_t nfiles, uint64_t *file_off /* nfiles + 1 */);
+int zultra_hip_stitch_files(zultra_hip_ctx_t *ctx, uint64_t *file_off /* blocks + 1 */);
+
 /* CRC-32 of every max-block of the last batch, computed on the device while the blocks are compressed: out[b] is the
  * linear part (zero initial state, no final inversion). zultra_crc32_append() folds one block into a running gzip CRC
  * exactly as zultra_frame_update_checksum(crc, block, len, GZIP) would (reference src/frame.c:324-354,473-480). */

@@ -333,6 +333,10 @@ inline hipError_t hipEventDestroy(hipEvent_t e) {
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+typedef void *hipGraph_t;       // the emulator runs the plain kernel sequence; graphs only exist as null handles
+typedef void *hipGraphExec_t;
+inline hipError_t hipGraphDestroy(hipGraph_t) { return 0; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) {
    *ms = 0.f;
    return 0;

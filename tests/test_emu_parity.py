@@ -111,3 +111,22 @@ def test_memory_bound_and_checksums(emu, oracle):
     d = corpus.text_like(70001, 4)
     assert emu.checksum(d, 2) == zlib.crc32(d.tobytes())
     assert emu.checksum(d, 1) == zlib.adler32(d.tobytes())
+
+
+def test_files_mode_each_input_is_its_own_stream(emu, oracle):
+    # BASELINE configuration 5 in miniature: small JSON-like records, one raw deflate stream each
+    files = [corpus.json_like(n, 40 + k) for k, n in enumerate((4096, 1500, 1, 3000))]
+    data = np.concatenate(files)
+    offs = np.cumsum([0] + [len(f) for f in files[:-1]])
+    ctx = emu.files_context(4096, len(files))
+    try:
+        fo = ctx.compress_files(data, offs, [len(f) for f in files])
+        stream = ctx.stream_read(int(fo[-1]))
+        for k, f in enumerate(files):
+            got = stream[int(fo[k]):int(fo[k + 1])].tobytes()
+            assert got == oracle.memory_compress(f, 0, 32768), k
+            assert zlib.decompress(got, -15) == f.tobytes()
+        for k, lin in enumerate(ctx.block_crc32()):
+            assert emu.crc32_append(0, lin, len(files[k])) == zlib.crc32(files[k].tobytes())
+    finally:
+        ctx.close()

@@ -128,3 +128,28 @@ def test_full_size_properties(gpu, oracle):
         lo = blk * 65536
         prev = 32768 if blk else 0
         check_window(gpu, oracle, d[lo - prev: lo + 65536], prev, 65536, max_block=65536, tag="blk%d" % blk)
+
+
+def test_files_mode_graph_replay_vs_oracle(gpu, oracle):
+    """BASELINE configuration 5 in miniature: many small JSON-like inputs, one raw deflate stream each, the kernel sequence
+    captured in a hipGraph on the first batch and replayed on the second (different contents, same batch shape)."""
+    nfiles = 300
+    ctx = gpu.files_context(4096, nfiles)
+    try:
+        for batch in range(2):
+            rs = np.random.RandomState(50 + batch)
+            sizes = [4096] * 200 + [int(x) for x in rs.randint(1, 4097, size=nfiles - 200)]
+            files = [corpus.json_like(n, 1000 * batch + k) if k % 7 else corpus.noise(n, k) for k, n in enumerate(sizes)]
+            data = np.concatenate(files)
+            offs = np.cumsum([0] + sizes[:-1])
+            fo = ctx.compress_files(data, offs, sizes)
+            stream = ctx.stream_read(int(fo[-1]))
+            crcs = ctx.block_crc32()
+            for k in range(0, nfiles, 1 if batch == 0 else 3):
+                got = stream[int(fo[k]):int(fo[k + 1])].tobytes()
+                assert zlib.decompress(got, -15) == files[k].tobytes(), (batch, k)
+                if k % 5 == 0:
+                    assert got == oracle.memory_compress(files[k], 0, 32768), (batch, k)
+                assert gpu.crc32_append(0, crcs[k], sizes[k]) == zlib.crc32(files[k].tobytes())
+    finally:
+        ctx.close()

@@ -71,6 +71,7 @@ EXPORTS = [
     "zultra_hip_last_timing", "zultra_hip_get_matches", "zultra_hip_get_splits", "zultra_hip_get_parse",
     "zultra_hip_stitch", "zultra_hip_stitch_finish",
     "zultra_hip_stitch_device", "zultra_hip_stream_device", "zultra_hip_stream_read", "zultra_hip_block_crc32", "zultra_crc32_append", "zultra_crc32_append_many",
+    "zultra_hip_create_files", "zultra_hip_compress_files", "zultra_hip_stitch_files",
 ]
 
 
@@ -185,6 +186,9 @@ class Lib:
     def context(self, max_block, max_blocks, device=0):
         return HipContext(self, device, max_block, max_blocks)
 
+    def files_context(self, max_file_size, max_files, device=0):
+        return HipContext(self, device, max_file_size, max_files, files=True)
+
 
 class Stream:
     """zultra_stream_t driven the way tool/zultra.c:151-186 drives it."""
@@ -244,9 +248,11 @@ class Stream:
 class HipContext:
     """zultra_hip_ctx_t: batches of independent max-blocks (include/zultra_hip.h)."""
 
-    def __init__(self, lib, device, max_block, max_blocks):
+    def __init__(self, lib, device, max_block, max_blocks, files=False):
         self.lib = lib
-        self.h = lib.L.zultra_hip_create(device, max_block, max_blocks)
+        lib.L.zultra_hip_create_files.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+        lib.L.zultra_hip_create_files.restype = C.c_void_p
+        self.h = (lib.L.zultra_hip_create_files if files else lib.L.zultra_hip_create)(device, max_block, max_blocks)
         if not self.h:
             raise ZultraError("zultra_hip_create failed: no usable HIP device (there is no CPU fallback)")
         self.max_block = max_block
@@ -282,6 +288,24 @@ class HipContext:
         if n <= 0:
             raise ZultraError("zultra_hip_compress_blocks: " + self.lib.L.zultra_hip_last_error(self.h).decode())
         return n
+
+    def compress_files(self, data, offsets, sizes, data_on_device=False, data_size=None):
+        """Each (offset, size) is an independent input; -> uint64 array file_off[n+1] into the device stream buffer."""
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        szs = np.ascontiguousarray(sizes, dtype=np.uint32)
+        self._blocks = [(int(o), 0, int(n)) for o, n in zip(offs, szs)]
+        out = np.zeros(len(offs) + 1, dtype=np.uint64)
+        if data_on_device:
+            ptr, size = int(data), int(data_size)
+        else:
+            self._data = _as_u8(data)
+            ptr, size = self._data.ctypes.data, len(self._data)
+        f = self.lib.L.zultra_hip_compress_files
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        n = f(self.h, ptr, size, 1 if data_on_device else 0, offs.ctypes.data, szs.ctypes.data, len(offs), out.ctypes.data)
+        if n <= 0:
+            raise ZultraError("zultra_hip_compress_files: " + self.lib.L.zultra_hip_last_error(self.h).decode())
+        return out
 
     def subblocks(self):
         cnt = C.c_uint32()

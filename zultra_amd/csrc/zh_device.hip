@@ -60,6 +60,16 @@ struct zultra_hip_ctx_s {
    uint32_t *d_ntasks, *d_hist_part, *d_task_bits;
    hipEvent_t ev2[16];
    // sub-batch pipelining: a batch runs as up to ZH_MAX_LANES contiguous runs of max-blocks, each on its own stream
+   // "files" mode (zultra_hip_create_files): every max-block is a whole small input (< 8192 bytes, so the splitter can
+   // never cut it, blockdeflate.c:646): no history, one sub-block and one task per block, no host decision anywhere in
+   // the sequence -> stages 1-3 are captured once in a hipGraph and replayed per batch.
+   int files_mode;
+   uint32_t max_subs;           // sub-blocks a max-block can have: 64, or 1 in files mode
+   hipGraph_t graph;
+   hipGraphExec_t graph_exec;
+   uint32_t graph_nblocks;
+   const uint8_t *graph_data;
+   std::vector<uint64_t> file_off;
    int nlanes;
    hipStream_t lane_stream[4];
    hipEvent_t lane_ev[4][24];
@@ -243,6 +253,8 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
       if (c->lane_stream[k]) (void)hipStreamDestroy(c->lane_stream[k]);
    }
    if (c->ev_input) (void)hipEventDestroy(c->ev_input);
+   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+   if (c->graph) (void)hipGraphDestroy(c->graph);
    if (c->h_split_cnt) (void)hipHostFree(c->h_split_cnt);
    if (c->h_sub_base) (void)hipHostFree(c->h_sub_base);
    if (c->h_crc) (void)hipHostFree(c->h_crc);
@@ -275,24 +287,24 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
          for (int i = 0; i < 24; i++) ZH_CHECK(c, hipEventCreate(&c->lane_ev[k][i]));
       }
       ZH_CHECK(c, hipEventCreate(&c->ev_input));
-      if (zh_alloc(c, &c->d_results_compact, B * ZH_MAX_SPLITS)) return -1;
+      if (zh_alloc(c, &c->d_results_compact, B * c->max_subs)) return -1;
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_split_cnt, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_sub_base, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_crc, B * sizeof(uint32_t), 0));
-      ZH_CHECK(c, hipHostMalloc((void **)&c->h_results, B * ZH_MAX_SPLITS * sizeof(zh_subblock_t), 0));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_results, B * c->max_subs * sizeof(zh_subblock_t), 0));
    }
    c->bar_stride = c->tok_stride / 64;
-   c->max_tasks = B * (N / ZH_TASK + ZH_MAX_SPLITS);
-   if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * ZH_MAX_SPLITS) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
+   c->max_tasks = B * (N / ZH_TASK + c->max_subs);
+   if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->sort_stride) || zh_alloc(c, &c->d_ntasks, 4) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
        zh_alloc(c, &c->d_tok_pos, B * c->tok_stride) || zh_alloc(c, &c->d_tok_info, B * c->tok_stride) ||
        zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_split_tok, B * (ZH_MAX_SPLITS + 1)) || zh_alloc(c, &c->d_split_cnt, B) ||
-       zh_alloc(c, &c->d_sub_base, B) || zh_alloc(c, &c->d_best, B * c->best_stride) || zh_alloc(c, &c->d_work, B * ZH_MAX_SPLITS) ||
-       zh_alloc(c, &c->d_results, B * ZH_MAX_SPLITS) || zh_alloc(c, &c->d_payload, B * c->slot_stride) ||
-       zh_alloc(c, &c->d_items, B * ZH_MAX_SPLITS) || zh_alloc(c, &c->d_crc, B) || zh_alloc(c, &c->d_crc_tables, 256 + 1024))
+       zh_alloc(c, &c->d_sub_base, B) || zh_alloc(c, &c->d_best, B * c->best_stride) || zh_alloc(c, &c->d_work, B * c->max_subs) ||
+       zh_alloc(c, &c->d_results, B * c->max_subs) || zh_alloc(c, &c->d_payload, B * c->slot_stride) ||
+       zh_alloc(c, &c->d_items, B * c->max_subs) || zh_alloc(c, &c->d_crc, B) || zh_alloc(c, &c->d_crc_tables, 256 + 1024))
       return -1;
    c->stream_cap = (size_t)(B * (N + 5 * (N / 65535 + 1) + 8) + 64) & ~(size_t)3;
    ZH_CHECK(c, hipMalloc((void **)&c->d_stream, c->stream_cap + 16));
@@ -317,20 +329,22 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    return 0;
 }
 
-extern "C" zultra_hip_ctx_t *zultra_hip_create(int device, uint32_t max_block_size, uint32_t max_blocks) {
+static zultra_hip_ctx_t *zh_create(int device, uint32_t max_block, uint32_t max_blocks, int files_mode) {
    int ndev = zultra_hip_device_count();
    if (ndev <= 0 || device < 0 || device >= ndev || max_blocks == 0) return NULL;
    zultra_hip_ctx_t *c = new zultra_hip_ctx_s();
    memset((void *)&c->timing, 0, sizeof(c->timing));
    c->device = device;
-   c->max_block = zh_clamp_block(max_block_size);
+   c->files_mode = files_mode;
+   c->max_block = max_block;
    c->max_blocks = max_blocks;
-   c->W = (uint64_t)c->max_block + ZH_HISTORY;
+   c->max_subs = files_mode ? 1u : (uint32_t)ZH_MAX_SPLITS;
+   c->W = (uint64_t)c->max_block + (files_mode ? 0u : (uint32_t)ZH_HISTORY);
    c->sort_stride = (c->W + 63) & ~63ull;
    c->match_stride = (uint64_t)c->max_block * ZH_NMATCH;
    c->tok_stride = ((uint64_t)c->max_block + 63) & ~63ull;
    c->best_stride = c->tok_stride;
-   c->slot_stride = (((uint64_t)c->max_block + 64 * ZH_MAX_SPLITS + 64) + 63) & ~63ull;
+   c->slot_stride = (((uint64_t)c->max_block + 64 * c->max_subs + 64) + 63) & ~63ull;
    c->data_cap = (size_t)c->W + (size_t)(max_blocks - 1) * c->max_block;
    c->err[0] = 0;
    if (zh_create_buffers(c) != 0) {
@@ -341,8 +355,108 @@ extern "C" zultra_hip_ctx_t *zultra_hip_create(int device, uint32_t max_block_si
    return c;
 }
 
+extern "C" zultra_hip_ctx_t *zultra_hip_create(int device, uint32_t max_block_size, uint32_t max_blocks) {
+   return zh_create(device, zh_clamp_block(max_block_size), max_blocks, 0);
+}
+
+extern "C" zultra_hip_ctx_t *zultra_hip_create_files(int device, uint32_t max_file_size, uint32_t max_files) {
+   if (max_file_size == 0 || max_file_size >= 8192) return NULL;   // larger inputs can be split: use the block interface
+   return zh_create(device, (max_file_size + 63u) & ~63u, max_files, 1);
+}
+
 extern "C" const char *zultra_hip_last_error(const zultra_hip_ctx_t *c) { return c ? c->err : "no context"; }
 extern "C" size_t zultra_hip_data_capacity(const zultra_hip_ctx_t *c) { return c ? c->data_cap : 0; }
+
+// files mode: what zh_split would report for an input below its 8192-byte threshold — one sub-block spanning all tokens
+__global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, uint32_t *split_tok, uint32_t *split_cnt, uint32_t *sub_base) {
+   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+   if (b >= nblocks) return;
+   split_tok[(uint64_t)b * (ZH_MAX_SPLITS + 1)] = 0;
+   split_tok[(uint64_t)b * (ZH_MAX_SPLITS + 1) + 1] = ntok[b];
+   split_cnt[b] = 1;
+   sub_base[b] = b;
+}
+
+// The kernel sequence of a files-mode batch on one stream, with no host decision in it. Captured into a hipGraph the
+// first time a (batch size, input pointer) pair is seen and replayed afterwards: one graph launch per batch.
+static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
+   const zh_block_t *blk = c->d_blocks;
+   if (c->W <= ZH_MF_LDS_WINDOW) {
+      ZH_LAUNCH(zh_mf_group<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a, c->d_sort_b, c->d_prev3, c->sort_stride, 0);
+      ZH_LAUNCH(zh_mf_frontier<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3, c->sort_stride,
+                c->d_match, c->match_stride);
+   }
+   else {
+      ZH_LAUNCH(zh_mf_group<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a, c->d_sort_b, c->d_prev3, c->sort_stride, 0);
+      ZH_LAUNCH(zh_mf_frontier<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3, c->sort_stride,
+                c->d_match, c->match_stride);
+   }
+   ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok,
+             c->d_bars, c->bar_stride);
+   ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 4 * sizeof(uint32_t), st));
+   ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, (size_t)nb * c->slot_stride, st));
+   ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)c->d_tok_pos, c->tok_stride, (const uint32_t *)c->d_ntok,
+             (const uint32_t *)c->d_split_tok, (const uint32_t *)c->d_split_cnt, (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work, c->d_taskmap,
+             c->d_ntasks);
+   ZH_LAUNCH(zh_sb_init, nb, 64, st, (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_states);
+   const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
+   for (int pass = 0; pass <= 3; pass++) {
+      ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride,
+                (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
+                c->best_stride, c->d_hist_part, pass);
+      ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)c->d_work, c->d_states, (const uint32_t *)c->d_hist_part, c->d_payload, pass);
+   }
+   ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work,
+             (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride, c->d_task_bits);
+   ZH_LAUNCH(zh_emit_tasks, task_grid, 64, st, c->cur_data, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work,
+             (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, (const uint32_t *)c->d_best, c->best_stride,
+             (const uint32_t *)c->d_task_bits, c->d_payload, c->d_results);
+   ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc);
+   ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results, nb * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
+   ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+   return 0;
+}
+
+static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
+   hipStream_t st = c->lane_stream[0];
+#ifndef ZH_EMU
+   if (!c->graph_exec || c->graph_nblocks != nblocks || c->graph_data != c->cur_data) {
+      if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+      if (c->graph) (void)hipGraphDestroy(c->graph);
+      c->graph_exec = NULL;
+      c->graph = NULL;
+      ZH_CHECK(c, hipStreamSynchronize(st));   // the input upload is not part of the graph
+      ZH_CHECK(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      const int rc = zh_enqueue_files(c, nblocks, st);
+      const hipError_t e = hipStreamEndCapture(st, &c->graph);
+      if (rc != 0) return -1;
+      ZH_CHECK(c, e);
+      ZH_CHECK(c, hipGraphInstantiate(&c->graph_exec, c->graph, NULL, NULL, 0));
+      c->graph_nblocks = nblocks;
+      c->graph_data = c->cur_data;
+   }
+   ZH_CHECK(c, hipEventRecord(c->lane_ev[0][1], st));
+   ZH_CHECK(c, hipGraphLaunch(c->graph_exec, st));
+#else
+   ZH_CHECK(c, hipEventRecord(c->lane_ev[0][1], st));
+   if (zh_enqueue_files(c, nblocks, st) != 0) return -1;
+#endif
+   ZH_CHECK(c, hipEventRecord(c->lane_ev[0][16], st));
+   ZH_CHECK(c, hipStreamSynchronize(st));
+   ZH_CHECK(c, hipGetLastError());
+   for (uint32_t b = 0; b < nblocks; b++) {
+      c->split_cnt[b] = 1;
+      c->sub_base[b] = b;
+   }
+   c->results.assign(c->h_results, c->h_results + nblocks);
+   memcpy(c->crc.data(), c->h_crc, nblocks * sizeof(uint32_t));
+   c->nsubs = nblocks;
+   (void)hipEventElapsedTime(&c->timing.h2d_ms, c->lane_ev[0][0], c->ev_input);
+   (void)hipEventElapsedTime(&c->timing.encode_ms, c->lane_ev[0][1], c->lane_ev[0][16]);   // the whole graph
+   (void)hipEventElapsedTime(&c->timing.total_ms, c->lane_ev[0][0], c->lane_ev[0][16]);
+   return (int)nblocks;
+}
 
 extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data, size_t data_size, int data_on_device,
                                           const zultra_hip_block_t *blocks, uint32_t nblocks) {
@@ -351,7 +465,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       return -1;
    }
    for (uint32_t b = 0; b < nblocks; b++) {
-      if (blocks[b].n == 0 || blocks[b].n > c->max_block || blocks[b].prev > ZH_HISTORY ||
+      if (blocks[b].n == 0 || blocks[b].n > c->max_block || blocks[b].prev > ZH_HISTORY || (uint64_t)blocks[b].prev + blocks[b].n > c->W ||
           blocks[b].win_off + blocks[b].prev + blocks[b].n > data_size) {
          snprintf(c->err, sizeof(c->err), "block %u out of range", b);
          return -1;
@@ -390,6 +504,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    }
    ZH_CHECK(c, hipMemcpyAsync(c->d_blocks, blocks, nblocks * sizeof(zh_block_t), hipMemcpyHostToDevice, st0));
    ZH_CHECK(c, hipEventRecord(c->ev_input, st0));
+   if (c->files_mode) return zh_run_files(c, nblocks);
 
    // ---- stages 1 and 2 of every run: match rows, token chain + barrier bitmap, splitter ----------------------------
    for (int k = 0; k < lanes; k++) {
@@ -459,7 +574,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       lane_nsubs[k] = ns;
       nsubs += ns;
       // per-sub-block and per-task buffers of the run start at its worst-case offset
-      const uint64_t s0 = (uint64_t)b0 * ZH_MAX_SPLITS, t0 = (uint64_t)b0 * tasks_per_block;
+      const uint64_t s0 = (uint64_t)b0 * c->max_subs, t0 = (uint64_t)b0 * tasks_per_block;
       zh_work_t *work = c->d_work + s0;
       zh_sbstate_t *states = c->d_states + s0;
       uint2 *taskmap = c->d_taskmap + t0;
@@ -596,6 +711,62 @@ extern "C" int zultra_hip_stitch_device(zultra_hip_ctx_t *c, zultra_hip_bitstate
    state->nacc = (uint32_t)(eb & 7);
    *end_bit = eb;
    return 0;
+}
+
+// Files mode assembly: every max-block of the last batch becomes its own raw deflate stream (BFINAL on its last
+// sub-block, padded to a byte, libzultra.c:414-417), laid end to end in the stream buffer; file_off[b]..file_off[b+1]
+// are its bytes. Works for any context, it is what compressing each max-block with its own zultra_memory_compress gives.
+extern "C" int zultra_hip_stitch_files(zultra_hip_ctx_t *c, uint64_t *file_off /* nblocks + 1 */) {
+   if (!c || !file_off || c->nsubs == 0) return -1;
+   c->items.resize(c->nsubs);
+   uint64_t bit = 0;
+   uint32_t k = 0;
+   for (uint32_t b = 0; b < c->nblocks; b++) {
+      uint32_t k1 = k;
+      while (k1 < c->nsubs && c->results[k1].block == b) k1++;
+      uint64_t eb = 0;
+      file_off[b] = bit >> 3;
+      if (zh_stitch_plan(0, c->results.data() + k, k1 - k, c->max_block < ZH_MIN_BLOCK ? (uint32_t)ZH_MIN_BLOCK : c->max_block, (int)b, c->items.data() + k, &eb) != 0) {
+         snprintf(c->err, sizeof(c->err), "stream assembly overflows the per-block buffer bound (ZULTRA_ERROR_DST)");
+         return -2;
+      }
+      for (uint32_t j = k; j < k1; j++) c->items[j].dst_bit += bit;
+      bit = (bit + eb + 7) & ~7ull;
+      k = k1;
+   }
+   file_off[c->nblocks] = bit >> 3;
+   const size_t nbytes = (size_t)(bit >> 3);
+   if (nbytes + 8 > c->stream_cap) {
+      snprintf(c->err, sizeof(c->err), "stream buffer too small");
+      return -1;
+   }
+   ZH_CHECK(c, hipSetDevice(c->device));
+   hipStream_t st = c->stream;
+   ZH_CHECK(c, hipEventRecord(c->ev[0], st));
+   ZH_CHECK(c, hipMemsetAsync(c->d_stream, 0, (nbytes + 8 + 3) & ~(size_t)3, st));
+   ZH_CHECK(c, hipMemcpyAsync(c->d_items, c->items.data(), c->nsubs * sizeof(zh_stitch_item_t), hipMemcpyHostToDevice, st));
+   ZH_CHECK(c, hipMemcpyAsync(c->d_results_compact, c->results.data(), c->nsubs * sizeof(zh_subblock_t), hipMemcpyHostToDevice, st));
+   ZH_LAUNCH(zh_stitch, c->nsubs, ZH_STITCH_THREADS, st, (const zh_subblock_t *)c->d_results_compact, (const zh_stitch_item_t *)c->d_items,
+             (const zh_block_t *)c->d_blocks, c->cur_data, (const uint8_t *)c->d_payload, c->d_stream);
+   ZH_CHECK(c, hipEventRecord(c->ev[1], st));
+   ZH_CHECK(c, hipStreamSynchronize(st));
+   ZH_CHECK(c, hipGetLastError());
+   (void)hipEventElapsedTime(&c->timing.stitch_ms, c->ev[0], c->ev[1]);
+   return 0;
+}
+
+extern "C" int zultra_hip_compress_files(zultra_hip_ctx_t *c, const void *data, size_t data_size, int data_on_device, const uint64_t *offsets,
+                                         const uint32_t *sizes, uint32_t nfiles, uint64_t *file_off) {
+   if (!c || !offsets || !sizes || !file_off || nfiles == 0) return -1;
+   std::vector<zultra_hip_block_t> blk(nfiles);
+   for (uint32_t i = 0; i < nfiles; i++) {
+      blk[i].win_off = offsets[i];
+      blk[i].prev = 0;
+      blk[i].n = sizes[i];
+   }
+   const int rc = zultra_hip_compress_blocks(c, data, data_size, data_on_device, blk.data(), nfiles);
+   if (rc <= 0) return rc;
+   return zultra_hip_stitch_files(c, file_off) == 0 ? rc : -1;
 }
 
 extern "C" const void *zultra_hip_stream_device(const zultra_hip_ctx_t *c) { return c ? c->d_stream : NULL; }
