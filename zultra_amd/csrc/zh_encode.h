@@ -88,6 +88,7 @@ struct zh_sb_ws_t {
    zh_huff_scratch_t sc;
    zh_cl_t cl;
    zh_cl_t cl_work[20];
+   uint16_t runs[ZH_NLIT + ZH_NDIST];   // run list of the header's code lengths, shared by the 20 mask candidates
    int32_t tmp;
 };
 
@@ -266,18 +267,23 @@ zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint
    if ((int)lane < ndist) ws.lens[nlit + (int)lane] = ws.dist_len[lane];
    zh_sync();
 
+   if (lane == 0) ws.tmp = zh_cl_make_runs(ws.lens, nlit + ndist, ws.runs);
+   zh_sync();
+   const int nruns = ws.tmp;
+   zh_sync();
    uint32_t mkey = 0xFFFFFFFFu;
    if (lane < 20) {
+      // 20 lanes, one mask each, all walking the same run list: the loop trip counts agree, only the token choice differs
       const unsigned mask = lane < 8 ? lane : 9 + 2 * (lane - 8);   // 0..7, 9, 11, ..., 31 (:959)
       zh_cl_t *h = &ws.cl_work[lane];
       zh_cl_reset(h);
       zh_cl_count_sink cs{h};
-      zh_cl_tokenize(ws.lens, nlit + ndist, mask, cs);
+      zh_cl_tokenize_runs(ws.runs, nruns, mask, cs);
       if (zh_cl_build_lane(h, 7) < 0)
          mkey = 0xFFFFFFFEu;
       else {
          zh_cl_size_sink ss{h, 0};
-         zh_cl_tokenize(ws.lens, nlit + ndist, mask, ss);
+         zh_cl_tokenize_runs(ws.runs, nruns, mask, ss);
          mkey = ((uint32_t)ss.bits << 6) | (63u - lane);   // cheapest; among equals the last tried (:966)
       }
    }
@@ -300,7 +306,7 @@ zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint
          w.put((uint32_t)(ncl - 4), 4);
          for (int k = 0; k < ncl; k++) w.put(h->len[zh_cl_order(k)], 3);
          zh_cl_write_sink sink{h, &w};
-         zh_cl_tokenize(ws.lens, nlit + ndist, best_mask, sink);
+         zh_cl_tokenize_runs(ws.runs, nruns, best_mask, sink);
          // the partial dword: the slot is zero-filled and the first task ORs its bits in later
          if (w.nacc && w.nbits - w.nacc + 32 <= w.cap_bits) out[(w.nbits - w.nacc) >> 5] = (uint32_t)w.acc;
          ws.tmp = (int32_t)w.nbits;

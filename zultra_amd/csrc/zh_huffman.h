@@ -325,6 +325,75 @@ __device__ inline void zh_cl_tokenize(const uint8_t *lens, int n, unsigned mask,
    }
 }
 
+// The same tokenizer over a precomputed run list (entry = value | run length << 4, runs of equal code lengths <= 15): the
+// symbol-by-symbol version above rescans the rest of a run after every token it emits; on the run list every step emits
+// a token. Each iteration of the outer loops below is one iteration of the loop above applied to what is left of the run.
+template <typename Sink>
+__device__ inline void zh_cl_tokenize_runs(const uint16_t *runs, int nruns, unsigned mask, Sink &sink) {
+   for (int q = 0; q < nruns; q++) {
+      const int v = runs[q] & 15;
+      int run = runs[q] >> 4;
+      if (v == 0) {
+         while (run > 0) {
+            if (run >= 3) {
+               while (run >= 11 && (mask & 4)) {
+                  int take = run > 138 ? 138 : run;
+                  sink.put(18, take - 11, 7);
+                  run -= take;
+               }
+               while (run >= 3 && (mask & 2)) {
+                  int take = run > 10 ? 10 : run;
+                  sink.put(17, take - 3, 3);
+                  run -= take;
+               }
+               if (run) {
+                  sink.put(0, 0, 0);
+                  run--;
+               }
+            }
+            else {
+               sink.put(0, 0, 0);
+               run--;
+            }
+         }
+      }
+      else {
+         while (run > 0) {
+            sink.put(v > 15 ? 15 : v, 0, 0);
+            run--;
+            if (run == 7 && (mask & 1) && !(mask & 8)) {
+               sink.put(16, 1, 2);
+               sink.put(16, 0, 2);
+               run = 0;
+            }
+            else if (run == 8 && (mask & 1) && !(mask & 16)) {
+               sink.put(16, 1, 2);
+               sink.put(16, 1, 2);
+               run = 0;
+            }
+            while (run >= 3 && (mask & 1)) {
+               int take = run > 6 ? 6 : run;
+               sink.put(16, take - 3, 2);
+               run -= take;
+            }
+         }
+      }
+   }
+}
+
+// run list of n code lengths (single lane); returns the number of runs (<= n)
+__device__ inline int zh_cl_make_runs(const uint8_t *lens, int n, uint16_t *runs) {
+   int nruns = 0, i = 0;
+   while (i < n) {
+      const int v = lens[i];
+      int run = 1;
+      while (i + run < n && lens[i + run] == v) run++;
+      runs[nruns++] = (uint16_t)(v | (run << 4));   // v <= 15, run <= 320
+      i += run;
+   }
+   return nruns;
+}
+
 struct zh_cl_count_sink {
    zh_cl_t *h;
    __device__ __forceinline__ void put(int sym, int, int) { h->freq[sym]++; }
@@ -345,13 +414,14 @@ __device__ inline void zh_cl_reset(zh_cl_t *h) {
 
 // blockdeflate.c:594-613: header cost of a (lit, dist) pair — code-length alphabet histogrammed with mask 7,
 // sized with mask 31, its own lengths from the *unlimited* estimate. Single lane; lens = concatenated lengths.
-__device__ inline int zh_table_cost_lane(const uint8_t *lens, int n, zh_cl_t *h) {
+__device__ inline int zh_table_cost_lane(const uint8_t *lens, int n, zh_cl_t *h, uint16_t *runs /* LDS scratch, n entries */) {
+   const int nruns = zh_cl_make_runs(lens, n, runs);
    zh_cl_reset(h);
    zh_cl_count_sink cs{h};
-   zh_cl_tokenize(lens, n, 7, cs);
+   zh_cl_tokenize_runs(runs, nruns, 7, cs);
    zh_cl_lengths_lane(h);
    zh_cl_size_sink ss{h, 0};
-   zh_cl_tokenize(lens, n, 31, ss);
+   zh_cl_tokenize_runs(runs, nruns, 31, ss);
    return 5 + 5 + 4 + 3 * zh_cl_raw_table_size(h) + ss.bits;
 }
 

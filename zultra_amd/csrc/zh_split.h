@@ -133,7 +133,7 @@ __device__ inline int zh_dynamic_cost_wave(const int32_t *lit, const int32_t *di
    for (int s = lane; s < nlit; s += 64) lens[s] = lit_len[s];
    if (lane < ndist) lens[nlit + lane] = dist_len[lane];
    zh_sync();
-   if (lane == 0) *tmp = zh_table_cost_lane(lens, nlit + ndist, cl);
+   if (lane == 0) *tmp = zh_table_cost_lane(lens, nlit + ndist, cl, (uint16_t *)sc->keys);   // the sort scratch is free here
    zh_sync();
    int r = (int)body + *tmp + 3;
    zh_sync();

@@ -114,19 +114,19 @@ def assemble(lib, ctx, max_block, dist, torch, device, is_stream_end_rank, nbloc
     parts = [torch.empty(maxl, dtype=torch.uint8, device=device) for _ in range(world)]
     dist.gather(sendb, parts, dst=0)
 
-    # rank 0: concatenate; a shard that starts mid-byte shares that byte with its predecessor
+    # rank 0: join on the device (a shard that starts mid-byte shares that byte with its predecessor), then one pinned D2H
     total = sum(lens)
-    stream = np.zeros(total, dtype=np.uint8)
+    stream = torch.zeros(total + 1, dtype=torch.uint8, device=device)
     pos = 0
     phase = 0
     for r in range(world):
-        b = parts[r][:lens[r]].cpu().numpy()
+        b = parts[r][:lens[r]]
         if phase:   # first byte overlaps the previous shard's last (partial) byte
             stream[pos - 1] |= b[0]
-            stream[pos:pos + len(b) - 1] = b[1:]
-            pos += len(b) - 1
+            stream[pos:pos + lens[r] - 1] = b[1:]
+            pos += lens[r] - 1
         else:
-            stream[pos:pos + len(b)] = b
-            pos += len(b)
+            stream[pos:pos + lens[r]] = b
+            pos += lens[r]
         _, phase = _plan_bits(lib, np.ascontiguousarray(allsubs[r][:counts[r]]), counts[r], max_block, phase)
-    return stream[:pos], {"shard_bytes": nbytes, "start_phase": 0}
+    return _to_host(torch, stream[:pos]), {"shard_bytes": nbytes, "start_phase": 0}
