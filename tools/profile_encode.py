@@ -19,6 +19,19 @@ if kind == "text":
 elif kind == "mixed":
     import numpy as np
     d = np.concatenate([corpus.mixed(1 << 22, 5 + k) for k in range((size + (1 << 22) - 1) >> 22)])[:size]
+elif kind == "pysrc":   # real text: the Python sources of this image (same files on the GPU box), concatenated
+    import glob
+    import numpy as np
+    buf = bytearray()
+    for f in sorted(glob.glob("/usr/lib/python3*/**/*.py", recursive=True)) + sorted(glob.glob("/usr/local/lib/python3*/**/*.py", recursive=True)):
+        try:
+            buf += open(f, "rb").read()
+        except OSError:
+            pass
+        if len(buf) >= size:
+            break
+    d = np.frombuffer(bytes(buf[:size]), dtype=np.uint8).copy()
+    size = len(d)
 else:
     import numpy as np
     d = np.concatenate([corpus.json_like(1 << 20, 5 + k) for k in range((size + (1 << 20) - 1) >> 20)])[:size]

@@ -41,6 +41,9 @@
 #define ZH_PIECE 128        // target positions per piece
 #endif
 #define ZH_MAXPIECES 64
+#ifndef ZH_COOP_MIN
+#define ZH_COOP_MIN 1536     // pieces longer than this are parsed by three rows together, three positions per step
+#endif
 #define ZH_NSYM (ZH_NLIT + ZH_NDIST)
 // Costs are kept modulo 2^16: within the 258 positions a step can look ahead, two costs differ by less than 258 x 15 bits
 // (either can be reached from the other by literals), so candidate costs relative to cost[p+1], biased by 2^14, stay
@@ -144,6 +147,85 @@ struct zh_tile_regs_t {
    uint32_t byte;
 };
 
+// Digest of one position's 8 match slots into its tile entries and its 16-byte record (branch-free).
+__device__ __forceinline__ void zh_stage_position(zh_parse_ws_t &ws, uint32_t row, uint32_t slot, const zh_tile_regs_t &regs, uint32_t room) {
+   const uint32_t raw[ZH_NMATCH] = {regs.a.x, regs.a.y, regs.a.z, regs.a.w, regs.b.x, regs.b.y, regs.b.z, regs.b.w};
+   uint32_t nlong = 0, nshort = 0, kmax = 0, run = 0xFFu;
+   uint64_t pm = 0, lmask = 0;
+#pragma unroll
+   for (uint32_t m = 0; m < ZH_NMATCH; m++) {
+      const uint32_t len = raw[m] & 0xffffu, off = raw[m] >> 16;
+      const bool valid = len >= ZH_MIN_MATCH;
+      const bool is_long = len >= ZH_LEAVE_ALONE;
+      const bool is_short = valid && !is_long;
+      const uint32_t oc = (uint32_t)ws.distcost[zh_dist_sym(valid ? off : 1u)];
+      ws.tile[row][slot][m] = valid ? (len | (oc << 9) | (off << 16)) : 0u;
+      nlong += is_long ? 1u : 0u;
+      kmax = max(kmax, is_short ? len : 0u);               // the first short slot is the longest
+      lmask |= is_short ? (1ull << (len - ZH_MIN_MATCH)) : 0ull;
+      run = is_short ? min(run, (oc << 3) | m) : run;
+      pm |= is_short ? ((uint64_t)run << (8 * nshort)) : 0ull;
+      nshort += is_short ? 1u : 0u;
+   }
+   const uint32_t mask_hi = (uint32_t)(lmask >> 32);
+   uint4 r;
+   r.x = (uint32_t)lmask;
+   r.y = (uint32_t)pm;
+   r.z = (uint32_t)(pm >> 32);
+   // room = end clamp (blockdeflate.c:283-284); a no-op away from the sub-block end
+   r.w = mask_hi | ((uint32_t)__popc(mask_hi) << 5) | (nlong << 8) | (min(kmax, room) << 12) | ((uint32_t)ws.litprice[regs.byte & 0xffu] << 18);
+   ws.rec[row][slot] = r;
+}
+
+// This lane's best match candidate for the position at p with record R (tile entries at tile[trow][tslot]), costs in
+// `ring`: lane s prices length 3+s, and in the rarely executed section (taken by the whole wave when any position needs
+// it) lengths 19+s, 35+s and long slot s. Key = (cost - base) << 9 | slot << 6 | (39 - k).
+__device__ __forceinline__ uint32_t zh_lane_key(zh_parse_ws_t &ws, const uint16_t *ring, uint32_t trow, uint32_t tslot, const uint4 &R, uint32_t p, uint32_t s,
+                                                uint32_t base, uint32_t lc0, uint32_t lc1, uint32_t lc2, uint32_t sb_end) {
+   const uint32_t kmax = ZH_REC_KMAX(R.w), nlong = ZH_REC_NLONG(R.w), nhi = ZH_REC_NHI(R.w);
+   uint32_t key = 0xFFFFFFFFu;
+   if (3 + s <= kmax) {
+      const uint32_t sel = (uint32_t)__popc(R.x >> s) + nhi - 1u;            // index of the last short slot reaching 3+s
+      const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
+      const uint32_t c = (lc0 + (b >> 3) + (uint32_t)ring[(p + 3 + s) & 511] - base) & 0xffffu;
+      key = (c << 9) | ((b & 7u) << 6) | (36u - s);                          // 39 - k
+   }
+   // rarely needed: lengths 19..39, and slots stored with length >= 40
+   if (zh_ballot(kmax > 18u || nlong != 0)) {
+      if (19 + s <= kmax) {
+         const uint32_t sel = (uint32_t)__popc(R.x >> (16 + s)) + nhi - 1u;
+         const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
+         const uint32_t c = (lc1 + (b >> 3) + (uint32_t)ring[(p + 19 + s) & 511] - base) & 0xffffu;
+         key = min(key, (c << 9) | ((b & 7u) << 6) | (20u - s));
+      }
+      if (s < 5 && 35 + s <= kmax) {
+         const uint32_t sel = (uint32_t)__popc((R.w & 31u) >> s) - 1u;
+         const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
+         const uint32_t c = (lc2 + (b >> 3) + (uint32_t)ring[(p + 35 + s) & 511] - base) & 0xffffu;
+         key = min(key, (c << 9) | ((b & 7u) << 6) | (4u - s));
+      }
+      if (s < nlong) {                                                        // long slot s: full (clamped) length only
+         const uint32_t e = ws.tile[trow][tslot][s];
+         const uint32_t mlen = min(e & 511u, sb_end - p);
+         uint32_t enc = mlen - ZH_MIN_MATCH;                                  // wraps below 3, then saturates (:289, :216-219)
+         if (enc > 255) enc = 255;
+         const uint32_t c = ((uint32_t)ws.lencost[enc] + ((e >> 9) & 31u) + (uint32_t)ring[(p + mlen) & 511] - base) & 0xffffu;
+         key = min(key, (c << 9) | (s << 6));
+      }
+   }
+   return key;
+}
+
+// decode the winning (slot, length) of a staged position into the parse entry
+__device__ __forceinline__ uint32_t zh_decode_pick(zh_parse_ws_t &ws, uint32_t trow, uint32_t tslot, uint32_t kk, uint32_t room) {
+   if (kk == 0xFFFFFFFFu) return 0;
+   const uint32_t m = (kk >> 6) & 7u;
+   const uint32_t e = ws.tile[trow][tslot][m];
+   const uint32_t nlong = ZH_REC_NLONG(ws.rec[trow][tslot].w);
+   const uint32_t len = (m < nlong) ? min(e & 511u, room) : (39u - (kk & 63u));
+   return len | (e & 0xffff0000u);
+}
+
 __global__ void __launch_bounds__(64)
 zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match,
                uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
@@ -211,12 +293,12 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          const bool need_ = zh_readlane((uint32_t)(p_hi <= p_lo), (int)(r_ * 16)) != 0;                        \
          if (need_) {                                                                                          \
             uint32_t lo_ = 0, hi_ = 0;                                                                         \
-            while (next_piece >= 0 && hi_ <= lo_) {                                                            \
+            while (next_piece >= 0 && (hi_ <= lo_ || hi_ > lo_ + ZH_COOP_MIN)) { /* huge pieces: see below */   \
                lo_ = ws.bnd[next_piece];                                                                       \
                hi_ = ws.bnd[next_piece + 1];                                                                   \
                next_piece--;                                                                                   \
             }                                                                                                  \
-            if (row == r_ && hi_ > lo_) {                                                                      \
+            if (row == r_ && hi_ > lo_ && hi_ <= lo_ + ZH_COOP_MIN) {                                                                      \
                p_lo = lo_;                                                                                     \
                p_hi = hi_;                                                                                     \
                n_top = true;                                                                                   \
@@ -245,36 +327,9 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       const bool c_top = n_top;
       if (!zh_ballot(c_cnt != 0)) break;
 
-      // ---- stage the tile: every lane digests the 8 slots of its own position (branch-free: lanes beyond the tile's
-      //      count digest zeros into their own, unused, record) ---------------------------------------------------------
-      {
-         const uint32_t raw[ZH_NMATCH] = {regs.a.x, regs.a.y, regs.a.z, regs.a.w, regs.b.x, regs.b.y, regs.b.z, regs.b.w};
-         uint32_t nlong = 0, nshort = 0, kmax = 0, run = 0xFFu;
-         uint64_t pm = 0, lmask = 0;
-#pragma unroll
-         for (uint32_t m = 0; m < ZH_NMATCH; m++) {
-            const uint32_t len = raw[m] & 0xffffu, off = raw[m] >> 16;
-            const bool valid = len >= ZH_MIN_MATCH;
-            const bool is_long = len >= ZH_LEAVE_ALONE;
-            const bool is_short = valid && !is_long;
-            const uint32_t oc = (uint32_t)ws.distcost[zh_dist_sym(valid ? off : 1u)];
-            ws.tile[row][s][m] = valid ? (len | (oc << 9) | (off << 16)) : 0u;
-            nlong += is_long ? 1u : 0u;
-            kmax = max(kmax, is_short ? len : 0u);               // the first short slot is the longest
-            lmask |= is_short ? (1ull << (len - ZH_MIN_MATCH)) : 0ull;
-            run = is_short ? min(run, (oc << 3) | m) : run;
-            pm |= is_short ? ((uint64_t)run << (8 * nshort)) : 0ull;
-            nshort += is_short ? 1u : 0u;
-         }
-         const uint32_t room = sb_end - (c_lo + s);   // end clamp (blockdeflate.c:283-284); a no-op away from the sub-block end
-         const uint32_t mask_hi = (uint32_t)(lmask >> 32);
-         uint4 r;
-         r.x = (uint32_t)lmask;
-         r.y = (uint32_t)pm;
-         r.z = (uint32_t)(pm >> 32);
-         r.w = mask_hi | ((uint32_t)__popc(mask_hi) << 5) | (nlong << 8) | (min(kmax, room) << 12) | ((uint32_t)ws.litprice[regs.byte & 0xffu] << 18);
-         ws.rec[row][s] = r;
-      }
+      // ---- stage the tile: every lane digests the 8 slots of its own position (lanes beyond the tile's count digest
+      //      zeros into their own, unused, record) ---------------------------------------------------------------------
+      zh_stage_position(ws, row, s, regs, sb_end - (c_lo + s));
       if (c_top && s == 0) ws.ring[row][(c_lo + c_cnt) & 511] = 0;   // cost[piece end] = 0
       if (c_top) cost_next = 0;
       zh_sync();
@@ -288,38 +343,8 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          const uint32_t p = c_lo + a;
          uint4 R = ws.rec[row][a];
          if (!act) R.w = 0;
-         const uint32_t kmax = ZH_REC_KMAX(R.w), nlong = ZH_REC_NLONG(R.w), nhi = ZH_REC_NHI(R.w);
          const uint32_t base = cost_next - ZH_KEY_BIAS;   // key cost = (candidate cost - base) mod 2^16, below 2^15
-         uint32_t key = 0xFFFFFFFFu;
-         if (3 + s <= kmax) {
-            const uint32_t sel = (uint32_t)__popc(R.x >> s) + nhi - 1u;            // index of the last short slot reaching 3+s
-            const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
-            const uint32_t c = (lc0 + (b >> 3) + (uint32_t)ws.ring[row][(p + 3 + s) & 511] - base) & 0xffffu;
-            key = (c << 9) | ((b & 7u) << 6) | (36u - s);                          // 39 - k
-         }
-         // rarely needed: lengths 19..39, and slots stored with length >= 40
-         if (zh_ballot(kmax > 18u || nlong != 0)) {
-            if (19 + s <= kmax) {
-               const uint32_t sel = (uint32_t)__popc(R.x >> (16 + s)) + nhi - 1u;
-               const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
-               const uint32_t c = (lc1 + (b >> 3) + (uint32_t)ws.ring[row][(p + 19 + s) & 511] - base) & 0xffffu;
-               key = min(key, (c << 9) | ((b & 7u) << 6) | (20u - s));
-            }
-            if (s < 5 && 35 + s <= kmax) {
-               const uint32_t sel = (uint32_t)__popc((R.w & 31u) >> s) - 1u;
-               const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
-               const uint32_t c = (lc2 + (b >> 3) + (uint32_t)ws.ring[row][(p + 35 + s) & 511] - base) & 0xffffu;
-               key = min(key, (c << 9) | ((b & 7u) << 6) | (4u - s));
-            }
-            if (s < nlong) {                                                        // long slot s: full (clamped) length only
-               const uint32_t e = ws.tile[row][a][s];
-               const uint32_t mlen = min(e & 511u, sb_end - p);
-               uint32_t enc = mlen - ZH_MIN_MATCH;                                  // wraps below 3, then saturates (:289, :216-219)
-               if (enc > 255) enc = 255;
-               const uint32_t c = ((uint32_t)ws.lencost[enc] + ((e >> 9) & 31u) + (uint32_t)ws.ring[row][(p + mlen) & 511] - base) & 0xffffu;
-               key = min(key, (c << 9) | (s << 6));
-            }
-         }
+         const uint32_t key = zh_lane_key(ws, ws.ring[row], row, a, R, p, s, base, lc0, lc1, lc2, sb_end);
          const uint32_t rkey = zh_row_min(key);   // every lane of a row now holds that row's best match candidate
          // literal first; a match must be strictly cheaper (:292,:307). An absent candidate (all ones) prices at 2^23-1,
          // above any literal (5 bits + bias).
@@ -336,21 +361,90 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       }
       zh_sync();
       // ---- flush: decode the winning (slot, length) of each position and store the parse --------------------------
-      if (s < c_cnt) {
-         const uint32_t kk = ws.bt[row][s];
-         uint32_t pick = 0;
-         if (kk != 0xFFFFFFFFu) {
-            const uint32_t m = (kk >> 6) & 7u;
-            const uint32_t e = ws.tile[row][s][m];
-            const uint32_t nlong = ZH_REC_NLONG(ws.rec[row][s].w);
-            const uint32_t len = (m < nlong) ? min(e & 511u, sb_end - (c_lo + s)) : (39u - (kk & 63u));
-            pick = len | (e & 0xffff0000u);
-         }
-         best[(c_lo + s) - prev] = pick;
-      }
+      if (s < c_cnt) best[(c_lo + s) - prev] = zh_decode_pick(ws, row, s, ws.bt[row][s], sb_end - (c_lo + s));
       zh_sync();
    }
 #undef ZH_NEXT_TILE
+
+   // ================================================================================================================
+   // Huge pieces (barrier-free runs: repeated boilerplate, logs, long matches everywhere). Four independent recurrences
+   // are of no use when a task is one run; instead rows 0..2 price positions p, p-1, p-2 of the SAME run in one step — the
+   // match candidates of all three only read cost[>= p+1] — and the three literal-vs-match decisions chain on the scalar
+   // unit. One shared cost ring; tiles of 48 positions.
+   // ================================================================================================================
+   for (int32_t pi = (int32_t)np - 1; pi >= 0; pi--) {
+      const uint32_t lo = ws.bnd[pi], hi = ws.bnd[pi + 1];
+      if (hi <= lo + ZH_COOP_MIN) continue;
+      uint16_t *ring = ws.ring[0];
+      if (lane == 0) ring[hi & 511] = 0;   // cost[piece end] = 0
+      uint32_t cnext = 0;
+      zh_tile_regs_t cr;
+#define ZH_COOP_FETCH(THI, TLO)                                                                          \
+      do {                                                                                               \
+         const uint32_t idx_ = 3 * s + row;                                                              \
+         const bool ok_ = row < 3 && idx_ < (THI) - (TLO);                                               \
+         const uint32_t pos_ = ok_ ? (THI) - 1 - idx_ : lo;   /* clamped: the loads are always legal */  \
+         const uint4 a_ = rows[(uint64_t)(pos_ - prev) * 2], b_ = rows[(uint64_t)(pos_ - prev) * 2 + 1]; \
+         const uint32_t y_ = win[pos_];                                                                  \
+         cr.a.x = ok_ ? a_.x : 0u; cr.a.y = ok_ ? a_.y : 0u; cr.a.z = ok_ ? a_.z : 0u; cr.a.w = ok_ ? a_.w : 0u;    \
+         cr.b.x = ok_ ? b_.x : 0u; cr.b.y = ok_ ? b_.y : 0u; cr.b.z = ok_ ? b_.z : 0u; cr.b.w = ok_ ? b_.w : 0u;    \
+         cr.byte = y_;                                                                                   \
+      } while (0)
+      {
+         const uint32_t tlo0 = hi > lo + 48 ? hi - 48 : lo;
+         ZH_COOP_FETCH(hi, tlo0);
+      }
+      for (uint32_t thi = hi; thi > lo;) {
+         const uint32_t tlo = thi > lo + 48 ? thi - 48 : lo;
+         const uint32_t cnt = thi - tlo;
+         // lane (row, s) stages the position that row `row` prices at step s
+         zh_stage_position(ws, row, s, cr, sb_end - (thi - 1 - min(3 * s + row, cnt - 1)));
+         zh_sync();
+         if (tlo > lo) {
+            const uint32_t nlo = tlo > lo + 48 ? tlo - 48 : lo;
+            ZH_COOP_FETCH(tlo, nlo);
+         }
+         const uint32_t steps = (cnt + 2) / 3;
+         for (uint32_t t = 0; t < steps; t++) {
+            const uint32_t idx = 3 * t + row;
+            const bool act = row < 3 && idx < cnt;
+            const uint32_t p = act ? thi - 1 - idx : thi - 1 - 3 * t;
+            uint4 R = ws.rec[row][t];
+            if (!act) R.w = 0;
+            const uint32_t base = cnext - ZH_KEY_BIAS;
+            const uint32_t key = zh_lane_key(ws, ring, row, t, R, p, s, base, lc0, lc1, lc2, sb_end);
+            const uint32_t rkey = zh_row_min(key);
+            const uint32_t litv = ZH_REC_LIT(R.w);
+            // literal first; a match must be strictly cheaper (:292,:307); the three decisions chain: cost[p-1] needs cost[p]
+            const uint32_t m0 = zh_readlane(rkey, 0) >> 9, m1 = zh_readlane(rkey, 16) >> 9, m2 = zh_readlane(rkey, 32) >> 9;
+            const uint32_t l0 = zh_readlane(litv, 0) + ZH_KEY_BIAS;
+            const uint32_t c0 = min(l0, m0);
+            const uint32_t l1 = zh_readlane(litv, 16) + c0;
+            const uint32_t c1 = min(l1, m1);
+            const uint32_t l2 = zh_readlane(litv, 32) + c1;
+            const uint32_t c2 = min(l2, m2);
+            const bool act1 = 3 * t + 1 < cnt, act2 = 3 * t + 2 < cnt;
+            if (act && s == 0) {
+               const uint32_t myc = row == 0 ? c0 : (row == 1 ? c1 : c2);
+               const bool take = row == 0 ? (m0 < l0) : (row == 1 ? (m1 < l1) : (m2 < l2));
+               ring[p & 511] = (uint16_t)((base + myc) & 0xffffu);
+               ws.bt[row][t] = take ? rkey : 0xFFFFFFFFu;
+            }
+            cnext = (base + (act2 ? c2 : (act1 ? c1 : c0))) & 0xffffu;
+         }
+         zh_sync();
+         {
+            const uint32_t idx = 3 * s + row;
+            if (row < 3 && idx < cnt) {
+               const uint32_t pos = thi - 1 - idx;
+               best[pos - prev] = zh_decode_pick(ws, row, s, ws.bt[row][s], sb_end - pos);
+            }
+         }
+         zh_sync();
+         thi = tlo;
+      }
+#undef ZH_COOP_FETCH
+   }
 
    // ---- histogram of the task's parse; the per-sub-block sum is taken by zh_sb_build -------------------------------
    if (st->is_dynamic) {
