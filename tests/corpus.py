@@ -132,6 +132,26 @@ def sparse_ones(size, seed=1, gap=200):
     return buf
 
 
+def indented(size, seed=1):
+    """Source-code-like lines: runs of spaces of many lengths (incl. > 258), zero padding, repeated line bodies — the byte-run
+    classes of the matchfinder (zh_matchfinder.h) in every combination: same / shorter / longer earlier runs, equal runs with
+    and without a continuing match."""
+    rs = np.random.RandomState(seed)
+    words = [b"def", b"return", b"self", b"x", b"if", b"else:", b"value", b"for i in range(n):", b"pass", b"0", b"=="]
+    out = bytearray()
+    while len(out) < size:
+        kind = rs.randint(0, 20)
+        if kind == 0:
+            out += bytes(int(rs.randint(4, 600)))            # zero padding, sometimes longer than the match limit
+        elif kind == 1:
+            out += b" " * int(rs.randint(250, 300)) + b"\n"
+        else:
+            ind = int(rs.choice([0, 1, 2, 3, 4, 4, 4, 5, 7, 8, 8, 8, 12, 12, 16, 20, 40]))
+            body = b" ".join(words[int(t)] for t in rs.randint(0, len(words), size=int(rs.randint(1, 5))))
+            out += b" " * ind + body + (b" " * int(rs.randint(0, 6)) if rs.randint(0, 4) == 0 else b"") + b"\n"
+    return np.frombuffer(bytes(out[:size]), dtype=np.uint8).copy()
+
+
 def mixed(size, seed=1):
     """Segments cycling through the self-test grid plus noise and constant runs (config 4 shape)."""
     rs = np.random.RandomState(seed)

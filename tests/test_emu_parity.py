@@ -41,6 +41,8 @@ def test_emu_is_not_the_product_library(emu):
     ("three", lambda: corpus.text_like(3, 1), 0, 3),
     ("one", lambda: corpus.text_like(1, 1), 0, 1),
     ("end_clamp", lambda: np.concatenate([corpus.noise(300, 2), corpus.constant(700, 65)]), 0, 1000),
+    ("byte_runs", lambda: corpus.indented(7000, 11), 2000, 5000),
+    ("byte_runs_first", lambda: corpus.indented(3000, 12), 0, 3000),
 ], ids=lambda c: c[0])
 def test_stages_vs_oracle(emu, oracle, case):
     name, gen, prev, n = case

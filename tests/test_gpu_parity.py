@@ -46,6 +46,8 @@ def test_wave_primitives_selfcheck(gpu):
     ("one", lambda: corpus.text_like(1, 1), 0, 1, 32768),
     ("json4k", lambda: corpus.json_like(4096, 3), 0, 4096, 32768),
     ("big_block", lambda: corpus.text_like(300000, 6), 32768, 267232, 1 << 20),
+    ("byte_runs", lambda: corpus.indented(98304, 11), 32768, 65536, 65536),
+    ("byte_runs_big", lambda: corpus.indented(300000, 13), 32768, 267232, 1 << 20),
 ], ids=lambda c: c[0])
 def test_stages_vs_oracle(gpu, oracle, case):
     name, gen, prev, n, bs = case

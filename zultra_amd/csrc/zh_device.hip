@@ -44,7 +44,8 @@ struct zultra_hip_ctx_s {
 
    uint8_t *d_data;
    zh_block_t *d_blocks;
-   uint32_t *d_sort_a, *d_sort_b, *d_prev3;
+   uint32_t *d_sort_a, *d_sort_b, *d_prev3, *d_runs;
+   uint64_t run_stride;
    zh_match_t *d_match;
    uint32_t *d_tok_pos;
    uint16_t *d_tok_info;
@@ -228,6 +229,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_sort_a);
    (void)hipFree(c->d_sort_b);
    (void)hipFree(c->d_prev3);
+   (void)hipFree(c->d_runs);
    (void)hipFree(c->d_match);
    (void)hipFree(c->d_tok_pos);
    (void)hipFree(c->d_tok_info);
@@ -296,7 +298,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->bar_stride = c->tok_stride / 64;
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
-       zh_alloc(c, &c->d_prev3, B * c->sort_stride) || zh_alloc(c, &c->d_ntasks, 4) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+       zh_alloc(c, &c->d_prev3, B * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->run_stride) || zh_alloc(c, &c->d_ntasks, 4) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
@@ -341,6 +343,7 @@ static zultra_hip_ctx_t *zh_create(int device, uint32_t max_block, uint32_t max_
    c->max_subs = files_mode ? 1u : (uint32_t)ZH_MAX_SPLITS;
    c->W = (uint64_t)c->max_block + (files_mode ? 0u : (uint32_t)ZH_HISTORY);
    c->sort_stride = (c->W + 63) & ~63ull;
+   c->run_stride = c->sort_stride + 576;   // start[Q] length[Q] first[256] end[256] count, Q = W/4 + 1
    c->match_stride = (uint64_t)c->max_block * ZH_NMATCH;
    c->tok_stride = ((uint64_t)c->max_block + 63) & ~63ull;
    c->best_stride = c->tok_stride;
@@ -382,14 +385,14 @@ __global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, 
 static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    const zh_block_t *blk = c->d_blocks;
    if (c->W <= ZH_MF_LDS_WINDOW) {
-      ZH_LAUNCH(zh_mf_group<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a, c->d_sort_b, c->d_prev3, c->sort_stride, 0);
-      ZH_LAUNCH(zh_mf_frontier<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3, c->sort_stride,
-                c->d_match, c->match_stride);
+      ZH_LAUNCH(zh_mf_group<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride, c->run_stride, 0);
+      ZH_LAUNCH(zh_mf_frontier<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3,
+                (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride);
    }
    else {
-      ZH_LAUNCH(zh_mf_group<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a, c->d_sort_b, c->d_prev3, c->sort_stride, 0);
-      ZH_LAUNCH(zh_mf_frontier<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3, c->sort_stride,
-                c->d_match, c->match_stride);
+      ZH_LAUNCH(zh_mf_group<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride, c->run_stride, 0);
+      ZH_LAUNCH(zh_mf_frontier<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3,
+                (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride);
    }
    ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok,
              c->d_bars, c->bar_stride);
@@ -522,18 +525,20 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_CHECK(c, hipEventRecord(ev[1], st));
       if (c->W <= ZH_MF_LDS_WINDOW)
          ZH_LAUNCH(zh_mf_group<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a + b0 * c->sort_stride, c->d_sort_b + b0 * c->sort_stride,
-                   c->d_prev3 + b0 * c->sort_stride, c->sort_stride, mf_stop);
+                   c->d_prev3 + b0 * c->sort_stride, c->d_runs + b0 * c->run_stride, c->sort_stride, c->run_stride, mf_stop);
       else
          ZH_LAUNCH(zh_mf_group<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a + b0 * c->sort_stride, c->d_sort_b + b0 * c->sort_stride,
-                   c->d_prev3 + b0 * c->sort_stride, c->sort_stride, mf_stop);
+                   c->d_prev3 + b0 * c->sort_stride, c->d_runs + b0 * c->run_stride, c->sort_stride, c->run_stride, mf_stop);
       ZH_CHECK(c, hipEventRecord(ev[2], st));
       if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
       if (c->W <= ZH_MF_LDS_WINDOW)
          ZH_LAUNCH(zh_mf_frontier<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)(c->d_sort_a + b0 * c->sort_stride),
-                   (const uint32_t *)(c->d_prev3 + b0 * c->sort_stride), c->sort_stride, c->d_match + b0 * c->match_stride, c->match_stride);
+                   (const uint32_t *)(c->d_prev3 + b0 * c->sort_stride), (const uint32_t *)(c->d_runs + b0 * c->run_stride), c->sort_stride, c->run_stride,
+                   c->d_match + b0 * c->match_stride, c->match_stride);
       else
          ZH_LAUNCH(zh_mf_frontier<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)(c->d_sort_a + b0 * c->sort_stride),
-                   (const uint32_t *)(c->d_prev3 + b0 * c->sort_stride), c->sort_stride, c->d_match + b0 * c->match_stride, c->match_stride);
+                   (const uint32_t *)(c->d_prev3 + b0 * c->sort_stride), (const uint32_t *)(c->d_runs + b0 * c->run_stride), c->sort_stride, c->run_stride,
+                   c->d_match + b0 * c->match_stride, c->match_stride);
       ZH_CHECK(c, hipEventRecord(ev[3], st));
       ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)(c->d_match + b0 * c->match_stride), c->match_stride,
                 c->d_tok_pos + b0 * c->tok_stride, c->d_tok_info + b0 * c->tok_stride, c->tok_stride, c->d_ntok + b0, c->d_bars + b0 * c->bar_stride,
