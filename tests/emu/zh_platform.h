@@ -149,6 +149,9 @@ inline uint64_t collect(uint64_t mine, F combine) {
 
 inline void __syncthreads() { zh_emu::park(2); }
 inline void zh_sync() { zh_emu::park(2); }
+inline void zh_wave_sync() {
+   zh_emu::collect(0, [] { return (uint64_t)0; });
+}
 
 inline unsigned zh_lane() { return (unsigned)zh_emu::g_cur & 63u; }
 inline uint64_t zh_ballot(bool p) {

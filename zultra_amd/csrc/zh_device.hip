@@ -543,7 +543,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)(c->d_match + b0 * c->match_stride), c->match_stride,
                 c->d_tok_pos + b0 * c->tok_stride, c->d_tok_info + b0 * c->tok_stride, c->tok_stride, c->d_ntok + b0, c->d_bars + b0 * c->bar_stride,
                 c->bar_stride);
-      ZH_LAUNCH(zh_split, nb, 64, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride),
+      ZH_LAUNCH(zh_split, nb, ZH_SPLIT_THREADS, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride),
                 c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0);
       ZH_CHECK(c, hipMemcpyAsync(c->h_split_cnt + b0, c->d_split_cnt + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipEventRecord(ev[4], st));

@@ -3,7 +3,8 @@
 // Replaces reference src/huffman/huffencoder.c (code lengths :157-270, length limit + canonical codes
 // :279-375, code-length RLE :446-735, table trimming :400-406,:532-538) and src/huffman/huffutils.c:34-114.
 // The arrays live in LDS. Two calling conventions:
-//   *_wave   : called by all 64 lanes; sorting is lane-parallel (rank sort), the inherently serial
+//   *_wave   : called by all 64 lanes of one wave on that wave's own LDS data (synchronised with zh_wave_sync, so several
+//              waves of a workgroup can run different instances at once); sorting is lane-parallel (rank sort), the inherently serial
 //              two-queue merge runs on lane 0;
 //   *_lane   : plain single-lane code on a private LDS slice, for small alphabets (the 19-symbol code-length
 //              alphabet) where several independent instances run in different lanes at once.
@@ -72,7 +73,7 @@ __device__ inline void zh_rank_sort_wave(const uint32_t *keys, uint32_t *sorted,
          sorted[rank] = k;
       }
    }
-   zh_sync();
+   zh_wave_sync();
 }
 
 // Collect (value<<9 | symbol) keys of the symbols with value != 0, in symbol order. Returns the count.
@@ -87,7 +88,7 @@ __device__ inline int zh_collect_keys_wave(const T *value, int nsym, zh_huff_scr
       if (v != 0) sc->keys[n + zh_popc64(m & ((1ull << lane) - 1))] = (v << 9) | (uint32_t)s;
       n += zh_popc64(m);
    }
-   zh_sync();
+   zh_wave_sync();
    return n;
 }
 
@@ -96,19 +97,19 @@ __device__ inline void zh_huff_lengths_wave(const int32_t *freq, uint8_t *len, i
    const int lane = (int)zh_lane();
    int n = zh_collect_keys_wave(freq, nsym, sc);
    for (int s = lane; s < nsym; s += 64) len[s] = 0;
-   zh_sync();
+   zh_wave_sync();
    if (n <= 1) {
       if (lane == 0) len[0] = 1;   // huffencoder.c:263-267: symbol 0, whichever symbol was used
-      zh_sync();
+      zh_wave_sync();
       return;
    }
    zh_rank_sort_wave(sc->keys, sc->sorted, n);
    for (int e = lane; e < n; e += 64) sc->A[e] = (int32_t)(sc->sorted[e] >> 9);
-   zh_sync();
+   zh_wave_sync();
    if (lane == 0) zh_mk_depths(sc->A, n);
-   zh_sync();
+   zh_wave_sync();
    for (int e = lane; e < n; e += 64) len[sc->sorted[e] & 511u] = (uint8_t)sc->A[e];
-   zh_sync();
+   zh_wave_sync();
 }
 
 __device__ __forceinline__ uint32_t zh_bitrev16(uint32_t v, int nbits) {
@@ -168,14 +169,14 @@ __device__ inline int zh_huff_build_wave(const int32_t *freq, uint8_t *len, uint
    int rc = 0;
    if (over) {
       if (lane == 0) sc->count = (uint32_t)zh_limit_lengths(len, sc->sorted, n, maxbits);
-      zh_sync();
+      zh_wave_sync();
       rc = (int)sc->count;
-      zh_sync();
+      zh_wave_sync();
       n = zh_collect_keys_wave(len, nsym, sc);   // huffencoder.c:344: order again after the repair
       zh_rank_sort_wave(sc->keys, sc->sorted, n);
    }
    if (lane == 0 && n > 0) zh_assign_codes(len, code, sc->sorted, n);
-   zh_sync();
+   zh_wave_sync();
    return rc;
 }
 
@@ -183,10 +184,10 @@ __device__ inline int zh_huff_build_wave(const int32_t *freq, uint8_t *len, uint
 __device__ inline void zh_huff_static_codes_wave(const uint8_t *len, uint16_t *code, int nsym, zh_huff_scratch_t *sc) {
    const int lane = (int)zh_lane();
    for (int s = lane; s < nsym; s += 64) sc->keys[s] = ((uint32_t)len[s] << 9) | (uint32_t)s;
-   zh_sync();
+   zh_wave_sync();
    zh_rank_sort_wave(sc->keys, sc->sorted, nsym);
    if (lane == 0) zh_assign_codes(len, code, sc->sorted, nsym);
-   zh_sync();
+   zh_wave_sync();
 }
 
 // huffencoder.c:532-538

@@ -99,6 +99,13 @@ __device__ __forceinline__ uint64_t zh_clock() { return (uint64_t)clock64(); }
 
 // LDS visibility between the lanes of a workgroup (a single wave for the 64-thread kernels)
 __device__ __forceinline__ void zh_sync() { __syncthreads(); }
+// LDS visibility between the lanes of ONE wave (wave-private data inside a multi-wave workgroup): LDS operations of a
+// wave execute in order, so draining them and stopping the compiler from moving accesses across is all it takes.
+__device__ __forceinline__ void zh_wave_sync() {
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+   __builtin_amdgcn_wave_barrier();
+   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 __device__ __forceinline__ uint32_t zh_atomic_add_lds(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t zh_atomic_add_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }

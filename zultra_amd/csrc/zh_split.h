@@ -96,22 +96,35 @@ zh_tokenize(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blo
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// per-wave LDS workspace of zh_split
+// zh_split: one workgroup of ZH_SPLIT_WAVES waves per max-block
 // ---------------------------------------------------------------------------------------------------------
-struct zh_split_ws_t {
-   int32_t tot_lit[ZH_NLIT], tot_dist[ZH_NDIST];
+// The reference's search (blockdeflate.c:659-773) walks the checkpoints of a range one after another, but nothing it
+// decides at a checkpoint feeds the next one except cumulative histograms: whether checkpoint j triggers an evaluation
+// depends on the 18-bin statistics before and inside its interval, and an evaluation prices "tokens before the previous
+// checkpoint" against "the rest". So: the interval statistics are gathered by all waves, every wave then replays the cheap
+// trigger scan, the triggered evaluations (four Huffman length builds and two table costs each — what the kernel's time
+// goes into) are dealt round-robin to the waves, and the reference's selection rule runs over the gains in order.
+#define ZH_SPLIT_WAVES 8
+#define ZH_SPLIT_THREADS (64 * ZH_SPLIT_WAVES)
+#define ZH_SPLIT_MAXCP 256   // checkpoints per chunk (a 64 KiB max-block has at most 256)
+
+struct zh_split_wave_ws_t {   // private to one wave
    int32_t left_lit[ZH_NLIT], left_dist[ZH_NDIST];
    int32_t cur_lit[ZH_NLIT], cur_dist[ZH_NDIST];
    uint8_t lit_len[ZH_NLIT], dist_len[ZH_NDIST];
    uint8_t lens[ZH_NLIT + ZH_NDIST];
-   uint32_t fresh[18], seen[18];
    zh_huff_scratch_t sc;
    zh_cl_t cl;
    int32_t tmp;
 };
+struct zh_split_shared_t {
+   int32_t tot_lit[ZH_NLIT], tot_dist[ZH_NDIST];
+   uint32_t fresh[ZH_SPLIT_MAXCP][18];
+   int32_t gain[ZH_SPLIT_MAXCP];
+};
 
 // blockdeflate.c:577-618 for the histogram in (lit, dist): unlimited lengths, body bits, header bits, +3.
-// All lanes call; returns the same value in every lane.
+// All lanes of one wave call; returns the same value in every lane.
 __device__ inline int zh_dynamic_cost_wave(const int32_t *lit, const int32_t *dist, uint8_t *lit_len, uint8_t *dist_len,
                                            uint8_t *lens, zh_cl_t *cl, int32_t *tmp, zh_huff_scratch_t *sc,
                                            bool compute_lengths) {
@@ -132,15 +145,15 @@ __device__ inline int zh_dynamic_cost_wave(const int32_t *lit, const int32_t *di
    const int ndist = zh_defined_count(dist_len, ZH_NDIST, 1);
    for (int s = lane; s < nlit; s += 64) lens[s] = lit_len[s];
    if (lane < ndist) lens[nlit + lane] = dist_len[lane];
-   zh_sync();
+   zh_wave_sync();
    if (lane == 0) *tmp = zh_table_cost_lane(lens, nlit + ndist, cl, (uint16_t *)sc->keys);   // the sort scratch is free here
-   zh_sync();
+   zh_wave_sync();
    int r = (int)body + *tmp + 3;
-   zh_sync();
+   zh_wave_sync();
    return r;
 }
 
-// histogram of the greedy tokens [t0, t1) added into (lit, dist). All lanes call.
+// histogram of the greedy tokens [t0, t1) added into (lit, dist). All lanes of one wave call.
 __device__ inline void zh_token_histogram_wave(const uint16_t *ti, uint32_t t0, uint32_t t1, int32_t *lit, int32_t *dist) {
    for (uint32_t t = t0 + zh_lane(); t < t1; t += 64) {
       uint32_t info = ti[t];
@@ -148,104 +161,124 @@ __device__ inline void zh_token_histogram_wave(const uint16_t *ti, uint32_t t0, 
       atomicAdd(&lit[s], 1);
       if (s > 256) atomicAdd(&dist[ZH_TOK_DSYM(info)], 1);
    }
-   zh_sync();
+   zh_wave_sync();
 }
 
 // Search the best split of token range [t0, t1) (blockdeflate.c:659-773). Returns the token index of the
-// split boundary, or 0xFFFFFFFF. All lanes call; uniform result.
-__device__ inline uint32_t zh_split_search_wave(zh_split_ws_t *ws, const uint32_t *tp, const uint16_t *ti, uint32_t t0,
-                                                uint32_t t1, uint32_t start_pos, uint32_t end_pos) {
-   const uint32_t lane = zh_lane();
+// split boundary, or 0xFFFFFFFF. All threads of the workgroup call; uniform result.
+__device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wave_ws_t *ws, const uint32_t *tp, const uint16_t *ti, uint32_t t0,
+                                              uint32_t t1, uint32_t start_pos, uint32_t end_pos) {
+   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-   for (uint32_t s = lane; s < ZH_NLIT; s += 64) {
-      ws->tot_lit[s] = 0;
-      ws->left_lit[s] = 0;
+   // histogram and price of the whole range
+   for (uint32_t s = tid; s < ZH_NLIT; s += ZH_SPLIT_THREADS) sh->tot_lit[s] = 0;
+   if (tid < ZH_NDIST) sh->tot_dist[tid] = 0;
+   __syncthreads();
+   for (uint32_t t = t0 + tid; t < t1; t += ZH_SPLIT_THREADS) {
+      const uint32_t info = ti[t];
+      const uint32_t s = ZH_TOK_SYM(info);
+      atomicAdd(&sh->tot_lit[s], 1);
+      if (s > 256) atomicAdd(&sh->tot_dist[ZH_TOK_DSYM(info)], 1);
    }
-   if (lane < ZH_NDIST) {
-      ws->tot_dist[lane] = 0;
-      ws->left_dist[lane] = 0;
-   }
-   if (lane < 18) ws->seen[lane] = 0;
-   zh_sync();
-   zh_token_histogram_wave(ti, t0, t1, ws->tot_lit, ws->tot_dist);
-   if (lane == 0) ws->tot_lit[ZH_EOB] += 1;
-   zh_sync();
-   const int total_cost = zh_dynamic_cost_wave(ws->tot_lit, ws->tot_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl,
-                                               &ws->tmp, &ws->sc, true);
+   __syncthreads();
+   if (tid == 0) sh->tot_lit[ZH_EOB] += 1;
+   __syncthreads();
+   // (every wave prices it for itself, on its own scratch: no hand-over needed)
+   const int total_cost = zh_dynamic_cost_wave(sh->tot_lit, sh->tot_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl, &ws->tmp, &ws->sc, true);
 
+   // checkpoints: the first boundary c0 with >= 256 tokens and >= 512 bytes since the range start, then every 256 tokens (:705)
+   uint32_t c0 = t0 + 256;
+   if (c0 > t1) return 0xFFFFFFFFu;
+   while (c0 < t1 && tp[c0] - start_pos < 512) c0++;
+   {
+      const uint32_t pc = (c0 < t1) ? tp[c0] : end_pos;
+      if (pc - start_pos < 512) return 0xFFFFFFFFu;   // ran out of tokens before 512 bytes
+   }
+   const uint32_t ncp = (t1 - c0) / 256 + 1;
+
+   uint32_t seen = 0;      // lane < 18: tokens of this bin before the current interval (:709-719)
    uint32_t nseen = 0;
-   uint32_t cp_prev = t0;             // token index where the current stats interval starts
-   uint32_t checkpoint = 0xFFFFFFFFu; // nLastGoodSplitIdx as a token boundary
-   uint32_t left_end = t0;            // nLastLeftEndOffset as a token boundary
    uint32_t best = 0xFFFFFFFFu;
    int best_gain = 0;
 
-   for (;;) {
-      // next check: first boundary c with c - cp_prev >= 256 tokens and pos(c) - start >= 512 (:705)
-      uint32_t c = cp_prev + 256;
-      if (c > t1) break;
-      while (c < t1 && tp[c] - start_pos < 512) c++;
-      {
-         uint32_t pc = (c < t1) ? tp[c] : end_pos;
-         if (pc - start_pos < 512) break;   // ran out of tokens before 512 bytes
-      }
-      const uint32_t nfresh = c - cp_prev;
-
-      if (lane < 18) ws->fresh[lane] = 0;
-      zh_sync();
-      for (uint32_t t = cp_prev + lane; t < c; t += 64) {
-         uint32_t s = ZH_TOK_SYM(ti[t]);
-         uint32_t bin = (s < 256) ? (((s >> 4) & 0xc) | (s & 3)) : (s >= 263 ? 17u : 16u);   // :689-699 (len >= 9 <=> symbol >= 263)
-         atomicAdd(&ws->fresh[bin], 1u);
-      }
-      zh_sync();
-
-      if (nseen) {
-         uint32_t d = 0;
-         if (lane < 18) {
-            uint32_t expected = ws->seen[lane] * nfresh;   // uint32 wrap is part of the behaviour (:710-711)
-            uint32_t actual = ws->fresh[lane] * nseen;
-            d = expected > actual ? expected - actual : actual - expected;
+   for (uint32_t j0 = 0; j0 < ncp; j0 += ZH_SPLIT_MAXCP) {
+      const uint32_t nj = min((uint32_t)ZH_SPLIT_MAXCP, ncp - j0);
+      // 18-bin statistics of every interval of the chunk: interval j = tokens [c(j-1), c(j)), c(-1) = t0, c(j) = c0 + 256 j
+      for (uint32_t k = tid; k < nj * 18; k += ZH_SPLIT_THREADS) sh->fresh[k / 18][k % 18] = 0;
+      __syncthreads();
+      for (uint32_t jj = wave; jj < nj; jj += ZH_SPLIT_WAVES) {
+         const uint32_t j = j0 + jj;
+         const uint32_t lo = j == 0 ? t0 : c0 + 256 * (j - 1), hi = c0 + 256 * j;
+         for (uint32_t t = lo + lane; t < hi; t += 64) {
+            const uint32_t s = ZH_TOK_SYM(ti[t]);
+            const uint32_t bin = (s < 256) ? (((s >> 4) & 0xc) | (s & 3)) : (s >= 263 ? 17u : 16u);   // :689-699 (len >= 9 <=> symbol >= 263)
+            atomicAdd(&sh->fresh[jj][bin], 1u);
          }
-         const uint32_t drift = zh_wave_sum(d);
-         if ((drift / nfresh) >= (nseen * 45 / 100) && checkpoint != 0xFFFFFFFFu) {
-            // left += tokens [left_end, checkpoint); right = total - left (:732-743)
-            zh_token_histogram_wave(ti, left_end, checkpoint, ws->left_lit, ws->left_dist);
-            if (lane == 0) ws->left_lit[ZH_EOB] = 1;
-            zh_sync();
-            const int lcost = zh_dynamic_cost_wave(ws->left_lit, ws->left_dist, ws->lit_len, ws->dist_len, ws->lens,
-                                                   &ws->cl, &ws->tmp, &ws->sc, true);
-            for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws->cur_lit[s] = ws->tot_lit[s] - ws->left_lit[s];
-            if (lane < ZH_NDIST) ws->cur_dist[lane] = ws->tot_dist[lane] - ws->left_dist[lane];
-            zh_sync();
-            if (lane == 0) ws->cur_lit[ZH_EOB] = 1;
-            zh_sync();
-            const int rcost = zh_dynamic_cost_wave(ws->cur_lit, ws->cur_dist, ws->lit_len, ws->dist_len, ws->lens,
-                                                   &ws->cl, &ws->tmp, &ws->sc, true);
-            const int gain = total_cost - (lcost + rcost);
-            if (gain >= 0 && (best == 0xFFFFFFFFu || best_gain < gain)) {
-               best = checkpoint;
-               best_gain = gain;
+      }
+      __syncthreads();
+      // which checkpoints trigger an evaluation (every wave replays this; it is a few instructions per checkpoint)
+      uint64_t trig[ZH_SPLIT_MAXCP / 64] = {0, 0, 0, 0};
+      for (uint32_t jj = 0; jj < nj; jj++) {
+         const uint32_t j = j0 + jj;
+         const uint32_t nfresh = j == 0 ? c0 - t0 : 256u;
+         const uint32_t fr = lane < 18 ? sh->fresh[jj][lane] : 0u;
+         if (nseen) {
+            uint32_t d = 0;
+            if (lane < 18) {
+               const uint32_t expected = seen * nfresh;   // uint32 wrap is part of the behaviour (:710-711)
+               const uint32_t actual = fr * nseen;
+               d = expected > actual ? expected - actual : actual - expected;
             }
-            left_end = checkpoint;
+            const uint32_t drift = zh_wave_sum(d);
+            if ((drift / nfresh) >= (nseen * 45 / 100)) trig[jj >> 6] |= 1ull << (jj & 63);   // a previous checkpoint exists: nseen != 0
+         }
+         seen += fr;
+         nseen += nfresh;
+      }
+      // the triggered evaluations, dealt to the waves: left = tokens before the previous checkpoint, right = the rest (:732-750)
+      uint32_t k = 0;
+      for (uint32_t jj = 0; jj < nj; jj++) {
+         if (!((trig[jj >> 6] >> (jj & 63)) & 1ull)) continue;
+         if ((k++ % ZH_SPLIT_WAVES) != wave) continue;
+         const uint32_t cp = c0 + 256 * (j0 + jj - 1);
+         for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws->left_lit[s] = 0;
+         if (lane < ZH_NDIST) ws->left_dist[lane] = 0;
+         zh_wave_sync();
+         zh_token_histogram_wave(ti, t0, cp, ws->left_lit, ws->left_dist);
+         for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws->cur_lit[s] = sh->tot_lit[s] - ws->left_lit[s];
+         if (lane < ZH_NDIST) ws->cur_dist[lane] = sh->tot_dist[lane] - ws->left_dist[lane];
+         zh_wave_sync();
+         if (lane == 0) {
+            ws->left_lit[ZH_EOB] = 1;
+            ws->cur_lit[ZH_EOB] = 1;
+         }
+         zh_wave_sync();
+         const int lcost = zh_dynamic_cost_wave(ws->left_lit, ws->left_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl, &ws->tmp, &ws->sc, true);
+         const int rcost = zh_dynamic_cost_wave(ws->cur_lit, ws->cur_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl, &ws->tmp, &ws->sc, true);
+         if (lane == 0) sh->gain[jj] = total_cost - (lcost + rcost);
+      }
+      __syncthreads();
+      // the reference keeps the first non-negative gain, then only strictly larger ones (:751-757)
+      for (uint32_t jj = 0; jj < nj; jj++) {
+         if (!((trig[jj >> 6] >> (jj & 63)) & 1ull)) continue;
+         const int gain = sh->gain[jj];
+         if (gain >= 0 && (best == 0xFFFFFFFFu || best_gain < gain)) {
+            best = c0 + 256 * (j0 + jj - 1);
+            best_gain = gain;
          }
       }
-      if (lane < 18) ws->seen[lane] += ws->fresh[lane];
-      zh_sync();
-      nseen += nfresh;
-      checkpoint = c;
-      cp_prev = c;
-      if (c >= t1) break;
+      __syncthreads();
    }
    return best;
 }
 
-// One wave per max-block. Output: split_tok[b*65 + k] token boundaries (k = 0..count, first = 0, last = ntok),
-// split_cnt[b] = number of sub-blocks.
-__global__ void __launch_bounds__(64)
+// Output: split_tok[b*65 + k] token boundaries (k = 0..count, first = 0, last = ntok), split_cnt[b] = number of sub-blocks.
+__global__ void __launch_bounds__(ZH_SPLIT_THREADS)
 zh_split(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ tok_pos, const uint16_t *__restrict__ tok_info,
          uint64_t tok_stride, const uint32_t *__restrict__ ntok_in, uint32_t *split_tok, uint32_t *split_cnt) {
-   __shared__ zh_split_ws_t ws;
+   __shared__ zh_split_shared_t sh;
+   __shared__ zh_split_wave_ws_t wws[ZH_SPLIT_WAVES];
+   zh_split_wave_ws_t *ws = &wws[threadIdx.x >> 6];
    const zh_block_t blk = blocks[blockIdx.x];
    const uint32_t *tp = tok_pos + (uint64_t)blockIdx.x * tok_stride;
    const uint16_t *ti = tok_info + (uint64_t)blockIdx.x * tok_stride;
@@ -253,7 +286,7 @@ zh_split(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ tok
    const uint32_t block_end = blk.prev + blk.n;
    uint32_t *out = split_tok + (uint64_t)blockIdx.x * (ZH_MAX_SPLITS + 1);
 
-   // explicit recursion (depth <= 6): frames hold [t0,t1), the chosen boundary and a phase
+   // explicit recursion (depth <= 6): frames hold [t0,t1), the chosen boundary and a phase; identical in every thread
    uint32_t f_t0[8], f_t1[8], f_best[8];
    int f_phase[8];
    int sp = 0;
@@ -263,7 +296,7 @@ zh_split(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ tok
    f_phase[0] = 0;
    f_best[0] = 0;
 
-   if (zh_lane() == 0) out[0] = 0;
+   if (threadIdx.x == 0) out[0] = 0;
 
    while (sp >= 0) {
       const uint32_t t0 = f_t0[sp], t1 = f_t1[sp];
@@ -274,7 +307,7 @@ zh_split(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ tok
             sp--;
             continue;
          }
-         const uint32_t b = zh_split_search_wave(&ws, tp, ti, t0, t1, p0, p1);
+         const uint32_t b = zh_split_search_wg(&sh, ws, tp, ti, t0, t1, p0, p1);
          if (b == 0xFFFFFFFFu) {
             sp--;
             continue;
@@ -289,7 +322,7 @@ zh_split(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ tok
       else if (f_phase[sp] == 1) {
          if (count < ZH_MAX_SPLITS - 1) {
             count++;
-            if (zh_lane() == 0) out[count] = f_best[sp];
+            if (threadIdx.x == 0) out[count] = f_best[sp];
          }
          f_phase[sp] = 2;
          f_t0[sp + 1] = f_best[sp];
@@ -300,7 +333,7 @@ zh_split(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ tok
       else
          sp--;
    }
-   if (zh_lane() == 0) {
+   if (threadIdx.x == 0) {
       out[count + 1] = ntok;
       split_cnt[blockIdx.x] = count + 1;
    }
