@@ -468,41 +468,58 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
                else
                   b = mid;
             }
-            // (2) earlier runs of the same byte, nearest first; inside a run the nearer positions have fewer bytes left
-            for (uint32_t j = a > g0 ? a - 1 : g0; j > g0 && cur < maxlen;) {
-               j--;
-               const uint32_t e = RS[j] + RL[j], len = RL[j];   // run [start, e)
-               if (i - (e - ZH_RUN_MIN) > ZH_MAX_DIST) break;  // its nearest class member is out of reach: so is everything farther
-               // positions with cur < r_p < r bytes left: each matches r_p bytes, a new record every time
-               for (uint32_t k = max(cur + 1, (uint32_t)ZH_RUN_MIN); k < r && k <= len; k++) {
-                  if (i - (e - k) > ZH_MAX_DIST) break;
-                  myring[(nm & 7u) * ZH_MF_THREADS] = k | ((i - (e - k)) << 16);
-                  nm++;
-                  cur = k;
+            // (2) earlier runs of the same byte, nearest first; inside a run the nearer positions have fewer bytes left.
+            //     Four table entries are fetched per round trip.
+            uint32_t j = a > g0 ? a - 1 : g0;
+            while (j > g0 && cur < maxlen) {
+               const uint32_t nf = min(4u, j - g0);
+               uint32_t es[4], ls[4];
+#pragma unroll
+               for (uint32_t u = 0; u < 4; u++) {
+                  const uint32_t jj = j - 1 - min(u, nf - 1);
+                  ls[u] = RL[jj];
+                  es[u] = RS[jj] + ls[u];   // run [start, e)
                }
-               // the one position with exactly r bytes left: the match continues past the runs
-               if (len >= r && cur < maxlen) {
-                  const uint32_t p = e - r;
-                  if (i - p <= ZH_MAX_DIST) {
-                     uint32_t l = r;
-                     if (LDS_WIN) {
-                        while (l < maxlen) {
-                           const uint32_t x = zh_load32_at(lwin32, p + l) ^ zh_load32_at(lwin32, i + l);
-                           if (x) {
-                              l += (uint32_t)(__ffs((int)x) - 1) >> 3;
-                              break;
+               j -= nf;
+#pragma unroll
+               for (uint32_t u = 0; u < 4; u++) {
+                  if (u >= nf || cur >= maxlen) break;
+                  const uint32_t e = es[u], len = ls[u];
+                  if (i - (e - ZH_RUN_MIN) > ZH_MAX_DIST) {   // its nearest class member is out of reach: so is everything farther
+                     j = g0;
+                     break;
+                  }
+                  // positions with cur < r_p < r bytes left: each matches r_p bytes, a new record every time
+                  for (uint32_t k = max(cur + 1, (uint32_t)ZH_RUN_MIN); k < r && k <= len; k++) {
+                     if (i - (e - k) > ZH_MAX_DIST) break;
+                     myring[(nm & 7u) * ZH_MF_THREADS] = k | ((i - (e - k)) << 16);
+                     nm++;
+                     cur = k;
+                  }
+                  // the one position with exactly r bytes left: the match continues past the runs
+                  if (len >= r) {
+                     const uint32_t p = e - r;
+                     if (i - p <= ZH_MAX_DIST && (cur < r || win[p + cur] == win[i + cur])) {   // cheap reject: it must agree at byte `cur`
+                        uint32_t l = r;
+                        if (LDS_WIN) {
+                           while (l < maxlen) {
+                              const uint32_t x = zh_load32_at(lwin32, p + l) ^ zh_load32_at(lwin32, i + l);
+                              if (x) {
+                                 l += (uint32_t)(__ffs((int)x) - 1) >> 3;
+                                 break;
+                              }
+                              l += 4;
                            }
-                           l += 4;
+                           l = min(l, maxlen);
                         }
-                        l = min(l, maxlen);
-                     }
-                     else {
-                        while (l < maxlen && win[p + l] == win[i + l]) l++;
-                     }
-                     if (l > cur) {
-                        myring[(nm & 7u) * ZH_MF_THREADS] = l | ((i - p) << 16);
-                        nm++;
-                        cur = l;
+                        else {
+                           while (l < maxlen && win[p + l] == win[i + l]) l++;
+                        }
+                        if (l > cur) {
+                           myring[(nm & 7u) * ZH_MF_THREADS] = l | ((i - p) << 16);
+                           nm++;
+                           cur = l;
+                        }
                      }
                   }
                }
@@ -567,8 +584,12 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
             const uint32_t q1 = c1 & ZH_MF_POS_MASK, q2 = c2 & ZH_MF_POS_MASK;
             const uint32_t d1 = i - q1, d2 = i - q2;
             const bool ok1 = d1 <= ZH_MAX_DIST, ok2 = d2 <= ZH_MAX_DIST;     // false for the sentinel too
-            const uint32_t pb1 = win[(ok1 ? q1 : i) + fo + 3], pb2 = win[(ok2 ? q2 : i) + fo + 3];
-            const uint32_t tgt = ci >> 24;
+            // both 4-byte probes are issued before either is used (an out-of-reach candidate probes the lane's own position);
+            // nearly every candidate dies here, so the divergent verification below runs for few lanes and few iterations
+            const uint32_t a1 = (ok1 ? q1 : i) + fo, a2 = (ok2 ? q2 : i) + fo;
+            const uint32_t pb1 = LDS_WIN ? zh_load32_at(lwin32, a1) : zh_ld32(win + a1);
+            const uint32_t pb2 = LDS_WIN ? zh_load32_at(lwin32, a2) : zh_ld32(win + a2);
+            const uint32_t tgt = ci;
             if (ok1 && pb1 == tgt) { ZH_MF_VERIFY(q1, d1) }
             if (ok2 && pb2 == tgt && cur < maxlen) { ZH_MF_VERIFY(q2, d2) }
             // the class ends at its head; beyond 32 KiB everything else is farther still; 258 (or the window end) cannot be beaten
