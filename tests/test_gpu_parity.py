@@ -155,3 +155,30 @@ def test_files_mode_graph_replay_vs_oracle(gpu, oracle):
                 assert gpu.crc32_append(0, crcs[k], sizes[k]) == zlib.crc32(files[k].tobytes())
     finally:
         ctx.close()
+
+
+def _image_files(pattern, limit):
+    import glob
+    buf = bytearray()
+    for f in sorted(glob.glob(pattern, recursive=True)):
+        try:
+            buf += open(f, "rb").read()
+        except OSError:
+            continue
+        if len(buf) >= limit:
+            break
+    return np.frombuffer(bytes(buf[:limit]), dtype=np.uint8).copy()
+
+
+@pytest.mark.parametrize("kind,flags,bs", [("pysrc", 2, 65536), ("x86", 1, 32768), ("pysrc_1m", 0, 0)])
+def test_real_data_streams_vs_oracle(gpu, oracle, kind, flags, bs):
+    """Real text and a real executable from this image (same files on the GPU box): byte runs, long repeats, long
+    barrier-free stretches — the inputs the synthetic corpora are kind to. Whole streams must equal the oracle's."""
+    if kind == "x86":
+        d = _image_files("/usr/bin/python3*", 2_500_000)
+    else:
+        d = _image_files("/usr/lib/python3*/**/*.py", 6_000_000)[2_000_000:6_000_000 if kind == "pysrc" else 4_500_000]
+    if len(d) < 1_000_000:
+        pytest.skip("image files not available")
+    got = gpu.memory_compress(d, flags, bs)
+    assert got == oracle.memory_compress(d, flags, bs)
