@@ -49,6 +49,12 @@ def test_stages_vs_oracle(emu, oracle, case):
     check_window(emu, oracle, gen(), prev, n, tag=name)
 
 
+def test_large_max_block_is_cut_into_matchfinder_segments(emu, oracle):
+    # window of 20000 + 80000 bytes > the 96 KiB LDS window: two segments, the first with 258 bytes of look-ahead
+    d = np.concatenate([corpus.text_like(60000, 31), corpus.indented(25000, 5), corpus.text_like(15000, 32)])
+    check_window(emu, oracle, d, 20000, 80000, max_block=131072, tag="segments")
+
+
 @pytest.mark.parametrize("name", ["tiny_100", "one_byte", "two_bytes", "json_4k", "json_4k_b"])
 def test_golden_streams(emu, name):
     c = G.stream_case(name)

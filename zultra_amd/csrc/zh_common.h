@@ -30,6 +30,19 @@ typedef struct zh_block_s {
    uint32_t n;
 } zh_block_t;
 
+// Matchfinder segment (internal to the device layer). Match rows only depend on the 32 KiB before a position and the
+// <= 258 bytes after it, so a max-block of any size is cut into segments that fit the LDS window: `prev` bytes of history,
+// `n` positions that get rows, `tail` bytes of look-ahead (0 at the end of the max-block, where the reference clamps the
+// match length too). A max-block of <= 64 KiB is one segment.
+typedef struct zh_seg_s {
+   uint64_t win_off;   // segment window = data + win_off
+   uint32_t prev, n, tail;
+   uint32_t block;     // max-block it belongs to (index into the run's block list)
+   uint64_t row_off;   // its first row, in positions from the start of the max-block's rows
+} zh_seg_t;
+#define ZH_SEG_WINDOW 98304u                                   // LDS window of the matchfinder kernels
+#define ZH_SEG_POSITIONS (ZH_SEG_WINDOW - ZH_HISTORY - ZH_MAX_MATCH)   // rows per segment of a large max-block
+
 // Result of one sub-block (device -> host). `bits_off` is the byte offset of its phase-0 bitstream in the
 // batch payload buffer. BFINAL/BTYPE, the stored fallback and the bit carry are applied by the stitcher
 // (libzultra.c:327-398), which needs exactly these fields.

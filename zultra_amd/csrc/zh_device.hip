@@ -46,6 +46,11 @@ struct zultra_hip_ctx_s {
    zh_block_t *d_blocks;
    uint32_t *d_sort_a, *d_sort_b, *d_prev3, *d_runs;
    uint64_t run_stride;
+   // matchfinder segments (zh_common.h): max-blocks above 64 KiB are cut so that every segment window fits the LDS
+   uint32_t seg_n, segs_per_block, seg_W;
+   zh_seg_t *d_segs;
+   std::vector<zh_seg_t> segs;
+   std::vector<uint32_t> seg_base;
    zh_match_t *d_match;
    uint32_t *d_tok_pos;
    uint16_t *d_tok_info;
@@ -230,6 +235,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_sort_b);
    (void)hipFree(c->d_prev3);
    (void)hipFree(c->d_runs);
+   (void)hipFree(c->d_segs);
    (void)hipFree(c->d_match);
    (void)hipFree(c->d_tok_pos);
    (void)hipFree(c->d_tok_info);
@@ -298,10 +304,11 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->bar_stride = c->tok_stride / 64;
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
-       zh_alloc(c, &c->d_prev3, B * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->run_stride) || zh_alloc(c, &c->d_ntasks, 4) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+       zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
+       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_ntasks, 4) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
-   if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->sort_stride) ||
-       zh_alloc(c, &c->d_sort_b, B * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
+   if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
+       zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
        zh_alloc(c, &c->d_tok_pos, B * c->tok_stride) || zh_alloc(c, &c->d_tok_info, B * c->tok_stride) ||
        zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_split_tok, B * (ZH_MAX_SPLITS + 1)) || zh_alloc(c, &c->d_split_cnt, B) ||
        zh_alloc(c, &c->d_sub_base, B) || zh_alloc(c, &c->d_best, B * c->best_stride) || zh_alloc(c, &c->d_work, B * c->max_subs) ||
@@ -342,7 +349,17 @@ static zultra_hip_ctx_t *zh_create(int device, uint32_t max_block, uint32_t max_
    c->max_blocks = max_blocks;
    c->max_subs = files_mode ? 1u : (uint32_t)ZH_MAX_SPLITS;
    c->W = (uint64_t)c->max_block + (files_mode ? 0u : (uint32_t)ZH_HISTORY);
-   c->sort_stride = (c->W + 63) & ~63ull;
+   if (c->W <= ZH_SEG_WINDOW) {   // a max-block is one matchfinder segment
+      c->seg_n = c->max_block;
+      c->segs_per_block = 1;
+      c->seg_W = (uint32_t)c->W;
+   }
+   else {
+      c->seg_n = ZH_SEG_POSITIONS;
+      c->segs_per_block = (c->max_block + ZH_SEG_POSITIONS - 1) / ZH_SEG_POSITIONS;
+      c->seg_W = ZH_SEG_WINDOW;
+   }
+   c->sort_stride = ((uint64_t)c->seg_W + 63) & ~63ull;
    c->run_stride = c->sort_stride + 576;   // start[Q] length[Q] first[256] end[256] count, Q = W/4 + 1
    c->match_stride = (uint64_t)c->max_block * ZH_NMATCH;
    c->tok_stride = ((uint64_t)c->max_block + 63) & ~63ull;
@@ -370,6 +387,41 @@ extern "C" zultra_hip_ctx_t *zultra_hip_create_files(int device, uint32_t max_fi
 extern "C" const char *zultra_hip_last_error(const zultra_hip_ctx_t *c) { return c ? c->err : "no context"; }
 extern "C" size_t zultra_hip_data_capacity(const zultra_hip_ctx_t *c) { return c ? c->data_cap : 0; }
 
+// Cuts the max-blocks of a batch into matchfinder segments (zh_common.h) and uploads the list.
+static int zh_build_segments(zultra_hip_ctx_t *c, const zultra_hip_block_t *blocks, uint32_t nblocks, hipStream_t st) {
+   c->segs.clear();
+   c->seg_base.resize(nblocks + 1);
+   for (uint32_t b = 0; b < nblocks; b++) {
+      c->seg_base[b] = (uint32_t)c->segs.size();
+      const zultra_hip_block_t &blk = blocks[b];
+      if ((uint64_t)blk.prev + blk.n <= ZH_SEG_WINDOW && c->segs_per_block == 1) {
+         zh_seg_t sg = {blk.win_off, blk.prev, blk.n, 0, b, 0};
+         c->segs.push_back(sg);
+         continue;
+      }
+      if ((uint64_t)blk.prev + blk.n <= ZH_SEG_WINDOW) {   // a short max-block of a large-block context
+         zh_seg_t sg = {blk.win_off, blk.prev, blk.n, 0, b, 0};
+         c->segs.push_back(sg);
+         continue;
+      }
+      for (uint32_t pos = 0; pos < blk.n;) {
+         const uint32_t len = blk.n - pos < c->seg_n ? blk.n - pos : c->seg_n;
+         const uint32_t hist = blk.prev + pos < ZH_HISTORY ? blk.prev + pos : (uint32_t)ZH_HISTORY;
+         const uint32_t rest = blk.n - pos - len;
+         zh_seg_t sg = {blk.win_off + blk.prev + pos - hist, hist, len, rest < ZH_MAX_MATCH ? rest : (uint32_t)ZH_MAX_MATCH, b, pos};
+         c->segs.push_back(sg);
+         pos += len;
+      }
+   }
+   c->seg_base[nblocks] = (uint32_t)c->segs.size();
+   if (c->segs.size() > (size_t)c->max_blocks * c->segs_per_block) {
+      snprintf(c->err, sizeof(c->err), "segment list overflows");
+      return -1;
+   }
+   ZH_CHECK(c, hipMemcpyAsync(c->d_segs, c->segs.data(), c->segs.size() * sizeof(zh_seg_t), hipMemcpyHostToDevice, st));
+   return 0;
+}
+
 // files mode: what zh_split would report for an input below its 8192-byte threshold — one sub-block spanning all tokens
 __global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, uint32_t *split_tok, uint32_t *split_cnt, uint32_t *sub_base) {
    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -384,16 +436,10 @@ __global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, 
 // first time a (batch size, input pointer) pair is seen and replayed afterwards: one graph launch per batch.
 static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    const zh_block_t *blk = c->d_blocks;
-   if (c->W <= ZH_MF_LDS_WINDOW) {
-      ZH_LAUNCH(zh_mf_group<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride, c->run_stride, 0);
-      ZH_LAUNCH(zh_mf_frontier<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3,
-                (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride);
-   }
-   else {
-      ZH_LAUNCH(zh_mf_group<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride, c->run_stride, 0);
-      ZH_LAUNCH(zh_mf_frontier<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3,
-                (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride);
-   }
+   ZH_LAUNCH(zh_mf_group<true>, nb, ZH_MF_THREADS, st, c->cur_data, (const zh_seg_t *)c->d_segs, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride,
+             c->run_stride, 0);
+   ZH_LAUNCH(zh_mf_frontier<true>, nb, ZH_MF_THREADS, st, c->cur_data, (const zh_seg_t *)c->d_segs, (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3,
+             (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride);
    ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok,
              c->d_bars, c->bar_stride);
    ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
@@ -506,6 +552,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       c->cur_data = c->d_data;
    }
    ZH_CHECK(c, hipMemcpyAsync(c->d_blocks, blocks, nblocks * sizeof(zh_block_t), hipMemcpyHostToDevice, st0));
+   if (zh_build_segments(c, blocks, nblocks, st0) != 0) return -1;
    ZH_CHECK(c, hipEventRecord(c->ev_input, st0));
    if (c->files_mode) return zh_run_files(c, nblocks);
 
@@ -523,22 +570,16 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k - 1][3], 0));
       }
       ZH_CHECK(c, hipEventRecord(ev[1], st));
-      if (c->W <= ZH_MF_LDS_WINDOW)
-         ZH_LAUNCH(zh_mf_group<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a + b0 * c->sort_stride, c->d_sort_b + b0 * c->sort_stride,
-                   c->d_prev3 + b0 * c->sort_stride, c->d_runs + b0 * c->run_stride, c->sort_stride, c->run_stride, mf_stop);
-      else
-         ZH_LAUNCH(zh_mf_group<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, c->d_sort_a + b0 * c->sort_stride, c->d_sort_b + b0 * c->sort_stride,
-                   c->d_prev3 + b0 * c->sort_stride, c->d_runs + b0 * c->run_stride, c->sort_stride, c->run_stride, mf_stop);
+      const uint32_t sg0 = c->seg_base[b0], nsg = c->seg_base[b1] - sg0;   // this run's matchfinder segments
+      const zh_seg_t *sgs = c->d_segs + sg0;
+      uint32_t *sa = c->d_sort_a + (uint64_t)sg0 * c->sort_stride, *sb = c->d_sort_b + (uint64_t)sg0 * c->sort_stride;
+      uint32_t *p3 = c->d_prev3 + (uint64_t)sg0 * c->sort_stride, *rn = c->d_runs + (uint64_t)sg0 * c->run_stride;
+      ZH_LAUNCH(zh_mf_group<true>, nsg, ZH_MF_THREADS, st, c->cur_data, sgs, sa, sb, p3, rn, c->sort_stride, c->run_stride, mf_stop);
       ZH_CHECK(c, hipEventRecord(ev[2], st));
       if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
-      if (c->W <= ZH_MF_LDS_WINDOW)
-         ZH_LAUNCH(zh_mf_frontier<true>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)(c->d_sort_a + b0 * c->sort_stride),
-                   (const uint32_t *)(c->d_prev3 + b0 * c->sort_stride), (const uint32_t *)(c->d_runs + b0 * c->run_stride), c->sort_stride, c->run_stride,
-                   c->d_match + b0 * c->match_stride, c->match_stride);
-      else
-         ZH_LAUNCH(zh_mf_frontier<false>, nb, ZH_MF_THREADS, st, c->cur_data, blk, (const uint32_t *)(c->d_sort_a + b0 * c->sort_stride),
-                   (const uint32_t *)(c->d_prev3 + b0 * c->sort_stride), (const uint32_t *)(c->d_runs + b0 * c->run_stride), c->sort_stride, c->run_stride,
-                   c->d_match + b0 * c->match_stride, c->match_stride);
+      // (segment descriptors carry batch-wide block indices: the rows go to d_match + block * match_stride)
+      ZH_LAUNCH(zh_mf_frontier<true>, nsg, ZH_MF_THREADS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint32_t *)p3, (const uint32_t *)rn, c->sort_stride,
+                c->run_stride, c->d_match, c->match_stride);
       ZH_CHECK(c, hipEventRecord(ev[3], st));
       ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)(c->d_match + b0 * c->match_stride), c->match_stride,
                 c->d_tok_pos + b0 * c->tok_stride, c->d_tok_info + b0 * c->tok_stride, c->tok_stride, c->d_ntok + b0, c->d_bars + b0 * c->bar_stride,

@@ -204,11 +204,11 @@ __device__ __forceinline__ uint32_t zh_run_length(const uint8_t *g, uint32_t q, 
    return l;
 }
 
-__device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin, uint32_t W, uint32_t *T, uint32_t *runs, uint32_t *hist, uint32_t *wave_tot) {
+__device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin, uint32_t W, uint32_t Qn, uint32_t *T, uint32_t *runs, uint32_t *hist, uint32_t *wave_tot) {
    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const uint32_t Q = zh_runs_q(W);
    uint32_t *RS = runs, *RL = runs + Q, *first = runs + 2 * Q, *end = first + 256, *count = end + 256;
-   const uint32_t M = W >= ZH_RUN_MIN ? W - (ZH_RUN_MIN - 1) : 0;
+   const uint32_t M = min(Qn, W >= ZH_RUN_MIN ? W - (ZH_RUN_MIN - 1) : 0u);   // look-ahead positions start no runs of interest
    const uint32_t seg = (((M + ZH_MF_WAVES - 1) / ZH_MF_WAVES) + 63) & ~63u;
    const uint32_t lo = min(M, wave * seg), hi = min(M, lo + seg);
    const uint64_t lt_mask = (1ull << lane) - 1;
@@ -248,11 +248,12 @@ __device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin,
 
 // `win` is read linearly (global memory); `gwin` is the copy used for scattered reads (LDS when the window fits)
 template <bool PACKED>
-__device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin, uint32_t W, uint32_t first_needed, uint32_t *A, uint32_t *B, uint32_t *prev3,
-                                        uint32_t *runs, uint32_t *hist, uint32_t *wave_tot, int stop) {
+__device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin, uint32_t W, uint32_t Qn, uint32_t first_needed, uint32_t *A, uint32_t *B,
+                                        uint32_t *prev3, uint32_t *runs, uint32_t *hist, uint32_t *wave_tot, int stop) {
    const uint32_t tid = threadIdx.x;
-   const uint32_t M3 = W >= 3 ? W - 2 : 0;   // positions that start a trigram
-   const uint32_t M4 = W >= 4 ? W - 3 : 0;   // positions that start a 4-gram
+   // W = window bytes, Qn = positions that are candidates or get rows (the rest of the window is look-ahead)
+   const uint32_t M3 = min(Qn, W >= 3 ? W - 2 : 0u);   // positions that start a trigram
+   const uint32_t M4 = min(Qn, W >= 4 ? W - 3 : 0u);   // positions that start a 4-gram
    const uint32_t pmask = PACKED ? (ZH_MF_PACK_MAXW - 1) : 0xffffffffu;
 
    // ---- exact trigram order -> previous occurrence of every trigram -------------------------------------------
@@ -318,19 +319,19 @@ __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin,
       }
    }
    __syncthreads();
-   zh_mf_build_runs(win, gwin, W, B, runs, hist, wave_tot);   // B is free again: scratch for the run starts
+   zh_mf_build_runs(win, gwin, W, Qn, B, runs, hist, wave_tot);   // B is free again: scratch for the run starts
 }
 
 template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
-zh_mf_group(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, uint32_t *sort_a,
+zh_mf_group(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs, uint32_t *sort_a,
             uint32_t *sort_b, uint32_t *prev3_all, uint32_t *runs_all, uint64_t sort_stride, uint64_t run_stride, int stop) {
    __shared__ uint32_t hist[ZH_MF_WAVES * 256];
    __shared__ uint32_t wave_tot[ZH_MF_WAVES];
    __shared__ uint32_t lwin32[LDS_WIN ? (ZH_MF_LDS_WINDOW / 4 + 4) : 1];
-   const zh_block_t blk = blocks[blockIdx.x];
+   const zh_seg_t blk = segs[blockIdx.x];
    const uint8_t *win = data + blk.win_off;
-   const uint32_t W = blk.prev + blk.n;
+   const uint32_t W = blk.prev + blk.n + blk.tail;
    uint32_t *A = sort_a + (uint64_t)blockIdx.x * sort_stride;
    uint32_t *B = sort_b + (uint64_t)blockIdx.x * sort_stride;
    uint32_t *prev3 = prev3_all + (uint64_t)blockIdx.x * sort_stride;
@@ -341,9 +342,9 @@ zh_mf_group(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blo
       gwin = (const uint8_t *)lwin32;
    }
    if (W <= ZH_MF_PACK_MAXW)
-      zh_mf_group_body<true>(win, gwin, W, blk.prev, A, B, prev3, runs, hist, wave_tot, stop);
+      zh_mf_group_body<true>(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, runs, hist, wave_tot, stop);
    else
-      zh_mf_group_body<false>(win, gwin, W, blk.prev, A, B, prev3, runs, hist, wave_tot, stop);
+      zh_mf_group_body<false>(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, runs, hist, wave_tot, stop);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -364,22 +365,23 @@ __device__ __forceinline__ uint32_t zh_load32_at(const uint32_t *w32, uint32_t x
 
 template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
-zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
+zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs,
                const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ prev3_all, const uint32_t *__restrict__ runs_all,
                uint64_t sort_stride, uint64_t run_stride, zh_match_t *match, uint64_t match_stride) {
    __shared__ uint32_t next_chunk;
    __shared__ uint32_t lwin32[LDS_WIN ? (ZH_MF_LDS_WINDOW / 4 + 4) : 1];
    __shared__ uint32_t mring[8 * ZH_MF_THREADS];   // per thread: ring of the last 8 accepted matches, [slot][thread]
 
-   const zh_block_t blk = blocks[blockIdx.x];
+   const zh_seg_t blk = segs[blockIdx.x];
    const uint8_t *gwin = data + blk.win_off;
    const uint32_t prev = blk.prev;
-   const uint32_t W = blk.prev + blk.n;
-   const uint32_t M = W >= 4 ? W - 3 : 0;                           // entries of the 4-gram order
+   const uint32_t Qn = blk.prev + blk.n;                             // positions below Qn are candidates / get rows
+   const uint32_t W = Qn + blk.tail;                                 // window incl. look-ahead: match lengths clamp here
+   const uint32_t M = min(Qn, W >= 4 ? W - 3 : 0u);                  // entries of the 4-gram order
    const uint32_t *S = sorted + (uint64_t)blockIdx.x * sort_stride;
    const uint32_t *prev3 = prev3_all + (uint64_t)blockIdx.x * sort_stride;
    const uint32_t *runs = runs_all + (uint64_t)blockIdx.x * run_stride;
-   zh_match_t *rows = match + (uint64_t)blockIdx.x * match_stride;   // row r = block position prev + r
+   zh_match_t *rows = match + (uint64_t)blk.block * match_stride + blk.row_off * ZH_NMATCH;   // row r = segment position prev + r
    const uint32_t lane = threadIdx.x & 63;
    const uint8_t *win = gwin;
 
@@ -394,7 +396,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
    // LCP bounded by the window end); W-3 can only have the length-3 match with the previous occurrence of its trigram.
    if (threadIdx.x < 3 && W >= 1 + threadIdx.x) {
       const uint32_t i = W - 1 - threadIdx.x;
-      if (i >= prev) {
+      if (i >= prev && i < Qn) {
          uint32_t m0 = 0;
          if (threadIdx.x == 2) {
             const uint32_t p3 = prev3[i];
