@@ -186,7 +186,7 @@ def main():
         # the library runs a batch as `runs` staggered runs of max-blocks on separate streams (ZULTRA_HIP_STREAMS, default 2):
         # every kernel is launched once per run (the parse / code-rebuild pair once per pass and run) over 1/runs of the batch
         runs = max(1, min(4, int(os.environ.get("ZULTRA_HIP_STREAMS", "2"))))
-        if nblocks < 64 * runs:
+        if nblocks < 4 * runs or n < (runs << 22):
             runs = 1
         launches = {k: runs for k in kernels}
         launches["zh_parse_tasks"] = launches["zh_sb_build"] = 4 * runs

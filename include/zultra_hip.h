@@ -78,6 +78,11 @@ zultra_hip_ctx_t *zultra_hip_create(int device, uint32_t max_block_size, uint32_
 void zultra_hip_destroy(zultra_hip_ctx_t *ctx);
 const char *zultra_hip_last_error(const zultra_hip_ctx_t *ctx);
 
+/* Pinned host staging owned by the context (which: 0 = input side, 1 = output side), at least `size` bytes, valid until
+ * the context is destroyed or a larger size is requested. The streaming API stages caller data through these: copies
+ * from pageable memory run at a fraction of the PCIe rate. Returns NULL on failure. */
+void *zultra_hip_staging(zultra_hip_ctx_t *ctx, int which, size_t size);
+
 /* Bytes of input the context can hold per batch (max_blocks * max_block_size + 32768 of leading history). */
 size_t zultra_hip_data_capacity(const zultra_hip_ctx_t *ctx);
 

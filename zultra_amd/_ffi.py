@@ -71,7 +71,7 @@ EXPORTS = [
     "zultra_hip_last_timing", "zultra_hip_get_matches", "zultra_hip_get_splits", "zultra_hip_get_parse",
     "zultra_hip_stitch", "zultra_hip_stitch_finish",
     "zultra_hip_stitch_device", "zultra_hip_stream_device", "zultra_hip_stream_read", "zultra_hip_block_crc32", "zultra_crc32_append", "zultra_crc32_append_many",
-    "zultra_hip_create_files", "zultra_hip_compress_files", "zultra_hip_stitch_files",
+    "zultra_hip_create_files", "zultra_hip_compress_files", "zultra_hip_stitch_files", "zultra_hip_staging",
 ]
 
 

@@ -529,8 +529,9 @@ static zultra_status_t stream_init_sized(zultra_stream_t *s, unsigned flags, uns
    const size_t in_size = (size_t)HISTORY_SIZE + (size_t)batch_blocks * bs;
    // worst case per max-block: all sub-blocks stored (libzultra.c:576-587)
    c->out_cap = (size_t)batch_blocks * ((size_t)bs + 6 * 64 + 16) + 16;
-   c->in = (uint8_t *)malloc(in_size);
-   c->out = (uint8_t *)malloc(c->out_cap);
+   // staging lives in pinned memory owned by the (pooled) device context: it survives this stream and is reused by the next
+   c->in = (uint8_t *)zultra_hip_staging(c->hip, 0, in_size);
+   c->out = (uint8_t *)zultra_hip_staging(c->hip, 1, c->out_cap);
    if (!c->in || !c->out) {
       zultra_stream_end(s);
       return ZULTRA_ERROR_MEMORY;
@@ -557,8 +558,7 @@ extern "C" void zultra_stream_end(zultra_stream_t *s) {
    if (s->state && s->zfree) {
       zultra_compressor_t *c = s->state;
       ctx_release(c->hip, c->max_block, c->batch_blocks);
-      free(c->in);
-      free(c->out);
+      /* c->in / c->out belong to the device context */
       c->~zultra_compressor_t();
       s->zfree(s->opaque, c);
       s->state = NULL;

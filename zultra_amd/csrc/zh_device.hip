@@ -81,6 +81,8 @@ struct zultra_hip_ctx_s {
    hipEvent_t lane_ev[4][24];
    hipEvent_t ev_input;
    zh_subblock_t *d_results_compact;
+   uint8_t *h_stage[2];         // pinned staging for callers that hand over pageable host memory (zultra_hip_staging)
+   size_t h_stage_size[2];
    // pinned host mirrors: async copies to pageable memory would block the host and serialise the runs
    uint32_t *h_split_cnt, *h_sub_base, *h_crc;
    zh_subblock_t *h_results;
@@ -263,6 +265,8 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    if (c->ev_input) (void)hipEventDestroy(c->ev_input);
    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
    if (c->graph) (void)hipGraphDestroy(c->graph);
+   for (int k = 0; k < 2; k++)
+      if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
    if (c->h_split_cnt) (void)hipHostFree(c->h_split_cnt);
    if (c->h_sub_base) (void)hipHostFree(c->h_sub_base);
    if (c->h_crc) (void)hipHostFree(c->h_crc);
@@ -382,6 +386,21 @@ extern "C" zultra_hip_ctx_t *zultra_hip_create(int device, uint32_t max_block_si
 extern "C" zultra_hip_ctx_t *zultra_hip_create_files(int device, uint32_t max_file_size, uint32_t max_files) {
    if (max_file_size == 0 || max_file_size >= 8192) return NULL;   // larger inputs can be split: use the block interface
    return zh_create(device, (max_file_size + 63u) & ~63u, max_files, 1);
+}
+
+// Pinned host buffers owned by the context (which = 0: input staging, 1: output staging), grown on demand and kept for
+// the context's lifetime: host<->device copies from pageable memory run at a fraction of the PCIe rate and block the host.
+extern "C" void *zultra_hip_staging(zultra_hip_ctx_t *c, int which, size_t size) {
+   if (!c || which < 0 || which > 1) return NULL;
+   if (c->h_stage_size[which] < size) {
+      if (hipSetDevice(c->device) != hipSuccess) return NULL;
+      if (c->h_stage[which]) (void)hipHostFree(c->h_stage[which]);
+      c->h_stage[which] = NULL;
+      c->h_stage_size[which] = 0;
+      if (hipHostMalloc((void **)&c->h_stage[which], size, 0) != hipSuccess) return NULL;
+      c->h_stage_size[which] = size;
+   }
+   return c->h_stage[which];
 }
 
 extern "C" const char *zultra_hip_last_error(const zultra_hip_ctx_t *c) { return c ? c->err : "no context"; }
@@ -539,7 +558,9 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    // own stream. Max-blocks are independent, every per-block buffer is addressed as base + block * stride, so a run
    // simply sees base pointers advanced to its first block. The single-wave, latency-bound kernels of one run
    // (zh_split, zh_sb_build, ...) then overlap with the wide kernels of the others.
-   const int lanes = (nblocks >= 64u * (uint32_t)c->nlanes) ? c->nlanes : 1;
+   uint64_t batch_bytes = 0;
+   for (uint32_t b = 0; b < nblocks; b++) batch_bytes += blocks[b].n;
+   const int lanes = (nblocks >= 4u * (uint32_t)c->nlanes && batch_bytes >= ((uint64_t)c->nlanes << 22)) ? c->nlanes : 1;
    const int mf_stop = getenv("ZH_MF_STOP") ? atoi(getenv("ZH_MF_STOP")) : 0;   // timing experiments only
    const uint64_t tasks_per_block = c->max_tasks / c->max_blocks;
    hipStream_t st0 = c->lane_stream[0];
