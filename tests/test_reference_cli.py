@@ -1,0 +1,52 @@
+"""The reference's own command-line tool (tool/zultra.c, unmodified) linked against libzultra_amd.so — built by
+`make -C oracle refcli` where /root/reference exists, travels to the GPU box in oracle/_ref/. Link-time: every symbol the
+tool needs is exported with a compatible signature. Run-time (GPU): its round-trip self-test and its guard-byte benchmark
+(tool/zultra.c:465-641, 645-775) pass on the device library."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import corpus
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "oracle", "_ref", "zultra_ref_cli")
+
+
+def _need_cli():
+    if not os.path.exists(CLI):
+        if os.path.isdir("/root/reference/tool") and os.path.exists(os.path.join(ROOT, "zultra_amd", "libzultra_amd.so")):
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "refcli"], check=True)
+        if not os.path.exists(CLI):
+            pytest.skip("oracle/_ref/zultra_ref_cli not built")
+
+
+def test_reference_cli_links_against_the_product_library():
+    _need_cli()
+    out = subprocess.run(["ldd", CLI], capture_output=True, text=True).stdout
+    assert "libzultra_amd.so" in out and "not found" not in out.split("libzultra_amd.so")[1].splitlines()[0]
+    usage = subprocess.run([CLI], capture_output=True, text=True)
+    assert "usage:" in (usage.stdout + usage.stderr)
+
+
+@pytest.mark.gpu
+def test_reference_cli_quick_selftest_on_device():
+    _need_cli()
+    r = subprocess.run([CLI, "-quicktest"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_reference_cli_compress_verify_and_guard_byte_bench(tmp_path, oracle):
+    _need_cli()
+    d = np.concatenate([corpus.text_like(700000, 3), corpus.indented(300000, 4), corpus.noise(70000, 5)])
+    src, dst = tmp_path / "in.bin", tmp_path / "out.gz"
+    src.write_bytes(d.tobytes())
+    # -z compress then -c verify through the tool's own zlib inflate (tool/zultra.c:241-421)
+    r = subprocess.run([CLI, "-c", "-z", str(src), str(dst)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert dst.read_bytes() == oracle.memory_compress(d, 2, 0)       # default 1 MiB max-blocks, gzip: same bytes as the CPU path
+    # -cbench: five timed runs with guard bytes either side of the output buffer (tool/zultra.c:705-753)
+    r = subprocess.run([CLI, "-cbench", str(src), str(dst)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
