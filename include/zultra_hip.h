@@ -160,6 +160,11 @@ int zultra_hip_stitch_files(zultra_hip_ctx_t *ctx, uint64_t *file_off /* blocks 
  * exactly as zultra_frame_update_checksum(crc, block, len, GZIP) would (reference src/frame.c:324-354,473-480). */
 int zultra_hip_block_crc32(const zultra_hip_ctx_t *ctx, uint32_t *out);
 uint32_t zultra_crc32_append(uint32_t crc, uint32_t block_linear_crc, size_t block_len);
+/* Same for zlib framing: out[2b] = sum of the bytes of max-block b, out[2b+1] = sum of (n - i) * byte[i], both mod 65521.
+ * zultra_adler32_append() folds one block into a running Adler-32 exactly as zultra_frame_update_checksum(adler, block,
+ * len, ZLIB) would (reference src/frame.c:74-138). */
+int zultra_hip_block_adler32(const zultra_hip_ctx_t *ctx, uint32_t *out);
+uint32_t zultra_adler32_append(uint32_t adler, uint32_t block_sum, uint32_t block_weighted_sum, size_t block_len);
 uint32_t zultra_crc32_append_many(uint32_t crc, const uint32_t *block_linear_crc, const uint32_t *block_len, uint32_t nblocks);
 
 #ifdef __cplusplus

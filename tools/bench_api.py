@@ -14,7 +14,7 @@ import zultra_amd  # noqa: E402
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 L = zultra_amd.lib()
 d = corpus.text_like_fast(size, 1000)
-for flags, bs in ((2, 65536), (2, 0), (1, 32768)):
+for flags, bs in ((2, 65536), (1, 65536), (0, 65536), (2, 0), (1, 32768)):
     best = None
     for it in range(3):
         t0 = time.perf_counter()

@@ -72,6 +72,7 @@ EXPORTS = [
     "zultra_hip_stitch", "zultra_hip_stitch_finish",
     "zultra_hip_stitch_device", "zultra_hip_stream_device", "zultra_hip_stream_read", "zultra_hip_block_crc32", "zultra_crc32_append", "zultra_crc32_append_many",
     "zultra_hip_create_files", "zultra_hip_compress_files", "zultra_hip_stitch_files", "zultra_hip_staging",
+    "zultra_hip_block_adler32", "zultra_adler32_append",
 ]
 
 

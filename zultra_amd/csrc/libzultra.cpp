@@ -117,6 +117,14 @@ extern "C" uint32_t zultra_crc32_append_many(uint32_t crc, const uint32_t *block
    return crc;
 }
 
+extern "C" uint32_t zultra_adler32_append(uint32_t adler, uint32_t block_sum, uint32_t block_weighted_sum, size_t block_len) {
+   const uint64_t M = 65521;
+   const uint64_t a = adler & 0xffff, b = (adler >> 16) & 0xffff;
+   const uint64_t b2 = (b + (uint64_t)(block_len % M) * a + block_weighted_sum) % M;
+   const uint64_t a2 = (a + block_sum) % M;
+   return (uint32_t)((b2 << 16) | a2);
+}
+
 // Adler-32 (frame.c:74-138): sums modulo 65521, reduced every 5552 bytes.
 static uint32_t adler32_update(uint32_t adler, const uint8_t *p, size_t n) {
    uint32_t a = adler & 0xffff, b = (adler >> 16) & 0xffff;
@@ -478,6 +486,7 @@ struct _zultra_compressor_s {
    std::vector<zultra_hip_block_t> blocks;
    std::vector<uint64_t> raw_off;
    std::vector<uint32_t> crc;
+   std::vector<uint32_t> adler_parts;
    bool host_stitch;            // ZULTRA_HIP_HOST_STITCH=1: stitch on the host (A/B checking)
 };
 
@@ -597,15 +606,16 @@ static zultra_status_t compress_staged(zultra_stream_t *s, zultra_compressor_t *
    int nsubs = zultra_hip_compress_blocks(c->hip, c->in + base, data_size, 0, c->blocks.data(), count);
    if (nsubs <= 0) return ZULTRA_ERROR_COMPRESSION;
 
-   // checksum once per max-block over its bytes (libzultra.c:279): CRC-32 comes from the device, Adler-32 is host work
+   // checksum once per max-block over its bytes (libzultra.c:279): both kinds come from the device, folded here
    if (c->flags & ZULTRA_FLAG_GZIP_FRAMING) {
       c->crc.resize(count);
       if (zultra_hip_block_crc32(c->hip, c->crc.data()) != (int)count) return ZULTRA_ERROR_COMPRESSION;
       for (uint32_t b = 0; b < count; b++) s->adler = zultra_crc32_append(s->adler, c->crc[b], c->blocks[b].n);
    }
    else if (c->flags & ZULTRA_FLAG_ZLIB_FRAMING) {
-      for (uint32_t b = 0; b < count; b++)
-         s->adler = zultra_frame_update_checksum(s->adler, c->in + HISTORY_SIZE + (size_t)b * bs, c->blocks[b].n, c->flags);
+      c->adler_parts.resize(2 * (size_t)count);
+      if (zultra_hip_block_adler32(c->hip, c->adler_parts.data()) != (int)count) return ZULTRA_ERROR_COMPRESSION;
+      for (uint32_t b = 0; b < count; b++) s->adler = zultra_adler32_append(s->adler, c->adler_parts[2 * b], c->adler_parts[2 * b + 1], c->blocks[b].n);
    }
 
    size_t w = 0;

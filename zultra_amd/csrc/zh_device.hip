@@ -89,7 +89,9 @@ struct zultra_hip_ctx_s {
    zh_stitch_item_t *d_items;
    uint32_t *d_stream;        // stitched deflate bits of the last batch
    size_t stream_cap;         // bytes
-   uint32_t *d_crc, *d_crc_tables;
+   uint32_t *d_crc, *d_crc_tables, *d_adler;
+   uint32_t *h_adler;
+   std::vector<uint32_t> adler;
    std::vector<zh_stitch_item_t> items;
    std::vector<uint32_t> crc;
    int payload_on_host;       // lazily copied
@@ -275,6 +277,8 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_items);
    (void)hipFree(c->d_stream);
    (void)hipFree(c->d_crc);
+   (void)hipFree(c->d_adler);
+   if (c->h_adler) (void)hipHostFree(c->h_adler);
    (void)hipFree(c->d_crc_tables);
    if (c->h_payload) (void)hipHostFree(c->h_payload);
    for (int i = 0; i < 8; i++)
@@ -303,6 +307,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_split_cnt, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_sub_base, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_crc, B * sizeof(uint32_t), 0));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_adler, 2 * B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_results, B * c->max_subs * sizeof(zh_subblock_t), 0));
    }
    c->bar_stride = c->tok_stride / 64;
@@ -317,7 +322,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
        zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_split_tok, B * (ZH_MAX_SPLITS + 1)) || zh_alloc(c, &c->d_split_cnt, B) ||
        zh_alloc(c, &c->d_sub_base, B) || zh_alloc(c, &c->d_best, B * c->best_stride) || zh_alloc(c, &c->d_work, B * c->max_subs) ||
        zh_alloc(c, &c->d_results, B * c->max_subs) || zh_alloc(c, &c->d_payload, B * c->slot_stride) ||
-       zh_alloc(c, &c->d_items, B * c->max_subs) || zh_alloc(c, &c->d_crc, B) || zh_alloc(c, &c->d_crc_tables, 256 + 1024))
+       zh_alloc(c, &c->d_items, B * c->max_subs) || zh_alloc(c, &c->d_crc, B) || zh_alloc(c, &c->d_adler, 2 * B) || zh_alloc(c, &c->d_crc_tables, 256 + 1024))
       return -1;
    c->stream_cap = (size_t)(B * (N + 5 * (N / 65535 + 1) + 8) + 64) & ~(size_t)3;
    ZH_CHECK(c, hipMalloc((void **)&c->d_stream, c->stream_cap + 16));
@@ -480,7 +485,8 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    ZH_LAUNCH(zh_emit_tasks, task_grid, 64, st, c->cur_data, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work,
              (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, (const uint32_t *)c->d_best, c->best_stride,
              (const uint32_t *)c->d_task_bits, c->d_payload, c->d_results);
-   ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc);
+   ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc, c->d_adler);
+   ZH_CHECK(c, hipMemcpyAsync(c->h_adler, c->d_adler, 2 * nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
    ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results, nb * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
    ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
    return 0;
@@ -519,6 +525,7 @@ static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
    }
    c->results.assign(c->h_results, c->h_results + nblocks);
    memcpy(c->crc.data(), c->h_crc, nblocks * sizeof(uint32_t));
+   c->adler.assign(c->h_adler, c->h_adler + 2 * (size_t)nblocks);
    c->nsubs = nblocks;
    (void)hipEventElapsedTime(&c->timing.h2d_ms, c->lane_ev[0][0], c->ev_input);
    (void)hipEventElapsedTime(&c->timing.encode_ms, c->lane_ev[0][1], c->lane_ev[0][16]);   // the whole graph
@@ -677,9 +684,10 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 c->d_results + s0);
       ZH_CHECK(c, hipEventRecord(ev[15], st));
       // per-max-block CRC-32 (linear part) for the gzip footer
-      ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0);
+      ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
       ZH_CHECK(c, hipMemcpyAsync(c->h_results + lane_sub0[k], c->d_results + s0, ns * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipMemcpyAsync(c->h_crc + b0, c->d_crc + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipMemcpyAsync(c->h_adler + 2 * (size_t)b0, c->d_adler + 2 * (size_t)b0, 2 * nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipEventRecord(ev[16], st));
    }
    for (int k = 0; k < lanes; k++) ZH_CHECK(c, hipStreamSynchronize(c->lane_stream[k]));
@@ -687,6 +695,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    // sub-block descriptors in batch coordinates
    c->results.assign(c->h_results, c->h_results + nsubs);
    memcpy(c->crc.data(), c->h_crc, nblocks * sizeof(uint32_t));
+   c->adler.assign(c->h_adler, c->h_adler + 2 * (size_t)nblocks);
    for (int k = 0; k < lanes; k++) {
       const uint32_t b0 = (uint32_t)(((uint64_t)nblocks * k) / lanes);
       for (uint32_t i = 0; i < lane_nsubs[k]; i++) {
@@ -739,6 +748,12 @@ extern "C" const uint8_t *zultra_hip_payload(const zultra_hip_ctx_t *cc, size_t 
    }
    if (size) *size = c->payload_size;
    return c->h_payload;
+}
+
+extern "C" int zultra_hip_block_adler32(const zultra_hip_ctx_t *c, uint32_t *out /* 2 per block: A, Bw */) {
+   if (!c || !out) return -1;
+   memcpy(out, c->adler.data(), 2 * (size_t)c->nblocks * sizeof(uint32_t));
+   return (int)c->nblocks;
 }
 
 extern "C" int zultra_hip_block_crc32(const zultra_hip_ctx_t *c, uint32_t *out) {

@@ -159,15 +159,21 @@ zh_stitch(const zh_subblock_t *__restrict__ subs, const zh_stitch_item_t *__rest
 
 // tables: [0..255] byte table of the reflected polynomial 0xEDB88320; [256..1279] four tables of the operator
 // "append ZH_CRC_SLICE zero bytes" applied to a 32-bit state, one per state byte.
+// Also the two sums of Adler-32 (src/frame.c:74-138) per max-block, for zlib framing: A = sum of the bytes and
+// Bw = sum of (n - i) * byte[i], both mod 65521 — appending the block to a running (a, b) is then
+// b += n * a + Bw, a += A (zultra_adler32_append).
+#define ZH_ADLER_MOD 65521u
 __global__ void __launch_bounds__(ZH_CRC_THREADS)
 zh_crc32_blocks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ tables,
-                uint32_t *crc_out) {
+                uint32_t *crc_out, uint32_t *adler_out /* 2 per block */) {
    __shared__ uint32_t T[256 + 1024];
    __shared__ uint32_t part[ZH_CRC_THREADS];
+   __shared__ uint32_t asum[2];
    const zh_block_t blk = blocks[blockIdx.x];
    const uint8_t *p = data + blk.win_off + blk.prev;
    const uint32_t n = blk.n, tid = threadIdx.x;
    for (uint32_t k = tid; k < 256 + 1024; k += ZH_CRC_THREADS) T[k] = tables[k];
+   if (tid < 2) asum[tid] = 0;
    __syncthreads();
 
    // slices are aligned to the END of the block: slice 0 is the short one, all later slices are full
@@ -180,7 +186,17 @@ zh_crc32_blocks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__
       if (sl < nslices) {
          const uint32_t beg = sl == 0 ? 0 : first + (sl - 1) * ZH_CRC_SLICE;
          const uint32_t len = sl == 0 ? first : ZH_CRC_SLICE;
-         for (uint32_t k = 0; k < len; k++) c = (c >> 8) ^ T[(c ^ p[beg + k]) & 0xff];
+         uint32_t s1 = 0, s2 = 0;   // slice sums: bytes, and (len - k) * byte[k]  (< 2^24 for 256-byte slices)
+         for (uint32_t k = 0; k < len; k++) {
+            const uint32_t d = p[beg + k];
+            c = (c >> 8) ^ T[(c ^ d) & 0xff];
+            s1 += d;
+            s2 += (len - k) * d;
+         }
+         // weight of byte k of this slice inside the block = n - (beg + k) = (n - beg - len) + (len - k)
+         const uint64_t after = (uint64_t)(n - beg - len) % ZH_ADLER_MOD;
+         atomicAdd(&asum[0], s1 % ZH_ADLER_MOD);
+         atomicAdd(&asum[1], (uint32_t)((after * (s1 % ZH_ADLER_MOD) + s2) % ZH_ADLER_MOD));
       }
       part[tid] = c;
       __syncthreads();
@@ -194,7 +210,10 @@ zh_crc32_blocks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__
          }
       }
       __syncthreads();
+      if (tid < 2) asum[tid] %= ZH_ADLER_MOD;   // at most 256 addends below 65521 per round: no overflow
+      __syncthreads();
    }
+   if (tid < 2) adler_out[2 * blockIdx.x + tid] = asum[tid];
    // crc_out holds the linear part: CRC(data) with zero initial state and no final inversion; the affine terms
    // (initial 0xFFFFFFFF, final XOR) are applied by the host combine.
    if (tid == 0) crc_out[blockIdx.x] = total;
