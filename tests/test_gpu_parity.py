@@ -54,6 +54,15 @@ def test_stages_vs_oracle(gpu, oracle, case):
     check_window(gpu, oracle, gen(), prev, n, max_block=bs, tag=name)
 
 
+def test_large_max_block_is_cut_into_matchfinder_segments(gpu, oracle):
+    # windows of 20000 + 80000 and 32768 + 200000 bytes exceed the 96 KiB LDS window: two / four segments, all but the last
+    # with 258 bytes of look-ahead; byte runs and ordinary text straddle the cuts
+    d = np.concatenate([corpus.text_like(60000, 31), corpus.indented(25000, 5), corpus.text_like(15000, 32)])
+    check_window(gpu, oracle, d, 20000, 80000, max_block=131072, tag="segments2")
+    d = np.concatenate([corpus.indented(70000, 7), corpus.text_like(100000, 33), corpus.indented(62768, 8)])
+    check_window(gpu, oracle, d, 32768, 200000, max_block=262144, tag="segments4")
+
+
 @pytest.mark.parametrize("name", G.stream_names())
 def test_golden_streams(gpu, name):
     c = G.stream_case(name)
