@@ -1,19 +1,21 @@
 // zh_device.hip — host side of the device layer: context, HBM layout, launches (C ABI of include/zultra_hip.h).
 //
-// HBM layout of one context (B = max_blocks, N = max_block_size, W = N + 32768):
-//   d_data     W + (B-1)*N      input bytes when the caller hands over host memory (read in place otherwise)
-//   d_blocks   B * 16           max-block descriptors
-//   d_sort_a/b B * W * 4  each  window positions grouped by trigram / 4-gram hash (ping-pong of the 2-pass radix sorts)
-//   d_prev3    B * W * 4        previous occurrence of the trigram at every window position
-//   d_match    B * N * 32       match rows, 8 x {u16 length, u16 offset} per block position
-//   d_tok_pos  B * N * 4        greedy token chain: position / packed symbols
-//   d_tok_info B * N * 2
-//   d_best     B * N * 4        final parse per position
-//   d_payload  B * (N + 4224)   per-sub-block bit strings (slot of sub-block k of a block starts at its offset + 64k)
-//   d_bars     B * N / 8        barrier bitmap of every max-block (zh_parse.h)
-//   d_states   B * 64 * 1.4 KB  per-sub-block coder state between the kernels of stage 3
+// HBM layout of one context (B = max_blocks, N = max_block_size; S = matchfinder segments per max-block, 1 up to 64 KiB,
+// Ws = segment window, <= 96 KiB: zh_common.h):
+//   d_data     N + 32768 + (B-1)*N   input bytes when the caller hands over host memory (read in place otherwise)
+//   d_blocks   B * 16                max-block descriptors;  d_segs  B * S * 32  matchfinder segments
+//   d_sort_a/b B * S * Ws * 4  each  window positions in trigram / 4-gram-hash order (ping-pong of the radix sorts)
+//   d_prev3    B * S * Ws * 4        previous occurrence of the trigram at every window position
+//   d_runs     B * S * (Ws + 576) * 4  byte-run table of every segment window
+//   d_match    B * N * 32            match rows, 8 x {u16 length, u16 offset} per block position
+//   d_tok_pos  B * N * 4, d_tok_info B * N * 2   greedy token chain: position / packed symbols
+//   d_bars     B * N / 8             barrier bitmap of every max-block (zh_parse.h)
+//   d_best     B * N * 4             final parse per position
+//   d_payload  B * (N + 4224)        per-sub-block bit strings (slot of sub-block k of a block starts at its offset + 64k)
+//   d_states   B * 64 * 1.4 KB       per-sub-block coder state between the kernels of stage 3 (64 -> 1 in files mode)
 //   d_taskmap, d_hist_part, d_task_bits   per task (T = B * (N / 2048 + 64)): owner, 320-counter histogram, bit count
-//   small: ntok, split boundaries, counts, work items, results
+//   d_stream   B * (N + ...)         stitched deflate bytes of the last batch;  d_crc / d_adler  per max-block checksums
+//   small: ntok, split boundaries, counts, work items, results (+ pinned host mirrors of everything the host reads)
 #include <zh_platform.h>
 
 #include <stdio.h>
