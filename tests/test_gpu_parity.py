@@ -191,3 +191,16 @@ def test_real_data_streams_vs_oracle(gpu, oracle, kind, flags, bs):
         pytest.skip("image files not available")
     got = gpu.memory_compress(d, flags, bs)
     assert got == oracle.memory_compress(d, flags, bs)
+
+
+def test_full_size_properties_mixed_zlib_32k(gpu, oracle):
+    """BASELINE configurations 3 and 4 in spirit: zlib framing with 32 KiB max-blocks over the mixed-entropy corpus (self-test
+    grid segments, noise -> stored sub-blocks, constant runs, text). Inflate round trip with zlib's own Adler-32 check, and a
+    stage-by-stage spot check of a few max-blocks against the oracle."""
+    d = np.concatenate([corpus.mixed(1 << 22, 11 + k) for k in range(4)])   # 16 MiB
+    out = gpu.memory_compress(d, 1, 32768)
+    assert out is not None
+    assert zlib.decompress(out, 15) == d.tobytes()
+    for blk in (1, 100, 333, 511):
+        lo = blk * 32768
+        check_window(gpu, oracle, d[lo - 32768: lo + 32768], 32768, 32768, max_block=32768, tag="mixed_blk%d" % blk)
