@@ -263,6 +263,7 @@ struct uint2 {
 struct uint4 {
    uint32_t x, y, z, w;
 };
+inline uint32_t zh_load_relaxed(const uint32_t *p) { return *(const volatile uint32_t *)p; }
 inline uint32_t zh_atomic_add_lds(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 inline uint32_t zh_atomic_add_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }

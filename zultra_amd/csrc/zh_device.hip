@@ -51,6 +51,7 @@ struct zultra_hip_ctx_s {
    // matchfinder segments (zh_common.h): max-blocks above 64 KiB are cut so that every segment window fits the LDS
    uint32_t seg_n, segs_per_block, seg_W;
    zh_seg_t *d_segs;
+   uint32_t *d_chunk_ctr;       // per segment: {next chunk of the 4-gram order to hand out, workgroups serving it} (zh_mf_frontier)
    std::vector<zh_seg_t> segs;
    std::vector<uint32_t> seg_base;
    zh_match_t *d_match;
@@ -242,6 +243,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_prev3);
    (void)hipFree(c->d_runs);
    (void)hipFree(c->d_segs);
+   (void)hipFree(c->d_chunk_ctr);
    (void)hipFree(c->d_match);
    (void)hipFree(c->d_tok_pos);
    (void)hipFree(c->d_tok_info);
@@ -316,7 +318,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
-       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_ntasks, 4) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block) || zh_alloc(c, &c->d_ntasks, 4) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
@@ -464,8 +466,9 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    const zh_block_t *blk = c->d_blocks;
    ZH_LAUNCH(zh_mf_group<true>, nb, ZH_MF_THREADS, st, c->cur_data, (const zh_seg_t *)c->d_segs, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride,
              c->run_stride, 0);
-   ZH_LAUNCH(zh_mf_frontier<true>, nb, ZH_MF_THREADS, st, c->cur_data, (const zh_seg_t *)c->d_segs, (const uint32_t *)c->d_sort_a, (const uint32_t *)c->d_prev3,
-             (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride);
+   ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr, 0, (size_t)nb * 2 * sizeof(uint32_t), st));
+   ZH_LAUNCH(zh_mf_frontier<true>, nb, ZH_MF_THREADS, st, c->cur_data, (const zh_seg_t *)c->d_segs, (const uint32_t *)c->d_sort_a,
+             (const uint32_t *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
    ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok,
              c->d_bars, c->bar_stride);
    ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
@@ -608,8 +611,9 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_CHECK(c, hipEventRecord(ev[2], st));
       if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
       // (segment descriptors carry batch-wide block indices: the rows go to d_match + block * match_stride)
-      ZH_LAUNCH(zh_mf_frontier<true>, nsg, ZH_MF_THREADS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint32_t *)p3, (const uint32_t *)rn, c->sort_stride,
-                c->run_stride, c->d_match, c->match_stride);
+      ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr + (size_t)sg0 * 2, 0, (size_t)nsg * 2 * sizeof(uint32_t), st));
+      ZH_LAUNCH(zh_mf_frontier<true>, nsg, ZH_MF_THREADS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint32_t *)p3, (const uint32_t *)rn,
+                c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_chunk_ctr + (size_t)sg0 * 2, nsg, 1u);
       ZH_CHECK(c, hipEventRecord(ev[3], st));
       ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)(c->d_match + b0 * c->match_stride), c->match_stride,
                 c->d_tok_pos + b0 * c->tok_stride, c->d_tok_info + b0 * c->tok_stride, c->tok_stride, c->d_ntok + b0, c->d_bars + b0 * c->bar_stride,

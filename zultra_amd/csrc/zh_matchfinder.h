@@ -38,6 +38,10 @@
 
 #define ZH_MF_HASH_BITS 15
 #define ZH_MF_NONE 0xffffffffu       // prev3: no earlier occurrence
+#define ZH_MF_HELP_BEHIND 768u        // zh_mf_frontier: a finished workgroup looks at segments [b-768, b+256) for one to help
+#ifndef ZH_MF_HELP_MIN
+#define ZH_MF_HELP_MIN 32u           // ... and joins only for at least this many 64-entry chunks per workgroup
+#endif
 #define ZH_MF_PACK_SHIFT 17          // packed element: hash << 17 | position (windows of <= 128 Ki positions)
 #define ZH_MF_PACK_MAXW (1u << ZH_MF_PACK_SHIFT)
 
@@ -367,34 +371,44 @@ template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
 zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs,
                const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ prev3_all, const uint32_t *__restrict__ runs_all,
-               uint64_t sort_stride, uint64_t run_stride, zh_match_t *match, uint64_t match_stride) {
-   __shared__ uint32_t next_chunk;
+               uint64_t sort_stride, uint64_t run_stride, zh_match_t *match, uint64_t match_stride, uint32_t *chunk_ctr,
+               uint32_t nsegs, uint32_t steal) {
+   // Workgroup b serves segment b, then helps: on real data a few segments carry several times the average scan work
+   // (measured: 7x on source code), and a workgroup that only did its own would leave the chip waiting for them. Every
+   // segment hands out its 64-entry chunks from a counter in HBM, so any number of workgroups can serve one segment.
    __shared__ uint32_t lwin32[LDS_WIN ? (ZH_MF_LDS_WINDOW / 4 + 4) : 1];
    __shared__ uint32_t mring[8 * ZH_MF_THREADS];   // per thread: ring of the last 8 accepted matches, [slot][thread]
+   __shared__ uint32_t help_key;
+   const uint32_t lane = threadIdx.x & 63;
+   uint32_t seg_id = blockIdx.x;
+   bool owner = true;
 
-   const zh_seg_t blk = segs[blockIdx.x];
+   for (;;) {
+   const zh_seg_t blk = segs[seg_id];
    const uint8_t *gwin = data + blk.win_off;
    const uint32_t prev = blk.prev;
    const uint32_t Qn = blk.prev + blk.n;                             // positions below Qn are candidates / get rows
    const uint32_t W = Qn + blk.tail;                                 // window incl. look-ahead: match lengths clamp here
    const uint32_t M = min(Qn, W >= 4 ? W - 3 : 0u);                  // entries of the 4-gram order
-   const uint32_t *S = sorted + (uint64_t)blockIdx.x * sort_stride;
-   const uint32_t *prev3 = prev3_all + (uint64_t)blockIdx.x * sort_stride;
-   const uint32_t *runs = runs_all + (uint64_t)blockIdx.x * run_stride;
+   const uint32_t *S = sorted + (uint64_t)seg_id * sort_stride;
+   const uint32_t *prev3 = prev3_all + (uint64_t)seg_id * sort_stride;
+   const uint32_t *runs = runs_all + (uint64_t)seg_id * run_stride;
    zh_match_t *rows = match + (uint64_t)blk.block * match_stride + blk.row_off * ZH_NMATCH;   // row r = segment position prev + r
-   const uint32_t lane = threadIdx.x & 63;
    const uint8_t *win = gwin;
 
    if (LDS_WIN) {
       zh_stage_window(lwin32, gwin, W);
       win = (const uint8_t *)lwin32;
    }
-   if (threadIdx.x == 0) next_chunk = 0;
+   if (threadIdx.x == 0) {
+      help_key = 0;
+      atomicAdd(chunk_ctr + 2 * seg_id + 1, 1u);   // workgroups serving this segment
+   }
    __syncthreads();
 
    // The last three window positions are not in the 4-gram order. W-1 and W-2 cannot start a match (matchfinder.c:71:
    // LCP bounded by the window end); W-3 can only have the length-3 match with the previous occurrence of its trigram.
-   if (threadIdx.x < 3 && W >= 1 + threadIdx.x) {
+   if (owner && threadIdx.x < 3 && W >= 1 + threadIdx.x) {
       const uint32_t i = W - 1 - threadIdx.x;
       if (i >= prev && i < Qn) {
          uint32_t m0 = 0;
@@ -415,11 +429,15 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
    // looks at entry c+l-1-k, which is what lane l-1 looked at one step earlier: the candidates travel up the lanes with
    // one DPP wave shift per step and enter at lane 0 from a 64-entry vector fetched with one coalesced load per 64 steps.
    // No per-candidate memory access except the LDS probes.
+   // The counter is a device-scope atomic (it is served memory-side, microseconds away): each wave asks for its next
+   // chunk before it starts on the current one, so the round trip hides behind the scan.
+   uint32_t *ctr = chunk_ctr + 2 * seg_id;
+   uint32_t c_next = 0;
+   if (lane == 0) c_next = atomicAdd(ctr, 64u);
    for (;;) {
-      uint32_t c = 0;
-      if (lane == 0) c = atomicAdd(&next_chunk, 64u);
-      c = zh_readfirstlane(c);
+      const uint32_t c = zh_readfirstlane(c_next);
       if (c >= M) break;
+      if (lane == 0) c_next = atomicAdd(ctr, 64u);
 
       const uint32_t t = c + lane;
       const uint32_t own = t < M ? S[t] : ZH_MF_SENTINEL;
@@ -611,5 +629,30 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
          r[0] = a;
          r[1] = b2;
       }
+   }
+
+   // ---- help: among the segments around this one (workgroups are dispatched in order, so the unfinished ones are near), ----
+   //      join the one with the most chunks left per workgroup already on it — if that is worth staging its window for
+   if (!steal) return;
+   __syncthreads();   // every wave is done with the window in LDS
+   {
+      const uint32_t lo = blockIdx.x > ZH_MF_HELP_BEHIND ? blockIdx.x - ZH_MF_HELP_BEHIND : 0u;
+      const uint32_t sc = lo + threadIdx.x;
+      if (sc < nsegs) {
+         const zh_seg_t o = segs[sc];
+         const uint32_t oQn = o.prev + o.n, oW = oQn + o.tail;
+         const uint32_t oM = min(oQn, oW >= 4 ? oW - 3 : 0u);
+         const uint32_t next = zh_load_relaxed(chunk_ctr + 2 * sc), workers = zh_load_relaxed(chunk_ctr + 2 * sc + 1);
+         const uint32_t left = next < oM ? (oM - next + 63) >> 6 : 0u;
+         const uint32_t score = min(left / (workers + 1), 0x3fffu);
+         if (score >= ZH_MF_HELP_MIN) atomicMax(&help_key, (score << 18) | (((sc * 0x9e3779b1u + blockIdx.x * 0x85ebca6bu) >> 24) << 10) | threadIdx.x);
+      }
+      __syncthreads();
+      const uint32_t key = help_key;
+      if (!key) return;
+      seg_id = lo + (key & 1023u);
+      owner = false;
+      __syncthreads();   // help_key is reset at the top
+   }
    }
 }

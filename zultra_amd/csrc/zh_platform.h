@@ -22,6 +22,8 @@ __device__ __forceinline__ uint32_t zh_shfl(uint32_t v, int src_lane) { return (
 __device__ __forceinline__ uint32_t zh_readlane(uint32_t v, int lane) {
    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
+// a load that sees other workgroups' device-scope atomics (not a stale line of this XCD's L2)
+__device__ __forceinline__ uint32_t zh_load_relaxed(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t zh_readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int zh_popc64(uint64_t m) { return __popcll(m); }
 __device__ __forceinline__ int zh_ctz64(uint64_t m) { return __ffsll((long long)m) - 1; }
