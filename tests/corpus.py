@@ -152,6 +152,26 @@ def indented(size, seed=1):
     return np.frombuffer(bytes(out[:size]), dtype=np.uint8).copy()
 
 
+def duplicated(size, seed=1, edit_gap=400):
+    """Text followed by near-copies of itself (a byte changed every ~edit_gap bytes): long matches at nearly every position,
+    barrier-free runs of thousands of positions — the cooperative phase of the parse (zh_parse.h) with short, 19..39 and
+    long candidates, literals and sub-block ends in the mix."""
+    rs = np.random.RandomState(seed)
+    base = text_like(max(64, size // 3), seed + 100)
+    out = [base]
+    n = len(base)
+    while n < size:
+        c = base.copy()
+        at = int(rs.randint(1, edit_gap))
+        while at < len(c):
+            c[at] = rs.randint(97, 123)
+            at += int(rs.randint(1, 2 * edit_gap))
+        k = int(rs.randint(0, 50))
+        out.append(c[k:])
+        n += len(c) - k
+    return np.concatenate(out)[:size]
+
+
 def mixed(size, seed=1):
     """Segments cycling through the self-test grid plus noise and constant runs (config 4 shape)."""
     rs = np.random.RandomState(seed)
