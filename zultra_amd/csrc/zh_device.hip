@@ -30,6 +30,7 @@
 #include "zh_huffman.h"
 #include "zh_matchfinder.h"
 #include "zh_parse.h"
+#include "zh_parse_huge.h"
 #include "zh_split.h"
 #include "zh_stitch.h"
 
@@ -66,7 +67,8 @@ struct zultra_hip_ctx_s {
    uint64_t bar_stride, max_tasks;
    zh_sbstate_t *d_states;
    uint2 *d_taskmap;
-   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;
+   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: per run [0..3] tasks, [4..7] tasks listed for zh_parse_huge
+   uint32_t *d_hugelist;
    hipEvent_t ev2[16];
    // sub-batch pipelining: a batch runs as up to ZH_MAX_LANES contiguous runs of max-blocks, each on its own stream
    // "files" mode (zultra_hip_create_files): every max-block is a whole small input (< 8192 bytes, so the splitter can
@@ -82,6 +84,8 @@ struct zultra_hip_ctx_s {
    int nlanes;
    hipStream_t lane_stream[4];
    hipEvent_t lane_ev[4][24];
+   hipStream_t side_stream[4];     // per run: zh_parse_huge runs next to zh_parse_tasks
+   hipEvent_t side_ev[4][8];       // per pass: fork, join
    hipEvent_t ev_input;
    zh_subblock_t *d_results_compact;
    uint8_t *h_stage[2];         // pinned staging for callers that hand over pageable host memory (zultra_hip_staging)
@@ -259,6 +263,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_states);
    (void)hipFree(c->d_taskmap);
    (void)hipFree(c->d_ntasks);
+   (void)hipFree(c->d_hugelist);
    (void)hipFree(c->d_hist_part);
    (void)hipFree(c->d_task_bits);
    for (int i = 0; i < 16; i++)
@@ -267,6 +272,9 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
       for (int i = 0; i < 24; i++)
          if (c->lane_ev[k][i]) (void)hipEventDestroy(c->lane_ev[k][i]);
       if (c->lane_stream[k]) (void)hipStreamDestroy(c->lane_stream[k]);
+      for (int i = 0; i < 8; i++)
+         if (c->side_ev[k][i]) (void)hipEventDestroy(c->side_ev[k][i]);
+      if (c->side_stream[k]) (void)hipStreamDestroy(c->side_stream[k]);
    }
    if (c->ev_input) (void)hipEventDestroy(c->ev_input);
    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -305,6 +313,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       for (int k = 0; k < c->nlanes; k++) {
          ZH_CHECK(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
          for (int i = 0; i < 24; i++) ZH_CHECK(c, hipEventCreate(&c->lane_ev[k][i]));
+         ZH_CHECK(c, hipStreamCreateWithFlags(&c->side_stream[k], hipStreamNonBlocking));
+         for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->side_ev[k][i]));
       }
       ZH_CHECK(c, hipEventCreate(&c->ev_input));
       if (zh_alloc(c, &c->d_results_compact, B * c->max_subs)) return -1;
@@ -318,7 +328,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
-       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block) || zh_alloc(c, &c->d_ntasks, 4) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block) || zh_alloc(c, &c->d_ntasks, 8) || zh_alloc(c, &c->d_hugelist, c->max_tasks) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
@@ -472,17 +482,28 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok,
              c->d_bars, c->bar_stride);
    ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 4 * sizeof(uint32_t), st));
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 8 * sizeof(uint32_t), st));
    ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, (size_t)nb * c->slot_stride, st));
    ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)c->d_tok_pos, c->tok_stride, (const uint32_t *)c->d_ntok,
              (const uint32_t *)c->d_split_tok, (const uint32_t *)c->d_split_cnt, (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work, c->d_taskmap,
              c->d_ntasks);
    ZH_LAUNCH(zh_sb_init, nb, 64, st, (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_states);
    const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
+   ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap,
+             (const uint32_t *)c->d_ntasks, c->d_hugelist, c->d_ntasks + 4);
    for (int pass = 0; pass <= 3; pass++) {
+      // the tasks with barrier-free runs (zh_parse_huge: few workgroups, long) next to all the others
+      hipStream_t side = c->side_stream[0];
+      ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass], st));
+      ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[0][2 * pass], 0));
+      ZH_LAUNCH(zh_parse_huge, min(nb, (uint32_t)ZH_HUGE_GRID), ZH_HUGE_THREADS, side, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride,
+                (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_hugelist,
+                (const uint32_t *)(c->d_ntasks + 4), (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride, c->d_hist_part, pass);
+      ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass + 1], side));
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride,
                 (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
                 c->best_stride, c->d_hist_part, pass);
+      ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[0][2 * pass + 1], 0));
       ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)c->d_work, c->d_states, (const uint32_t *)c->d_hist_part, c->d_payload, pass);
    }
    ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work,
@@ -633,7 +654,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    // ---- stage 3 of every run: the sub-block coder, one kernel per step over the run (zh_encode.h) -------------------
    uint32_t nsubs = 0;
    uint32_t lane_sub0[4], lane_nsubs[4];
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 4 * sizeof(uint32_t), st0));
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 8 * sizeof(uint32_t), st0));
    ZH_CHECK(c, hipEventRecord(c->ev2[0], st0));
    for (int k = 0; k < lanes; k++) {
       hipStream_t st = c->lane_stream[k];
@@ -660,6 +681,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       uint2 *taskmap = c->d_taskmap + t0;
       uint32_t *ntasks = c->d_ntasks + k;
       uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM;
+      uint32_t *hugelist = c->d_hugelist + t0;
       uint32_t *task_bits = c->d_task_bits + t0;
       uint8_t *payload = c->d_payload + (uint64_t)b0 * c->slot_stride;
       uint32_t *best = c->d_best + b0 * c->best_stride;
@@ -674,10 +696,21 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)(c->d_ntok + b0), (const uint32_t *)(c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1)),
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
       ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
+      ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)ntasks, hugelist,
+                ntasks + 4);
       ZH_CHECK(c, hipEventRecord(ev[5], st));
       for (int pass = 0; pass <= 3; pass++) {
+         // the tasks with barrier-free runs (zh_parse_huge: few workgroups, long) next to all the others
+         hipStream_t side = c->side_stream[k];
+         ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
+         ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
+         ZH_LAUNCH(zh_parse_huge, ZH_HUGE_GRID, ZH_HUGE_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+                   (const uint2 *)taskmap, (const uint32_t *)hugelist, (const uint32_t *)(ntasks + 4), (const zh_sbstate_t *)states, best, c->best_stride,
+                   hist_part, pass);
+         ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
          ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                    (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass);
+         ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
          ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));
          ZH_LAUNCH(zh_sb_build, ns, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass);
          ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));

@@ -42,7 +42,7 @@
 #endif
 #define ZH_MAXPIECES 64
 #ifndef ZH_COOP_MIN
-#define ZH_COOP_MIN 1536     // pieces longer than this are parsed by three rows together, three positions per step
+#define ZH_COOP_MIN 1536     // a task with a piece longer than this goes to zh_parse_huge (zh_parse_huge.h)
 #endif
 #define ZH_NSYM (ZH_NLIT + ZH_NDIST)
 // Costs are kept modulo 2^16: within the 258 positions a step can look ahead, two costs differ by less than 258 x 15 bits
@@ -91,6 +91,24 @@ __device__ inline uint32_t zh_task_boundary(const uint64_t *bar, uint32_t prev, 
    if (j == 0) return start;
    if (j >= ntasks) return end;
    return prev + zh_first_barrier(bar, start + j * ZH_TASK - prev, end - prev);
+}
+
+// the pieces of task [t0, t1): boundaries bnd[0..np] (LDS, np <= ZH_MAXPIECES), every inner one a barrier
+__device__ inline uint32_t zh_task_pieces(uint32_t *bnd, const uint64_t *bar, uint32_t prev, uint32_t t0, uint32_t t1, uint32_t lane) {
+   uint32_t np = 0;
+   if (t1 > t0) {
+      const uint32_t len = t1 - t0;
+      const uint32_t ps = max((uint32_t)ZH_PIECE, (len + ZH_MAXPIECES - 1) / ZH_MAXPIECES);
+      np = (len + ps - 1) / ps;
+      if (lane < np) bnd[lane] = lane == 0 ? t0 : prev + zh_first_barrier(bar, t0 + lane * ps - prev, t1 - prev);
+      if (lane == 0) bnd[np] = t1;
+   }
+   return np;
+}
+
+// after a wave-level sync: does the task hold a piece of more than ZH_COOP_MIN positions?
+__device__ inline bool zh_task_is_huge(const uint32_t *bnd, uint32_t np, uint32_t lane) {
+   return zh_ballot(lane < np && bnd[lane + 1] - bnd[lane] > ZH_COOP_MIN) != 0;
 }
 
 // ---- forward walk over the chosen parse of [t0, t1): histogram into LDS counters (blockdeflate.c:371-400) ----------
@@ -266,15 +284,11 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
    // ---- task range and its pieces ------------------------------------------------------------------------------
    const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y, wk.ntasks);
    const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
-   uint32_t np = 0;
-   if (t1 > t0) {
-      const uint32_t len = t1 - t0;
-      const uint32_t ps = max((uint32_t)ZH_PIECE, (len + ZH_MAXPIECES - 1) / ZH_MAXPIECES);
-      np = (len + ps - 1) / ps;
-      if (lane < np) ws.bnd[lane] = lane == 0 ? t0 : prev + zh_first_barrier(bar, t0 + lane * ps - prev, t1 - prev);
-      if (lane == 0) ws.bnd[np] = t1;
-   }
+   const uint32_t np = zh_task_pieces(ws.bnd, bar, prev, t0, t1, lane);
    zh_sync();
+   // a barrier-free run of more than ZH_COOP_MIN positions: four independent recurrences are of no use when the task is
+   // (mostly) one run. Such tasks are listed by zh_list_huge and parsed by zh_parse_huge, next to this kernel.
+   if (zh_task_is_huge(ws.bnd, np, lane)) return;
    const uint32_t lc0 = ws.lencost[s], lc1 = ws.lencost[16 + s], lc2 = ws.lencost[32 + (s & 7)];
 
    // ---- row scheduler state (uniform within a row) ---------------------------------------------------------------
@@ -293,12 +307,12 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          const bool need_ = zh_readlane((uint32_t)(p_hi <= p_lo), (int)(r_ * 16)) != 0;                        \
          if (need_) {                                                                                          \
             uint32_t lo_ = 0, hi_ = 0;                                                                         \
-            while (next_piece >= 0 && (hi_ <= lo_ || hi_ > lo_ + ZH_COOP_MIN)) { /* huge pieces: see below */   \
+            while (next_piece >= 0 && hi_ <= lo_) {                                                            \
                lo_ = ws.bnd[next_piece];                                                                       \
                hi_ = ws.bnd[next_piece + 1];                                                                   \
                next_piece--;                                                                                   \
             }                                                                                                  \
-            if (row == r_ && hi_ > lo_ && hi_ <= lo_ + ZH_COOP_MIN) {                                                                      \
+            if (row == r_ && hi_ > lo_) {                                                                      \
                p_lo = lo_;                                                                                     \
                p_hi = hi_;                                                                                     \
                n_top = true;                                                                                   \
@@ -365,86 +379,6 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       zh_sync();
    }
 #undef ZH_NEXT_TILE
-
-   // ================================================================================================================
-   // Huge pieces (barrier-free runs: repeated boilerplate, logs, long matches everywhere). Four independent recurrences
-   // are of no use when a task is one run; instead rows 0..2 price positions p, p-1, p-2 of the SAME run in one step — the
-   // match candidates of all three only read cost[>= p+1] — and the three literal-vs-match decisions chain on the scalar
-   // unit. One shared cost ring; tiles of 48 positions.
-   // ================================================================================================================
-   for (int32_t pi = (int32_t)np - 1; pi >= 0; pi--) {
-      const uint32_t lo = ws.bnd[pi], hi = ws.bnd[pi + 1];
-      if (hi <= lo + ZH_COOP_MIN) continue;
-      uint16_t *ring = ws.ring[0];
-      if (lane == 0) ring[hi & 511] = 0;   // cost[piece end] = 0
-      uint32_t cnext = 0;
-      zh_tile_regs_t cr;
-#define ZH_COOP_FETCH(THI, TLO)                                                                          \
-      do {                                                                                               \
-         const uint32_t idx_ = 3 * s + row;                                                              \
-         const bool ok_ = row < 3 && idx_ < (THI) - (TLO);                                               \
-         const uint32_t pos_ = ok_ ? (THI) - 1 - idx_ : lo;   /* clamped: the loads are always legal */  \
-         const uint4 a_ = rows[(uint64_t)(pos_ - prev) * 2], b_ = rows[(uint64_t)(pos_ - prev) * 2 + 1]; \
-         const uint32_t y_ = win[pos_];                                                                  \
-         cr.a.x = ok_ ? a_.x : 0u; cr.a.y = ok_ ? a_.y : 0u; cr.a.z = ok_ ? a_.z : 0u; cr.a.w = ok_ ? a_.w : 0u;    \
-         cr.b.x = ok_ ? b_.x : 0u; cr.b.y = ok_ ? b_.y : 0u; cr.b.z = ok_ ? b_.z : 0u; cr.b.w = ok_ ? b_.w : 0u;    \
-         cr.byte = y_;                                                                                   \
-      } while (0)
-      {
-         const uint32_t tlo0 = hi > lo + 48 ? hi - 48 : lo;
-         ZH_COOP_FETCH(hi, tlo0);
-      }
-      for (uint32_t thi = hi; thi > lo;) {
-         const uint32_t tlo = thi > lo + 48 ? thi - 48 : lo;
-         const uint32_t cnt = thi - tlo;
-         // lane (row, s) stages the position that row `row` prices at step s
-         zh_stage_position(ws, row, s, cr, sb_end - (thi - 1 - min(3 * s + row, cnt - 1)));
-         zh_sync();
-         if (tlo > lo) {
-            const uint32_t nlo = tlo > lo + 48 ? tlo - 48 : lo;
-            ZH_COOP_FETCH(tlo, nlo);
-         }
-         const uint32_t steps = (cnt + 2) / 3;
-         for (uint32_t t = 0; t < steps; t++) {
-            const uint32_t idx = 3 * t + row;
-            const bool act = row < 3 && idx < cnt;
-            const uint32_t p = act ? thi - 1 - idx : thi - 1 - 3 * t;
-            uint4 R = ws.rec[row][t];
-            if (!act) R.w = 0;
-            const uint32_t base = cnext - ZH_KEY_BIAS;
-            const uint32_t key = zh_lane_key(ws, ring, row, t, R, p, s, base, lc0, lc1, lc2, sb_end);
-            const uint32_t rkey = zh_row_min(key);
-            const uint32_t litv = ZH_REC_LIT(R.w);
-            // literal first; a match must be strictly cheaper (:292,:307); the three decisions chain: cost[p-1] needs cost[p]
-            const uint32_t m0 = zh_readlane(rkey, 0) >> 9, m1 = zh_readlane(rkey, 16) >> 9, m2 = zh_readlane(rkey, 32) >> 9;
-            const uint32_t l0 = zh_readlane(litv, 0) + ZH_KEY_BIAS;
-            const uint32_t c0 = min(l0, m0);
-            const uint32_t l1 = zh_readlane(litv, 16) + c0;
-            const uint32_t c1 = min(l1, m1);
-            const uint32_t l2 = zh_readlane(litv, 32) + c1;
-            const uint32_t c2 = min(l2, m2);
-            const bool act1 = 3 * t + 1 < cnt, act2 = 3 * t + 2 < cnt;
-            if (act && s == 0) {
-               const uint32_t myc = row == 0 ? c0 : (row == 1 ? c1 : c2);
-               const bool take = row == 0 ? (m0 < l0) : (row == 1 ? (m1 < l1) : (m2 < l2));
-               ring[p & 511] = (uint16_t)((base + myc) & 0xffffu);
-               ws.bt[row][t] = take ? rkey : 0xFFFFFFFFu;
-            }
-            cnext = (base + (act2 ? c2 : (act1 ? c1 : c0))) & 0xffffu;
-         }
-         zh_sync();
-         {
-            const uint32_t idx = 3 * s + row;
-            if (row < 3 && idx < cnt) {
-               const uint32_t pos = thi - 1 - idx;
-               best[pos - prev] = zh_decode_pick(ws, row, s, ws.bt[row][s], sb_end - pos);
-            }
-         }
-         zh_sync();
-         thi = tlo;
-      }
-#undef ZH_COOP_FETCH
-   }
 
    // ---- histogram of the task's parse; the per-sub-block sum is taken by zh_sb_build -------------------------------
    if (st->is_dynamic) {

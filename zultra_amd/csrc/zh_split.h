@@ -104,7 +104,9 @@ zh_tokenize(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blo
 // checkpoint" against "the rest". So: the interval statistics are gathered by all waves, every wave then replays the cheap
 // trigger scan, the triggered evaluations (four Huffman length builds and two table costs each — what the kernel's time
 // goes into) are dealt round-robin to the waves, and the reference's selection rule runs over the gains in order.
+#ifndef ZH_SPLIT_WAVES
 #define ZH_SPLIT_WAVES 8
+#endif
 #define ZH_SPLIT_THREADS (64 * ZH_SPLIT_WAVES)
 #define ZH_SPLIT_MAXCP 256   // checkpoints per chunk (a 64 KiB max-block has at most 256)
 
