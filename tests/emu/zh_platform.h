@@ -146,6 +146,9 @@ inline uint64_t collect(uint64_t mine, F combine) {
 }   // namespace zh_emu
 
 #define ZH_LAUNCH(kernel, grid, block, stream, ...) zh_emu::launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)
+#define ZH_LAUNCH_LDS(kernel, grid, block, lds, stream, ...) zh_emu::launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)
+#define ZH_DYN_LDS(name) static uint32_t name[160 * 1024 / 4]
+
 
 inline void __syncthreads() { zh_emu::park(2); }
 inline void zh_sync() { zh_emu::park(2); }
@@ -286,6 +289,12 @@ inline hipError_t hipGetDeviceCount(int *n) {
    return 0;
 }
 inline hipError_t hipSetDevice(int) { return 0; }
+enum { hipDeviceAttributeMultiprocessorCount = 1, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void *, int, int) { return 0; }
+inline hipError_t hipDeviceGetAttribute(int *v, int, int) {
+   *v = 3;   // a grid smaller than most test batches: the ticket loops of the persistent kernels get exercised
+   return 0;
+}
 inline hipError_t hipMalloc(void **p, size_t n) {
    *p = malloc(n ? n : 1);
    return *p ? 0 : 2;

@@ -39,6 +39,7 @@ static_assert(sizeof(zultra_hip_subblock_t) == sizeof(zh_subblock_t), "ABI");
 
 struct zultra_hip_ctx_s {
    int device;
+   uint32_t num_cus;            // persistent kernels launch one workgroup per CU
    uint32_t max_block, max_blocks;
    uint64_t W, sort_stride, match_stride, tok_stride, best_stride, slot_stride;
    size_t data_cap;
@@ -52,7 +53,8 @@ struct zultra_hip_ctx_s {
    // matchfinder segments (zh_common.h): max-blocks above 64 KiB are cut so that every segment window fits the LDS
    uint32_t seg_n, segs_per_block, seg_W;
    zh_seg_t *d_segs;
-   uint32_t *d_chunk_ctr;       // per segment: {next chunk of the 4-gram order to hand out, workgroups serving it} (zh_mf_frontier)
+   uint32_t *d_chunk_ctr;       // per run: per segment {next chunk of the 4-gram order to hand out, workgroups serving it}, then the
+                                // segment tickets of zh_mf_frontier and zh_mf_group
    std::vector<zh_seg_t> segs;
    std::vector<uint32_t> seg_base;
    zh_match_t *d_match;
@@ -302,6 +304,14 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
 static int zh_create_buffers(zultra_hip_ctx_t *c) {
    const uint64_t B = c->max_blocks, N = c->max_block;
    ZH_CHECK(c, hipSetDevice(c->device));
+   {
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || n <= 0) n = 256;
+      c->num_cus = (uint32_t)n;
+      // the matchfinder kernels take all their LDS dynamically (zh_matchfinder.h): more than the 64 KiB default limit
+      ZH_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&zh_mf_group<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ZH_MF_GROUP_LDS));
+      ZH_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&zh_mf_frontier<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ZH_MF_FRONTIER_LDS));
+   }
    ZH_CHECK(c, hipStreamCreate(&c->stream));
    for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->ev[i]));
    for (int i = 0; i < 16; i++) ZH_CHECK(c, hipEventCreate(&c->ev2[i]));
@@ -328,7 +338,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
-       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block) || zh_alloc(c, &c->d_ntasks, 8) || zh_alloc(c, &c->d_hugelist, c->max_tasks) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, 8) || zh_alloc(c, &c->d_hugelist, c->max_tasks) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
@@ -474,10 +484,11 @@ __global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, 
 // first time a (batch size, input pointer) pair is seen and replayed afterwards: one graph launch per batch.
 static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    const zh_block_t *blk = c->d_blocks;
-   ZH_LAUNCH(zh_mf_group<true>, nb, ZH_MF_THREADS, st, c->cur_data, (const zh_seg_t *)c->d_segs, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride,
-             c->run_stride, 0);
-   ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr, 0, (size_t)nb * 2 * sizeof(uint32_t), st));
-   ZH_LAUNCH(zh_mf_frontier<true>, nb, ZH_MF_THREADS, st, c->cur_data, (const zh_seg_t *)c->d_segs, (const uint32_t *)c->d_sort_a,
+   const uint32_t mf_grid = min(nb, c->num_cus);   // persistent workgroups, one per CU (zh_matchfinder.h)
+   ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr, 0, ((size_t)nb * 2 + 2) * sizeof(uint32_t), st));
+   ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)c->d_segs, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride,
+             c->run_stride, 0, nb, c->d_chunk_ctr + (size_t)nb * 2 + 1);
+   ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, (const zh_seg_t *)c->d_segs, (const uint32_t *)c->d_sort_a,
              (const uint32_t *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
    ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok,
              c->d_bars, c->bar_stride);
@@ -628,13 +639,16 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       const zh_seg_t *sgs = c->d_segs + sg0;
       uint32_t *sa = c->d_sort_a + (uint64_t)sg0 * c->sort_stride, *sb = c->d_sort_b + (uint64_t)sg0 * c->sort_stride;
       uint32_t *p3 = c->d_prev3 + (uint64_t)sg0 * c->sort_stride, *rn = c->d_runs + (uint64_t)sg0 * c->run_stride;
-      ZH_LAUNCH(zh_mf_group<true>, nsg, ZH_MF_THREADS, st, c->cur_data, sgs, sa, sb, p3, rn, c->sort_stride, c->run_stride, mf_stop);
+      uint32_t *ctr = c->d_chunk_ctr + (size_t)sg0 * 2 + 2 * (size_t)k;   // this run's counters: 2 per segment + the two tickets
+      const uint32_t mf_grid = min(nsg, c->num_cus);                      // persistent workgroups, one per CU (zh_matchfinder.h)
+      ZH_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nsg * 2 + 2) * sizeof(uint32_t), st));
+      ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, rn, c->sort_stride, c->run_stride, mf_stop, nsg,
+                ctr + (size_t)nsg * 2 + 1);
       ZH_CHECK(c, hipEventRecord(ev[2], st));
       if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
       // (segment descriptors carry batch-wide block indices: the rows go to d_match + block * match_stride)
-      ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr + (size_t)sg0 * 2, 0, (size_t)nsg * 2 * sizeof(uint32_t), st));
-      ZH_LAUNCH(zh_mf_frontier<true>, nsg, ZH_MF_THREADS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint32_t *)p3, (const uint32_t *)rn,
-                c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_chunk_ctr + (size_t)sg0 * 2, nsg, 1u);
+      ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint32_t *)p3, (const uint32_t *)rn,
+                c->sort_stride, c->run_stride, c->d_match, c->match_stride, ctr, nsg, 1u);
       ZH_CHECK(c, hipEventRecord(ev[3], st));
       ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)(c->d_match + b0 * c->match_stride), c->match_stride,
                 c->d_tok_pos + b0 * c->tok_stride, c->d_tok_info + b0 * c->tok_stride, c->tok_stride, c->d_ntok + b0, c->d_bars + b0 * c->bar_stride,

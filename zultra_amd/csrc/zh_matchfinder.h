@@ -38,7 +38,9 @@
 
 #define ZH_MF_HASH_BITS 15
 #define ZH_MF_NONE 0xffffffffu       // prev3: no earlier occurrence
-#define ZH_MF_HELP_BEHIND 768u        // zh_mf_frontier: a finished workgroup looks at segments [b-768, b+256) for one to help
+#define ZH_MF_GROUP_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1) * 4)   // dynamic LDS bytes of zh_mf_group
+#define ZH_MF_FRONTIER_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + 8 * ZH_MF_THREADS + 1) * 4)              // ... of zh_mf_frontier
+#define ZH_MF_HELP_WINDOW 4096u       // zh_mf_frontier: a workgroup out of tickets looks at the last 4096 segments for one to help
 #ifndef ZH_MF_HELP_MIN
 #define ZH_MF_HELP_MIN 32u           // ... and joins only for at least this many 64-entry chunks per workgroup
 #endif
@@ -329,17 +331,33 @@ __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin,
 template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
 zh_mf_group(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs, uint32_t *sort_a,
-            uint32_t *sort_b, uint32_t *prev3_all, uint32_t *runs_all, uint64_t sort_stride, uint64_t run_stride, int stop) {
-   __shared__ uint32_t hist[ZH_MF_WAVES * 256];
-   __shared__ uint32_t wave_tot[ZH_MF_WAVES];
-   __shared__ uint32_t lwin32[LDS_WIN ? (ZH_MF_LDS_WINDOW / 4 + 4) : 1];
-   const zh_seg_t blk = segs[blockIdx.x];
+            uint32_t *sort_b, uint32_t *prev3_all, uint32_t *runs_all, uint64_t sort_stride, uint64_t run_stride, int stop, uint32_t nsegs,
+            uint32_t *ticket) {
+   // All of this kernel's LDS is dynamic (ZH_MF_GROUP_LDS bytes at launch). Measured on gfx950: next to a workgroup with
+   // 128 KiB of STATIC LDS, workgroups of another stream's kernel that use static LDS are not scheduled at all although
+   // they would fit (a 0.3 ms kernel took 6.4 ms); with the allocation made dynamic on either side they run side by side
+   // (tools/probes/corun_probe.hip).
+   ZH_DYN_LDS(dyn_lds);
+   uint32_t *lwin32 = dyn_lds;                                   // ZH_MF_LDS_WINDOW / 4 + 4 words
+   uint32_t *hist = dyn_lds + ZH_MF_LDS_WINDOW / 4 + 4;          // ZH_MF_WAVES x 256
+   uint32_t *wave_tot = hist + ZH_MF_WAVES * 256;                // ZH_MF_WAVES
+   uint32_t &cur_seg = wave_tot[ZH_MF_WAVES];
+   // Persistent workgroups (the host launches one per CU) take segments from a ticket counter. A grid of one workgroup
+   // per segment would keep workgroups of 114 KiB LDS waiting for a CU throughout the kernel, and while such a workgroup
+   // waits the dispatcher holds back the small kernels of the other run's stream (measured: a 0.3 ms kernel took 6.4 ms).
+   for (;;) {
+   __syncthreads();   // the previous segment is done with LDS (and with cur_seg)
+   if (threadIdx.x == 0) cur_seg = atomicAdd(ticket, 1u);
+   __syncthreads();
+   const uint32_t seg = cur_seg;
+   if (seg >= nsegs) return;
+   const zh_seg_t blk = segs[seg];
    const uint8_t *win = data + blk.win_off;
    const uint32_t W = blk.prev + blk.n + blk.tail;
-   uint32_t *A = sort_a + (uint64_t)blockIdx.x * sort_stride;
-   uint32_t *B = sort_b + (uint64_t)blockIdx.x * sort_stride;
-   uint32_t *prev3 = prev3_all + (uint64_t)blockIdx.x * sort_stride;
-   uint32_t *runs = runs_all + (uint64_t)blockIdx.x * run_stride;
+   uint32_t *A = sort_a + (uint64_t)seg * sort_stride;
+   uint32_t *B = sort_b + (uint64_t)seg * sort_stride;
+   uint32_t *prev3 = prev3_all + (uint64_t)seg * sort_stride;
+   uint32_t *runs = runs_all + (uint64_t)seg * run_stride;
    const uint8_t *gwin = win;
    if (LDS_WIN) {
       zh_stage_window(lwin32, win, W);
@@ -349,6 +367,7 @@ zh_mf_group(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs,
       zh_mf_group_body<true>(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, runs, hist, wave_tot, stop);
    else
       zh_mf_group_body<false>(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, runs, hist, wave_tot, stop);
+   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -373,17 +392,52 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
                const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ prev3_all, const uint32_t *__restrict__ runs_all,
                uint64_t sort_stride, uint64_t run_stride, zh_match_t *match, uint64_t match_stride, uint32_t *chunk_ctr,
                uint32_t nsegs, uint32_t steal) {
-   // Workgroup b serves segment b, then helps: on real data a few segments carry several times the average scan work
-   // (measured: 7x on source code), and a workgroup that only did its own would leave the chip waiting for them. Every
-   // segment hands out its 64-entry chunks from a counter in HBM, so any number of workgroups can serve one segment.
-   __shared__ uint32_t lwin32[LDS_WIN ? (ZH_MF_LDS_WINDOW / 4 + 4) : 1];
-   __shared__ uint32_t mring[8 * ZH_MF_THREADS];   // per thread: ring of the last 8 accepted matches, [slot][thread]
-   __shared__ uint32_t help_key;
+   // Persistent workgroups (one per CU, see zh_mf_group) take segments from a ticket counter, then help: on real data a
+   // few segments carry several times the average scan work (measured: 7x on source code), and a workgroup that only did
+   // its own would leave the chip waiting for them. Every segment hands out its 64-entry chunks from a counter in HBM, so
+   // any number of workgroups can serve one segment.
+   ZH_DYN_LDS(dyn_lds);                                            // all dynamic (ZH_MF_FRONTIER_LDS bytes), see zh_mf_group
+   uint32_t *lwin32 = dyn_lds;                                     // ZH_MF_LDS_WINDOW / 4 + 4 words
+   uint32_t *mring = dyn_lds + ZH_MF_LDS_WINDOW / 4 + 4;           // per thread: ring of the last 8 accepted matches, [slot][thread]
+   uint32_t &help_key = mring[8 * ZH_MF_THREADS];
    const uint32_t lane = threadIdx.x & 63;
-   uint32_t seg_id = blockIdx.x;
-   bool owner = true;
+   uint32_t seg_id = 0;
+   bool owner = true, tickets_left = true;
 
    for (;;) {
+   if (tickets_left) {
+      if (threadIdx.x == 0) help_key = atomicAdd(chunk_ctr + 2 * nsegs, 1u);
+      __syncthreads();
+      const uint32_t t = help_key;
+      __syncthreads();
+      if (t < nsegs)
+         seg_id = t;
+      else
+         tickets_left = false;
+   }
+   if (!tickets_left) {
+      // ---- help: every segment has been handed out; join the unfinished one with the most chunks left per workgroup already
+      //      on it — if that is worth staging its window for. The unfinished ones are among the last handed out.
+      if (!steal) return;
+      if (threadIdx.x == 0) help_key = 0;
+      __syncthreads();
+      const uint32_t lo = nsegs > ZH_MF_HELP_WINDOW ? nsegs - ZH_MF_HELP_WINDOW : 0u;
+      for (uint32_t sc = lo + threadIdx.x; sc < nsegs; sc += ZH_MF_THREADS) {
+         const zh_seg_t o = segs[sc];
+         const uint32_t oQn = o.prev + o.n, oW = oQn + o.tail;
+         const uint32_t oM = min(oQn, oW >= 4 ? oW - 3 : 0u);
+         const uint32_t next = zh_load_relaxed(chunk_ctr + 2 * sc), workers = zh_load_relaxed(chunk_ctr + 2 * sc + 1);
+         const uint32_t left = next < oM ? (oM - next + 63) >> 6 : 0u;
+         const uint32_t score = min(left / (workers + 1), 0x3fffu);
+         if (score >= ZH_MF_HELP_MIN) atomicMax(&help_key, (score << 18) | (((sc * 0x9e3779b1u + blockIdx.x * 0x85ebca6bu) >> 26) << 12) | (sc - lo));
+      }
+      __syncthreads();
+      const uint32_t key = help_key;
+      __syncthreads();
+      if (!key) return;
+      seg_id = lo + (key & 4095u);
+      owner = false;
+   }
    const zh_seg_t blk = segs[seg_id];
    const uint8_t *gwin = data + blk.win_off;
    const uint32_t prev = blk.prev;
@@ -631,28 +685,6 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       }
    }
 
-   // ---- help: among the segments around this one (workgroups are dispatched in order, so the unfinished ones are near), ----
-   //      join the one with the most chunks left per workgroup already on it — if that is worth staging its window for
-   if (!steal) return;
    __syncthreads();   // every wave is done with the window in LDS
-   {
-      const uint32_t lo = blockIdx.x > ZH_MF_HELP_BEHIND ? blockIdx.x - ZH_MF_HELP_BEHIND : 0u;
-      const uint32_t sc = lo + threadIdx.x;
-      if (sc < nsegs) {
-         const zh_seg_t o = segs[sc];
-         const uint32_t oQn = o.prev + o.n, oW = oQn + o.tail;
-         const uint32_t oM = min(oQn, oW >= 4 ? oW - 3 : 0u);
-         const uint32_t next = zh_load_relaxed(chunk_ctr + 2 * sc), workers = zh_load_relaxed(chunk_ctr + 2 * sc + 1);
-         const uint32_t left = next < oM ? (oM - next + 63) >> 6 : 0u;
-         const uint32_t score = min(left / (workers + 1), 0x3fffu);
-         if (score >= ZH_MF_HELP_MIN) atomicMax(&help_key, (score << 18) | (((sc * 0x9e3779b1u + blockIdx.x * 0x85ebca6bu) >> 24) << 10) | threadIdx.x);
-      }
-      __syncthreads();
-      const uint32_t key = help_key;
-      if (!key) return;
-      seg_id = lo + (key & 1023u);
-      owner = false;
-      __syncthreads();   // help_key is reset at the top
-   }
    }
 }

@@ -14,6 +14,10 @@
 
 #define ZH_LAUNCH(kernel, grid, block, stream, ...) \
    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (hipStream_t)(stream), __VA_ARGS__)
+// launch with `lds` bytes of dynamic LDS; the kernel declares it with ZH_DYN_LDS(name) and carves its arrays out of it
+#define ZH_LAUNCH_LDS(kernel, grid, block, lds, stream, ...) \
+   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds), (hipStream_t)(stream), __VA_ARGS__)
+#define ZH_DYN_LDS(name) extern __shared__ uint32_t name[]
 
 __device__ __forceinline__ unsigned zh_lane() { return __lane_id(); }
 __device__ __forceinline__ uint64_t zh_ballot(bool p) { return __ballot(p); }
