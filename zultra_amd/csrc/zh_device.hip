@@ -5,7 +5,7 @@
 //   d_data     N + 32768 + (B-1)*N   input bytes when the caller hands over host memory (read in place otherwise)
 //   d_blocks   B * 16                max-block descriptors;  d_segs  B * S * 32  matchfinder segments
 //   d_sort_a/b B * S * Ws * 4  each  window positions in trigram / 4-gram-hash order (ping-pong of the radix sorts)
-//   d_prev3    B * S * Ws * 4        previous occurrence of the trigram at every window position
+//   d_prev3    B * S * Ws * 8        previous occurrence of the trigram, 4-gram and 5-gram at every window position
 //   d_runs     B * S * (Ws + 576) * 4  byte-run table of every segment window
 //   d_match    B * N * 32            match rows, 8 x {u16 length, u16 offset} per block position
 //   d_tok_pos  B * N * 4, d_tok_info B * N * 2   greedy token chain: position / packed symbols
@@ -48,7 +48,8 @@ struct zultra_hip_ctx_s {
 
    uint8_t *d_data;
    zh_block_t *d_blocks;
-   uint32_t *d_sort_a, *d_sort_b, *d_prev3, *d_runs;
+   uint32_t *d_sort_a, *d_sort_b, *d_runs;
+   uint2 *d_prev3;              // per window position: previous trigram occurrence | distances of the previous 4-gram / 5-gram occurrence
    uint64_t run_stride;
    // matchfinder segments (zh_common.h): max-blocks above 64 KiB are cut so that every segment window fits the LDS
    uint32_t seg_n, segs_per_block, seg_W;
@@ -489,7 +490,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)c->d_segs, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride,
              c->run_stride, 0, nb, c->d_chunk_ctr + (size_t)nb * 2 + 1);
    ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, (const zh_seg_t *)c->d_segs, (const uint32_t *)c->d_sort_a,
-             (const uint32_t *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
+             (const uint2 *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
    ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok,
              c->d_bars, c->bar_stride);
    ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
@@ -638,7 +639,8 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       const uint32_t sg0 = c->seg_base[b0], nsg = c->seg_base[b1] - sg0;   // this run's matchfinder segments
       const zh_seg_t *sgs = c->d_segs + sg0;
       uint32_t *sa = c->d_sort_a + (uint64_t)sg0 * c->sort_stride, *sb = c->d_sort_b + (uint64_t)sg0 * c->sort_stride;
-      uint32_t *p3 = c->d_prev3 + (uint64_t)sg0 * c->sort_stride, *rn = c->d_runs + (uint64_t)sg0 * c->run_stride;
+      uint2 *p3 = c->d_prev3 + (uint64_t)sg0 * c->sort_stride;
+      uint32_t *rn = c->d_runs + (uint64_t)sg0 * c->run_stride;
       uint32_t *ctr = c->d_chunk_ctr + (size_t)sg0 * 2 + 2 * (size_t)k;   // this run's counters: 2 per segment + the two tickets
       const uint32_t mf_grid = min(nsg, c->num_cus);                      // persistent workgroups, one per CU (zh_matchfinder.h)
       ZH_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nsg * 2 + 2) * sizeof(uint32_t), st));
@@ -647,7 +649,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_CHECK(c, hipEventRecord(ev[2], st));
       if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
       // (segment descriptors carry batch-wide block indices: the rows go to d_match + block * match_stride)
-      ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint32_t *)p3, (const uint32_t *)rn,
+      ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint2 *)p3, (const uint32_t *)rn,
                 c->sort_stride, c->run_stride, c->d_match, c->match_stride, ctr, nsg, 1u);
       ZH_CHECK(c, hipEventRecord(ev[3], st));
       ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)(c->d_match + b0 * c->match_stride), c->match_stride,

@@ -6,55 +6,52 @@
 // The reference's rows have a closed form: for block position i, scan the earlier window
 // positions p from nearest to farthest; whenever the match length L(p) = min(LCP(i,p), 258, windowEnd-i)
 // is >= 3 and strictly longer than everything seen so far, p is a row entry; entries farther than 32768 are
-// dropped; the 8 longest survive, longest first. No suffix array is needed for that. Two facts bound the work:
+// dropped; the 8 longest survive, longest first. No suffix array is needed for that. Three facts bound the work:
 //   * the nearest entry is the previous occurrence of the trigram at i; it has length exactly 3 unless its 4th byte
-//     matches too;
-//   * every other entry is longer than 3, i.e. an earlier occurrence of the 4-gram at i.
-// So two grouped orders of the window positions are built, each with a stable 2-pass LSD radix sort on a 15-bit
-// multiplicative hash (collisions only add candidates that fail the byte compare):
-//   zh_mf_group    one workgroup per max-block.
-//                  trigram order  -> prev3[pos] = previous occurrence of the same trigram (one array lookup later);
-//                  4-gram order   -> every 4-gram class is a contiguous ascending run: candidate lists are contiguous
-//                                    memory, no pointer chasing (hash chains would serialise on memory latency).
-//                  For windows of <= 128 Ki positions the hash rides in the upper 15 bits of the 32-bit element, so
-//                  only the first pass touches the window bytes (a linear, coalesced read).
-//   zh_mf_frontier waves pull 64-entry chunks of the 4-gram order from a workgroup counter (load balance:
-//                  neighbouring entries belong to the same class and have near-equal candidate counts, so
-//                  the lanes of a wave stay busy together). The scan is wave-synchronous: lane l's k-th candidate is
-//                  lane l-1's (k-1)-th, so the candidate stream is passed up the lanes with one DPP wave shift per
-//                  step and refilled from one coalesced 64-entry load per 64 steps; the window sits in LDS.
+//     matches too. Likewise the previous occurrence of the 4-gram gives the entry of length 4 (unless its 5th byte
+//     matches), the previous occurrence of the 5-gram the entry of length 5;
+//   * every other entry is 6 or longer, i.e. an earlier occurrence of the 6-gram at i: only those need a walk, nearest
+//     first, over the 6-gram class (measured against walking 4-gram classes: 2.3x fewer steps on text, 1.5x on code);
+//   * a position with six or more bytes of a byte run ahead (indentation, padding) has its frontier in closed form from a
+//     table of the window's runs (see "byte runs" below): the class "cccccc" is never walked.
+// The orders are built with exact stable counting passes, digits = bytes:
+//   zh_mf_group    persistent workgroups, one segment (zh_common.h) at a time.
+//                  trigram order (3 passes)      -> prev.x = previous occurrence of the same trigram;
+//                  + one pass on byte 3          -> 4-gram classes, contiguous and ascending in position -> prev4
+//                  + one pass on byte 4          -> 5-gram classes -> prev5
+//                  + one pass on byte 5          -> 6-gram order with class heads marked: candidate lists are contiguous
+//                                                   memory, no pointer chasing (hash chains would serialise on latency).
+//                  Every pass gathers its digit from the window copy in LDS.
+//   zh_mf_frontier waves pull 64-entry chunks of the 6-gram order from a counter in HBM (any number of workgroups can
+//                  serve one segment: finished workgroups help unfinished segments). Neighbouring entries belong to the
+//                  same class and have near-equal candidate counts, so the lanes of a wave stay busy together. The scan is
+//                  wave-synchronous: lane l's k-th candidate is lane l-1's (k-1)-th, so the candidate stream is passed up
+//                  the lanes with one DPP wave shift per step and refilled from one coalesced 64-entry load per 64
+//                  steps; the window sits in LDS.
 //
-// HBM traffic per max-block: window read twice linearly, 4 x 2 x 4 B per window position for the sort ping-pong,
-// 4 B per position for prev3, 32 B per block position for the rows.
+// HBM traffic per segment: window read twice linearly, 6 x 2 x 4 B per window position for the sort ping-pong,
+// 8 B per position for the prev records, 32 B per block position for the rows.
 #pragma once
 #include <zh_platform.h>
 #include "zh_common.h"
 
 #define ZH_MF_THREADS 1024
 #define ZH_MF_WAVES (ZH_MF_THREADS / 64)
-#define ZH_MF_HEAD 0x80000000u       // sorted entry: first position of its trigram class
+#define ZH_MF_HEAD 0x80000000u       // sorted entry: first position of its 6-gram class
 #define ZH_MF_POS_MASK 0x7fffffffu
 #define ZH_MF_SENTINEL 0xffffffffu   // "no entry": marked, and farther than any legal distance
 
-#define ZH_MF_HASH_BITS 15
-#define ZH_MF_NONE 0xffffffffu       // prev3: no earlier occurrence
+#define ZH_MF_NONE 0xffffffffu       // prev.x: no earlier occurrence of the trigram
 #define ZH_MF_GROUP_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1) * 4)   // dynamic LDS bytes of zh_mf_group
 #define ZH_MF_FRONTIER_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + 8 * ZH_MF_THREADS + 1) * 4)              // ... of zh_mf_frontier
 #define ZH_MF_HELP_WINDOW 4096u       // zh_mf_frontier: a workgroup out of tickets looks at the last 4096 segments for one to help
 #ifndef ZH_MF_HELP_MIN
 #define ZH_MF_HELP_MIN 32u           // ... and joins only for at least this many 64-entry chunks per workgroup
 #endif
-#define ZH_MF_PACK_SHIFT 17          // packed element: hash << 17 | position (windows of <= 128 Ki positions)
-#define ZH_MF_PACK_MAXW (1u << ZH_MF_PACK_SHIFT)
 
 // unaligned little-endian loads from global memory
 __device__ __forceinline__ uint32_t zh_ld24(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
 __device__ __forceinline__ uint32_t zh_ld32(const uint8_t *p) { return zh_ld24(p) | ((uint32_t)p[3] << 24); }
-template <int GRAM>
-__device__ __forceinline__ uint32_t zh_mf_hash(const uint8_t *p) {
-   const uint32_t v = GRAM == 3 ? zh_ld24(p) : zh_ld32(p);
-   return (v * 0x9E3779B1u) >> (32 - ZH_MF_HASH_BITS);
-}
 
 // LDS_WIN: the whole window (<= ZH_MF_LDS_WINDOW bytes: 64 KiB max-blocks + 32 KiB history) is staged in LDS once
 // per workgroup with coalesced dword loads, so the scattered byte reads hit the 160 KiB LDS instead of L1/L2.
@@ -77,14 +74,14 @@ __device__ inline void zh_stage_window(uint32_t *lwin32, const uint8_t *gwin, ui
 // zh_mf_group
 // ---------------------------------------------------------------------------------------------------------
 // One stable counting pass over M elements: wave w owns the contiguous slice [w*seg, (w+1)*seg), so element order
-// within a digit is preserved. PASS 0 reads the identity permutation and hashes the window; PASS 1 orders by the high
-// hash bits. hist = ZH_MF_WAVES x 256 counters in LDS.
+// within a digit is preserved. hist = ZH_MF_WAVES x 256 counters in LDS.
 // MODE 0/1/2: the trigram's bytes 2/1/0 are the digits (exact order, three passes, elements are positions);
-// MODE 3/4: low / high byte of the 15-bit 4-gram hash (elements carry the hash when PACKED).
-// Modes 0 and 3 read the identity permutation and the window linearly (win); the others gather through gwin.
-template <int MODE, bool PACKED>
+// MODE 5/6/7: byte 3/4/5 of the string at the position: a stable pass over the k-gram order gives the (k+1)-gram classes,
+// contiguous and ascending in position (the classes come out ordered by their last byte first, which nobody minds).
+// Mode 0 reads the identity permutation and the window linearly (win); the others gather through gwin.
+template <int MODE>
 __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, uint32_t M, const uint32_t *src, uint32_t *dst, uint32_t *hist,
-                                       uint32_t *wave_tot) {
+                                       uint32_t *wave_tot, uint32_t W = 0) {
    const uint32_t tid = threadIdx.x;
    const uint32_t lane = tid & 63, wave = tid >> 6;
    const uint32_t seg = (((M + ZH_MF_WAVES - 1) / ZH_MF_WAVES) + 63) & ~63u;
@@ -106,14 +103,9 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
          e = src[idx];                                                                              \
          d = gwin[e + (MODE == 1 ? 1 : 0)];                                                         \
       }                                                                                             \
-      else if (MODE == 3) {                                                                         \
-         const uint32_t h_ = zh_mf_hash<4>(win + (idx));                                            \
-         e = PACKED ? ((h_ << ZH_MF_PACK_SHIFT) | (idx)) : (idx);                                   \
-         d = h_ & 0xffu;                                                                            \
-      }                                                                                             \
-      else {                                                                                        \
+      else { /* MODE 5/6/7: byte 3/4/5 of the string at e; strings that end before it are dropped */ \
          e = src[idx];                                                                              \
-         d = (PACKED ? (e >> ZH_MF_PACK_SHIFT) : zh_mf_hash<4>(gwin + e)) >> 8;                     \
+         d = (e + (MODE - 2) < W) ? (uint32_t)gwin[e + (MODE - 2)] : 0xffffffffu;                   \
       }                                                                                             \
    } while (0)
 
@@ -162,14 +154,14 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
       for (uint32_t u = 0; u < 4; u++) {
          const uint32_t idx = base4 + u * 64 + lane;
          e4[u] = 0;
-         d4[u] = 0;
+         d4[u] = 0xffffffffu;
          if (idx < hi) ZH_MF_FETCH(idx, e4[u], d4[u]);
       }
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
          const uint32_t idx = base4 + u * 64 + lane;
-         const bool valid = idx < hi;
          const uint32_t e = e4[u], d = d4[u];
+         const bool valid = idx < hi && d != 0xffffffffu;
          const uint32_t slot = valid ? hist[wave * 256 + d] : 0;
          uint64_t peers = zh_ballot(valid);
          for (int bit = 0; bit < 8; bit++) {
@@ -241,7 +233,7 @@ __device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin,
 #undef ZH_IS_RUN_START
    __threadfence_block();
    __syncthreads();
-   zh_mf_sort_pass<2, false>(win, gwin, total, T, RS, hist, wave_tot);   // stable by byte value: digit = gwin[start]
+   zh_mf_sort_pass<2>(win, gwin, total, T, RS, hist, wave_tot);   // stable by byte value: digit = gwin[start]
    for (uint32_t idx = tid; idx < total; idx += ZH_MF_THREADS) {
       const uint32_t q = RS[idx];
       const uint32_t c = gwin[q];
@@ -252,27 +244,50 @@ __device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin,
    if (tid == 0) *count = total;
 }
 
+// X = the K-gram order (MK entries, K = 4 or 5): prev[pos].y half K-4 = distance - 1 to the nearest earlier position
+// sharing K bytes, or 0xffff if there is none within ZH_MAX_DIST. Only block positions need it.
+template <int K>
+__device__ inline void zh_mf_prev_level(const uint32_t *__restrict__ X, uint32_t MK, const uint8_t *gwin, uint32_t first_needed, uint2 *__restrict__ prev) {
+   for (uint32_t idx0 = threadIdx.x; idx0 < MK; idx0 += 4 * ZH_MF_THREADS) {
+      uint32_t pos[4], q[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+         const uint32_t idx = idx0 + u * ZH_MF_THREADS;
+         pos[u] = idx < MK ? X[idx] : 0u;
+         q[u] = (idx < MK && idx > 0) ? X[idx - 1] : ZH_MF_NONE;
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+         const uint32_t idx = idx0 + u * ZH_MF_THREADS;
+         if (idx < MK && pos[u] >= first_needed) {
+            const bool same = q[u] != ZH_MF_NONE && zh_ld32(gwin + q[u]) == zh_ld32(gwin + pos[u]) && (K == 4 || gwin[q[u] + 4] == gwin[pos[u] + 4]);
+            const uint32_t d = pos[u] - q[u];   // classes ascend in position
+            ((uint16_t *)&prev[pos[u]].y)[K - 4] = (same && d <= ZH_MAX_DIST) ? (uint16_t)(d - 1) : (uint16_t)0xffffu;
+         }
+      }
+   }
+   __syncthreads();
+}
+
 // `win` is read linearly (global memory); `gwin` is the copy used for scattered reads (LDS when the window fits)
-template <bool PACKED>
 __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin, uint32_t W, uint32_t Qn, uint32_t first_needed, uint32_t *A, uint32_t *B,
-                                        uint32_t *prev3, uint32_t *runs, uint32_t *hist, uint32_t *wave_tot, int stop) {
+                                        uint2 *prev, uint32_t *runs, uint32_t *hist, uint32_t *wave_tot, int stop) {
    const uint32_t tid = threadIdx.x;
    // W = window bytes, Qn = positions that are candidates or get rows (the rest of the window is look-ahead)
    const uint32_t M3 = min(Qn, W >= 3 ? W - 2 : 0u);   // positions that start a trigram
    const uint32_t M4 = min(Qn, W >= 4 ? W - 3 : 0u);   // positions that start a 4-gram
-   const uint32_t pmask = PACKED ? (ZH_MF_PACK_MAXW - 1) : 0xffffffffu;
 
    // ---- exact trigram order -> previous occurrence of every trigram -------------------------------------------
    if (stop == 1) return;
-   zh_mf_sort_pass<0, PACKED>(win, gwin, M3, nullptr, A, hist, wave_tot);
+   zh_mf_sort_pass<0>(win, gwin, M3, nullptr, A, hist, wave_tot);
    if (stop == 2) return;
-   zh_mf_sort_pass<1, PACKED>(win, gwin, M3, A, B, hist, wave_tot);
-   zh_mf_sort_pass<2, PACKED>(win, gwin, M3, B, A, hist, wave_tot);
+   zh_mf_sort_pass<1>(win, gwin, M3, A, B, hist, wave_tot);
+   zh_mf_sort_pass<2>(win, gwin, M3, B, A, hist, wave_tot);
    if (stop == 3) return;
    {
       // only block positions need it (history positions get no rows); four entries per thread keep the loads overlapped
       const uint32_t *__restrict__ Ar = A;
-      uint32_t *__restrict__ P3 = prev3;
+      uint2 *__restrict__ P3 = prev;
       for (uint32_t idx0 = tid; idx0 < M3; idx0 += 4 * ZH_MF_THREADS) {
          uint32_t pos[4], q[4];
 #pragma unroll
@@ -287,7 +302,7 @@ __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin,
             if (idx < M3 && pos[u] >= first_needed) {
                // same class => the nearest earlier occurrence (classes ascend in position)
                const bool same = q[u] != ZH_MF_NONE && zh_ld24(gwin + q[u]) == zh_ld24(gwin + pos[u]);
-               P3[pos[u]] = same ? q[u] : ZH_MF_NONE;
+               P3[pos[u]].x = same ? q[u] : ZH_MF_NONE;
             }
          }
       }
@@ -295,31 +310,35 @@ __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin,
    __syncthreads();
    if (stop == 4) return;
 
-   // ---- 4-gram order, class heads marked -------------------------------------------------------------------------
-   zh_mf_sort_pass<3, PACKED>(win, gwin, M4, nullptr, A, hist, wave_tot);
-   zh_mf_sort_pass<4, PACKED>(win, gwin, M4, A, B, hist, wave_tot);
+   // ---- 4-, 5- and 6-gram classes: one more stable pass each over the previous order ------------------------------
+   // prev4 / prev5 (nearest earlier position sharing 4 / 5 bytes) give the records of length 4 and 5 directly; only
+   // matches of 6 and more are found by walking a class, and 6-gram classes are several times smaller than 4-gram
+   // classes (on text the walk shrinks 2.3x, on source code 1.5x).
+   const uint32_t M5 = min(Qn, W >= 5 ? W - 4 : 0u), M6 = min(Qn, W >= 6 ? W - 5 : 0u);
+   zh_mf_sort_pass<5>(win, gwin, M3, A, B, hist, wave_tot, W);   // B: 4-gram order, M4 entries
+   zh_mf_prev_level<4>(B, M4, gwin, first_needed, prev);
+   zh_mf_sort_pass<6>(win, gwin, M4, B, A, hist, wave_tot, W);   // A: 5-gram order, M5 entries
+   zh_mf_prev_level<5>(A, M5, gwin, first_needed, prev);
+   zh_mf_sort_pass<7>(win, gwin, M5, A, B, hist, wave_tot, W);   // B: 6-gram order, M6 entries
    if (stop == 5) return;
    {
       const uint32_t *__restrict__ Br = B;
       uint32_t *__restrict__ Aw = A;
-      for (uint32_t idx0 = tid; idx0 < M4; idx0 += 4 * ZH_MF_THREADS) {
+      for (uint32_t idx0 = tid; idx0 < M6; idx0 += 4 * ZH_MF_THREADS) {
          uint32_t e[4], eq[4];
 #pragma unroll
          for (uint32_t u = 0; u < 4; u++) {
             const uint32_t idx = idx0 + u * ZH_MF_THREADS;
-            e[u] = idx < M4 ? Br[idx] : 0u;
-            eq[u] = (idx < M4 && idx > 0) ? Br[idx - 1] : 0u;
+            e[u] = idx < M6 ? Br[idx] : 0u;
+            eq[u] = (idx < M6 && idx > 0) ? Br[idx - 1] : 0u;
          }
 #pragma unroll
          for (uint32_t u = 0; u < 4; u++) {
             const uint32_t idx = idx0 + u * ZH_MF_THREADS;
-            if (idx < M4) {
-               const uint32_t pos = e[u] & pmask;
-               bool head = idx == 0;
-               if (!head)
-                  head = PACKED ? ((eq[u] >> ZH_MF_PACK_SHIFT) != (e[u] >> ZH_MF_PACK_SHIFT))
-                                : (zh_mf_hash<4>(gwin + (eq[u] & pmask)) != zh_mf_hash<4>(gwin + pos));
-               Aw[idx] = pos | (head ? ZH_MF_HEAD : 0u);   // the scan stops after consuming a marked entry
+            if (idx < M6) {
+               const bool head = idx == 0 || zh_ld32(gwin + eq[u]) != zh_ld32(gwin + e[u]) ||
+                                 (((uint32_t)gwin[eq[u] + 4] | ((uint32_t)gwin[eq[u] + 5] << 8)) != ((uint32_t)gwin[e[u] + 4] | ((uint32_t)gwin[e[u] + 5] << 8)));
+               Aw[idx] = e[u] | (head ? ZH_MF_HEAD : 0u);   // the scan stops after consuming a marked entry
             }
          }
       }
@@ -331,7 +350,7 @@ __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin,
 template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
 zh_mf_group(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs, uint32_t *sort_a,
-            uint32_t *sort_b, uint32_t *prev3_all, uint32_t *runs_all, uint64_t sort_stride, uint64_t run_stride, int stop, uint32_t nsegs,
+            uint32_t *sort_b, uint2 *prev_all, uint32_t *runs_all, uint64_t sort_stride, uint64_t run_stride, int stop, uint32_t nsegs,
             uint32_t *ticket) {
    // All of this kernel's LDS is dynamic (ZH_MF_GROUP_LDS bytes at launch). Measured on gfx950: next to a workgroup with
    // 128 KiB of STATIC LDS, workgroups of another stream's kernel that use static LDS are not scheduled at all although
@@ -356,17 +375,14 @@ zh_mf_group(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs,
    const uint32_t W = blk.prev + blk.n + blk.tail;
    uint32_t *A = sort_a + (uint64_t)seg * sort_stride;
    uint32_t *B = sort_b + (uint64_t)seg * sort_stride;
-   uint32_t *prev3 = prev3_all + (uint64_t)seg * sort_stride;
+   uint2 *prev3 = prev_all + (uint64_t)seg * sort_stride;
    uint32_t *runs = runs_all + (uint64_t)seg * run_stride;
    const uint8_t *gwin = win;
    if (LDS_WIN) {
       zh_stage_window(lwin32, win, W);
       gwin = (const uint8_t *)lwin32;
    }
-   if (W <= ZH_MF_PACK_MAXW)
-      zh_mf_group_body<true>(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, runs, hist, wave_tot, stop);
-   else
-      zh_mf_group_body<false>(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, runs, hist, wave_tot, stop);
+   zh_mf_group_body(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, runs, hist, wave_tot, stop);
    }
 }
 
@@ -389,7 +405,7 @@ __device__ __forceinline__ uint32_t zh_load32_at(const uint32_t *w32, uint32_t x
 template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
 zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs,
-               const uint32_t *__restrict__ sorted, const uint32_t *__restrict__ prev3_all, const uint32_t *__restrict__ runs_all,
+               const uint32_t *__restrict__ sorted, const uint2 *__restrict__ prev_all, const uint32_t *__restrict__ runs_all,
                uint64_t sort_stride, uint64_t run_stride, zh_match_t *match, uint64_t match_stride, uint32_t *chunk_ctr,
                uint32_t nsegs, uint32_t steal) {
    // Persistent workgroups (one per CU, see zh_mf_group) take segments from a ticket counter, then help: on real data a
@@ -425,9 +441,12 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       for (uint32_t sc = lo + threadIdx.x; sc < nsegs; sc += ZH_MF_THREADS) {
          const zh_seg_t o = segs[sc];
          const uint32_t oQn = o.prev + o.n, oW = oQn + o.tail;
-         const uint32_t oM = min(oQn, oW >= 4 ? oW - 3 : 0u);
+         const uint32_t oM = min(oQn, oW >= 6 ? oW - 5 : 0u);
+         const uint32_t ochunks = (oM + 63) >> 6;
+         uint32_t opow = 1;
+         while (opow < ochunks) opow <<= 1;   // tickets run to the next power of two (see below)
          const uint32_t next = zh_load_relaxed(chunk_ctr + 2 * sc), workers = zh_load_relaxed(chunk_ctr + 2 * sc + 1);
-         const uint32_t left = next < oM ? (oM - next + 63) >> 6 : 0u;
+         const uint32_t left = next < opow * 64u ? (((opow * 64u - next) >> 6) * ochunks) / opow : 0u;
          const uint32_t score = min(left / (workers + 1), 0x3fffu);
          if (score >= ZH_MF_HELP_MIN) atomicMax(&help_key, (score << 18) | (((sc * 0x9e3779b1u + blockIdx.x * 0x85ebca6bu) >> 26) << 12) | (sc - lo));
       }
@@ -443,9 +462,9 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
    const uint32_t prev = blk.prev;
    const uint32_t Qn = blk.prev + blk.n;                             // positions below Qn are candidates / get rows
    const uint32_t W = Qn + blk.tail;                                 // window incl. look-ahead: match lengths clamp here
-   const uint32_t M = min(Qn, W >= 4 ? W - 3 : 0u);                  // entries of the 4-gram order
+   const uint32_t M = min(Qn, W >= 6 ? W - 5 : 0u);                  // entries of the 6-gram order
    const uint32_t *S = sorted + (uint64_t)seg_id * sort_stride;
-   const uint32_t *prev3 = prev3_all + (uint64_t)seg_id * sort_stride;
+   const uint2 *prevs = prev_all + (uint64_t)seg_id * sort_stride;   // x: previous trigram occurrence, y: distances of prev4 | prev5
    const uint32_t *runs = runs_all + (uint64_t)seg_id * run_stride;
    zh_match_t *rows = match + (uint64_t)blk.block * match_stride + blk.row_off * ZH_NMATCH;   // row r = segment position prev + r
    const uint8_t *win = gwin;
@@ -460,19 +479,30 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
    }
    __syncthreads();
 
-   // The last three window positions are not in the 4-gram order. W-1 and W-2 cannot start a match (matchfinder.c:71:
-   // LCP bounded by the window end); W-3 can only have the length-3 match with the previous occurrence of its trigram.
-   if (owner && threadIdx.x < 3 && W >= 1 + threadIdx.x) {
-      const uint32_t i = W - 1 - threadIdx.x;
+   // The last five window positions are not in the 6-gram order: their matches cannot be longer than the bytes left, so
+   // the nearest earlier occurrences of their 3-, 4- and 5-grams are their whole frontier (matchfinder.c:71: LCP bounded
+   // by the window end; W-1 and W-2 cannot start a match).
+   if (owner && threadIdx.x < 5 && W >= 1 + threadIdx.x) {
+      const uint32_t i = W - 1 - threadIdx.x, maxlen = threadIdx.x + 1;
       if (i >= prev && i < Qn) {
-         uint32_t m0 = 0;
-         if (threadIdx.x == 2) {
-            const uint32_t p3 = prev3[i];
-            if (p3 != ZH_MF_NONE && i - p3 <= ZH_MAX_DIST) m0 = ZH_MIN_MATCH | ((i - p3) << 16);
+         uint32_t m[3] = {0, 0, 0}, n = 0;
+         if (maxlen >= 3) {
+            const uint2 pv = prevs[i];
+            if (pv.x != ZH_MF_NONE && i - pv.x <= ZH_MAX_DIST) {
+               if (maxlen == 3 || gwin[pv.x + 3] != gwin[i + 3]) m[n++] = 3u | ((i - pv.x) << 16);
+               const uint32_t d4 = pv.y & 0xffffu, d5 = pv.y >> 16;
+               if (maxlen >= 4 && d4 != 0xffffu) {
+                  if (maxlen == 4 || gwin[i - 1 - d4 + 4] != gwin[i + 4]) m[n++] = 4u | ((d4 + 1) << 16);
+                  if (maxlen >= 5 && d5 != 0xffffu) m[n++] = 5u | ((d5 + 1) << 16);
+               }
+            }
          }
          uint4 *r = (uint4 *)(rows + (uint64_t)(i - prev) * ZH_NMATCH);
          uint4 a, z;
-         a.x = m0; a.y = 0; a.z = 0; a.w = 0;
+         a.x = n > 0 ? m[n - 1] : 0u;   // rows are longest first
+         a.y = n > 1 ? m[n - 2] : 0u;
+         a.z = n > 2 ? m[n - 3] : 0u;
+         a.w = 0;
          z.x = 0; z.y = 0; z.z = 0; z.w = 0;
          r[0] = a;
          r[1] = z;
@@ -486,12 +516,21 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
    // The counter is a device-scope atomic (it is served memory-side, microseconds away): each wave asks for its next
    // chunk before it starts on the current one, so the round trip hides behind the scan.
    uint32_t *ctr = chunk_ctr + 2 * seg_id;
+   // Chunks are handed out in a scattered order (ticket -> chunk is a bijection on the next power of two): the 6-gram
+   // order is sorted by bytes, so the expensive classes (common words) sit next to each other, and in ticket order
+   // they would all be met at the same time — or all at the end.
+   const uint32_t nchunks = (M + 63) >> 6;
+   uint32_t cmask = 1;
+   while (cmask < nchunks) cmask <<= 1;
+   cmask -= 1;
    uint32_t c_next = 0;
    if (lane == 0) c_next = atomicAdd(ctr, 64u);
    for (;;) {
-      const uint32_t c = zh_readfirstlane(c_next);
-      if (c >= M) break;
+      const uint32_t ticket = zh_readfirstlane(c_next);
+      if (ticket >= (cmask + 1) * 64u) break;
       if (lane == 0) c_next = atomicAdd(ctr, 64u);
+      const uint32_t c = ((((ticket >> 6) * 40503u + 12345u) & cmask)) << 6;
+      if (c >= M) continue;
 
       const uint32_t t = c + lane;
       const uint32_t own = t < M ? S[t] : ZH_MF_SENTINEL;
@@ -503,12 +542,17 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       uint32_t cur = ZH_MIN_MATCH - 1;
       bool alive = false;
       const uint32_t first4 = mine ? (LDS_WIN ? zh_load32_at(lwin32, i) : zh_ld32(win + i)) : 0;
+      bool has4 = false;
+      uint32_t d4 = 0xffffu, d5 = 0xffffu;
       if (mine) {
          // nearest occurrence of the trigram: without it there is no match at all; if its 4th byte differs it is the
-         // (only) length-3 entry, otherwise it is the first member of the 4-gram class met below
-         const uint32_t p3 = prev3[i];
+         // (only) length-3 entry. Likewise the nearest occurrences of the 4-gram and the 5-gram.
+         const uint2 pv = prevs[i];
+         const uint32_t p3 = pv.x;
          if (p3 != ZH_MF_NONE && i - p3 <= ZH_MAX_DIST) {
-            alive = !(own & ZH_MF_HEAD);   // a class head has no earlier 4-gram occurrence
+            d4 = pv.y & 0xffffu;
+            d5 = pv.y >> 16;
+            has4 = d4 != 0xffffu;
             const uint32_t q4 = LDS_WIN ? zh_load32_at(lwin32, p3) : zh_ld32(win + p3);
             if (q4 != first4) {
                myring[0] = ZH_MIN_MATCH | ((i - p3) << 16);
@@ -517,8 +561,28 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
             }
          }
       }
-      // ---- positions inside a byte run: the class "cccc" is not scanned; the frontier comes from the run table --------
-      if (mine && alive && first4 == (first4 & 0xffu) * 0x01010101u) {
+      // six equal bytes: the class "cccccc" is not walked, the run table below gives the frontier. (A run that ends within
+      // five bytes is an ordinary string: its 6-gram class is walked like any other; taking the run path for it would
+      // put a few slow lanes into every chunk of indented text.)
+      const bool isrun = first4 == (first4 & 0xffu) * 0x01010101u && mine && win[i + 4] == (first4 & 0xffu) && win[i + 5] == (first4 & 0xffu);
+      if (mine && has4 && !isrun) {
+         // (every position of the 6-gram order has at least 6 bytes left)
+         if (win[i - 1 - d4 + 4] != win[i + 4]) {
+            myring[(nm & 7u) * ZH_MF_THREADS] = 4u | ((d4 + 1) << 16);
+            nm++;
+            cur = 4;
+         }
+         if (d5 != 0xffffu) {
+            if (win[i - 1 - d5 + 5] != win[i + 5]) {
+               myring[(nm & 7u) * ZH_MF_THREADS] = 5u | ((d5 + 1) << 16);
+               nm++;
+               cur = 5;
+            }
+            alive = !(own & ZH_MF_HEAD);   // a class head has no earlier occurrence of its 6-gram
+         }
+      }
+      // ---- positions with six or more bytes of a byte run ahead: the frontier comes from the run table -----------------
+      if (mine && has4 && isrun) {
          alive = false;
          const uint32_t c = first4 & 0xffu;
          const uint32_t r = LDS_WIN ? zh_run_length(win, i, W, maxlen) : zh_run_length(gwin, i, W, maxlen);   // run bytes left, clamped to maxlen
@@ -601,9 +665,9 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
          }
       }
       // what a candidate must match to beat `cur`: the four bytes ending at position max(cur, 3) — for cur <= 3 that is
-      // the 4-gram itself (class membership; hash collisions fail here)
+      // a window inside the first six bytes, which every member of the class shares
       uint32_t fo = max(cur, 3u) - 3u;
-      uint32_t ci = first4;
+      uint32_t ci = (mine && fo) ? (LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo)) : first4;
 
       uint32_t cand = own;
       int64_t vbase = (int64_t)c - 64;                            // sorted index of lane 0 of the feed vector
@@ -611,8 +675,8 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       int vi = 63;
 
       // A candidate can only beat `cur` if its bytes fo..fo+3 equal ci; one LDS byte probe (the last of the four) weeds out
-      // most, the 4-byte probe nearly all of the rest, the survivors get their true match length from byte 0 (a hash
-      // collision, or an entry of a neighbouring class met after the class head, fails there). Both probes of an
+      // most, the 4-byte probe nearly all of the rest, the survivors get their true match length from byte 0 (an
+      // entry of a neighbouring class met after the class head fails there). Both probes of an
       // iteration are issued before either is used; a probe taken before `cur` grew stays a valid pre-filter.
 #define ZH_MF_VERIFY(Q, D)                                                                                        \
       if ((LDS_WIN ? zh_load32_at(lwin32, (Q) + fo) : zh_ld32(win + (Q) + fo)) == ci) {                           \
