@@ -137,49 +137,30 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
    }
    __syncthreads();
 
-   // ---- stable scatter, the whole workgroup one tile of 4096 elements at a time: wave w takes elements [256 w, 256 w + 256)
-   //      of the tile, 64 per sub-step ---------------------------------------------------------------------------------
+   // ---- stable scatter, the whole workgroup one tile of 1024 elements at a time ---------------------------------------
    // Only 256 output streams are open per workgroup (one per digit, not one per digit and wave): their partially written
    // lines stay in L2 until they are full. With a stream per digit and wave the same scatter wrote 3.4x its bytes to HBM
-   // (rocprofv3 WRITE_SIZE).
-   uint32_t e_n[4], d_n[4];
-#pragma unroll
-   for (uint32_t u = 0; u < 4; u++) {
-      const uint32_t idx = wave * 256 + u * 64 + lane;
-      e_n[u] = 0;
-      d_n[u] = 0xffffffffu;
-      if (idx < M) ZH_MF_FETCH(idx, e_n[u], d_n[u]);
-   }
-   for (uint32_t t0 = 0; t0 < M; t0 += 4 * ZH_MF_THREADS) {
-      uint32_t e[4], d[4], rank[4];
-#pragma unroll
-      for (uint32_t u = 0; u < 4; u++) {
-         e[u] = e_n[u];
-         d[u] = d_n[u];
+   // (rocprofv3 WRITE_SIZE) and took 60 % longer.
+   uint32_t e_n = 0, d_n = 0xffffffffu;
+   if (tid < M) ZH_MF_FETCH(tid, e_n, d_n);
+   for (uint32_t t0 = 0; t0 < M; t0 += ZH_MF_THREADS) {
+      const uint32_t e = e_n, d = d_n;
+      const bool valid = d != 0xffffffffu;
+      {
+         const uint32_t nidx = t0 + ZH_MF_THREADS + tid;   // next tile's element: its loads overlap this tile's barriers
+         e_n = 0;
+         d_n = 0xffffffffu;
+         if (nidx < M) ZH_MF_FETCH(nidx, e_n, d_n);
       }
-#pragma unroll
-      for (uint32_t u = 0; u < 4; u++) {   // next tile's elements: their loads overlap this tile's barriers
-         const uint32_t idx = t0 + 4 * ZH_MF_THREADS + wave * 256 + u * 64 + lane;
-         e_n[u] = 0;
-         d_n[u] = 0xffffffffu;
-         if (idx < M) ZH_MF_FETCH(idx, e_n[u], d_n[u]);
+      // rank among the wave's elements with the same digit
+      uint64_t peers = zh_ballot(valid);
+      for (int bit = 0; bit < 8; bit++) {
+         const bool one = (d >> bit) & 1u;
+         const uint64_t m = zh_ballot(valid && one);
+         peers &= one ? m : ~m;
       }
-      // rank among the wave's 256 elements with the same digit; hist[wave][digit] counts them
-#pragma unroll
-      for (uint32_t u = 0; u < 4; u++) {
-         const bool valid = d[u] != 0xffffffffu;
-         uint64_t peers = zh_ballot(valid);
-         for (int bit = 0; bit < 8; bit++) {
-            const bool one = (d[u] >> bit) & 1u;
-            const uint64_t m = zh_ballot(valid && one);
-            peers &= one ? m : ~m;
-         }
-         const uint32_t before = valid ? hist[wave * 256 + d[u]] : 0u;
-         rank[u] = before + (uint32_t)zh_popc64(peers & lt_mask);
-         zh_wave_sync();   // every lane has read the count
-         if (valid && (peers & lt_mask) == 0) hist[wave * 256 + d[u]] = before + (uint32_t)zh_popc64(peers);
-         zh_wave_sync();
-      }
+      const bool leader = valid && (peers & lt_mask) == 0;
+      if (leader) hist[wave * 256 + d] = (uint32_t)zh_popc64(peers);
       __syncthreads();
       // digit by digit, the waves' counts become output offsets (waves in order: stable); absent pairs stay zero
       if (tid < 256) {
@@ -195,13 +176,9 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
          dbase[tid] = run;
       }
       __syncthreads();
-#pragma unroll
-      for (uint32_t u = 0; u < 4; u++)
-         if (d[u] != 0xffffffffu) dst[hist[wave * 256 + d[u]] + rank[u]] = e[u];
-      zh_wave_sync();   // every lane of the wave has read its offsets
-#pragma unroll
-      for (uint32_t u = 0; u < 4; u++)
-         if (d[u] != 0xffffffffu) hist[wave * 256 + d[u]] = 0;
+      if (valid) dst[hist[wave * 256 + d] + (uint32_t)zh_popc64(peers & lt_mask)] = e;
+      zh_wave_sync();   // every lane of the wave has read its offset
+      if (leader) hist[wave * 256 + d] = 0;
    }
 #undef ZH_MF_FETCH
    __threadfence_block();
