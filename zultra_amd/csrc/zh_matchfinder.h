@@ -42,7 +42,7 @@
 #define ZH_MF_SENTINEL 0xffffffffu   // "no entry": marked, and farther than any legal distance
 
 #define ZH_MF_NONE 0xffffffffu       // prev.x: no earlier occurrence of the trigram
-#define ZH_MF_GROUP_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1 + 256) * 4)   // dynamic LDS bytes of zh_mf_group
+#define ZH_MF_GROUP_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1) * 4)   // dynamic LDS bytes of zh_mf_group
 #define ZH_MF_FRONTIER_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + 8 * ZH_MF_THREADS + 1) * 4)              // ... of zh_mf_frontier
 #define ZH_MF_HELP_WINDOW 4096u       // zh_mf_frontier: a workgroup out of tickets looks at the last 4096 segments for one to help
 #ifndef ZH_MF_HELP_MIN
@@ -73,7 +73,8 @@ __device__ inline void zh_stage_window(uint32_t *lwin32, const uint8_t *gwin, ui
 // ---------------------------------------------------------------------------------------------------------
 // zh_mf_group
 // ---------------------------------------------------------------------------------------------------------
-// One stable counting pass over M elements. hist = ZH_MF_WAVES x 256 counters in LDS.
+// One stable counting pass over M elements: wave w owns the contiguous slice [w*seg, (w+1)*seg), so element order
+// within a digit is preserved. hist = ZH_MF_WAVES x 256 counters in LDS.
 // MODE 0/1/2: the trigram's bytes 2/1/0 are the digits (exact order, three passes, elements are positions);
 // MODE 5/6/7: byte 3/4/5 of the string at the position: a stable pass over the k-gram order gives the (k+1)-gram classes,
 // contiguous and ascending in position (the classes come out ordered by their last byte first, which nobody minds).
@@ -83,13 +84,15 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
                                        uint32_t *wave_tot, uint32_t W = 0) {
    const uint32_t tid = threadIdx.x;
    const uint32_t lane = tid & 63, wave = tid >> 6;
+   const uint32_t seg = (((M + ZH_MF_WAVES - 1) / ZH_MF_WAVES) + 63) & ~63u;
+   const uint32_t lo = wave * seg;
+   const uint32_t hi = min(M, lo + seg);
    const uint64_t lt_mask = (1ull << lane) - 1;
-   uint32_t *dbase = wave_tot + ZH_MF_WAVES + 1;   // 256 words behind the kernel's small LDS variables: next output slot per digit
 
    for (uint32_t k = tid; k < ZH_MF_WAVES * 256; k += ZH_MF_THREADS) hist[k] = 0;
    __syncthreads();
 
-   // element and digit of index idx
+   // element and digit of slice index idx
 #define ZH_MF_FETCH(idx, e, d)                                                                      \
    do {                                                                                             \
       if (MODE == 0) {                                                                              \
@@ -106,79 +109,72 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
       }                                                                                             \
    } while (0)
 
-   // ---- digit totals (counted per wave to keep the LDS atomics apart); four independent fetches in flight per thread ------
-   for (uint32_t base = 0; base < M; base += 4 * ZH_MF_THREADS) {
+   // per-wave digit histogram of the wave's contiguous slice; four independent fetches in flight per lane
+   for (uint32_t base = lo; base < hi; base += 256) {
       uint32_t e[4], d[4];
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
-         const uint32_t idx = base + u * ZH_MF_THREADS + tid;
+         const uint32_t idx = base + u * 64 + lane;
          e[u] = 0;
          d[u] = 0xffffffffu;
-         if (idx < M) ZH_MF_FETCH(idx, e[u], d[u]);
+         if (idx < hi) ZH_MF_FETCH(idx, e[u], d[u]);
       }
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++)
          if (d[u] != 0xffffffffu) atomicAdd(&hist[wave * 256 + d[u]], 1u);
    }
    __syncthreads();
+
+   // exclusive scan in (digit, wave) order: entry e = digit*16 + wave; each thread owns 4 entries
    {
-      // exclusive scan of the 256 digit totals -> first output slot of every digit
-      uint32_t tot = 0;
-      if (tid < 256)
-         for (uint32_t w2 = 0; w2 < ZH_MF_WAVES; w2++) tot += hist[w2 * 256 + tid];
-      uint32_t ex = zh_wave_excl_sum(tot);
-      if (lane == 63) wave_tot[wave] = ex + tot;
-      __syncthreads();
-      if (tid < 256) {
-         for (uint32_t w2 = 0; w2 < wave; w2++) ex += wave_tot[w2];
-         dbase[tid] = ex;
+      uint32_t v[4], s = 0;
+      for (int q = 0; q < 4; q++) {
+         const uint32_t e = tid * 4 + (uint32_t)q;
+         v[q] = hist[(e & 15) * 256 + (e >> 4)];
+         s += v[q];
       }
-      for (uint32_t k = tid; k < ZH_MF_WAVES * 256; k += ZH_MF_THREADS) hist[k] = 0;   // from here on: per (wave, digit) counts of a tile
+      uint32_t ex = zh_wave_excl_sum(s);
+      if (lane == 63) wave_tot[wave] = ex + s;
+      __syncthreads();
+      uint32_t pre = 0;
+      for (uint32_t w2 = 0; w2 < wave; w2++) pre += wave_tot[w2];
+      ex += pre;
+      for (int q = 0; q < 4; q++) {
+         const uint32_t e = tid * 4 + (uint32_t)q;
+         hist[(e & 15) * 256 + (e >> 4)] = ex;
+         ex += v[q];
+      }
    }
    __syncthreads();
 
-   // ---- stable scatter, the whole workgroup one tile of 1024 elements at a time ---------------------------------------
-   // Only 256 output streams are open per workgroup (one per digit, not one per digit and wave): their partially written
-   // lines stay in L2 until they are full. With a stream per digit and wave the same scatter wrote 3.4x its bytes to HBM
-   // (rocprofv3 WRITE_SIZE) and took 60 % longer.
-   uint32_t e_n = 0, d_n = 0xffffffffu;
-   if (tid < M) ZH_MF_FETCH(tid, e_n, d_n);
-   for (uint32_t t0 = 0; t0 < M; t0 += ZH_MF_THREADS) {
-      const uint32_t e = e_n, d = d_n;
-      const bool valid = d != 0xffffffffu;
-      {
-         const uint32_t nidx = t0 + ZH_MF_THREADS + tid;   // next tile's element: its loads overlap this tile's barriers
-         e_n = 0;
-         d_n = 0xffffffffu;
-         if (nidx < M) ZH_MF_FETCH(nidx, e_n, d_n);
-      }
-      // rank among the wave's elements with the same digit
-      uint64_t peers = zh_ballot(valid);
-      for (int bit = 0; bit < 8; bit++) {
-         const bool one = (d >> bit) & 1u;
-         const uint64_t m = zh_ballot(valid && one);
-         peers &= one ? m : ~m;
-      }
-      const bool leader = valid && (peers & lt_mask) == 0;
-      if (leader) hist[wave * 256 + d] = (uint32_t)zh_popc64(peers);
-      __syncthreads();
-      // digit by digit, the waves' counts become output offsets (waves in order: stable); absent pairs stay zero
-      if (tid < 256) {
-         uint32_t c[ZH_MF_WAVES];
+   // stable scatter: each wave walks its slice in order, 64 elements per step; the fetches of four steps are issued together
+   for (uint32_t base4 = lo; base4 < hi; base4 += 256) {
+      uint32_t e4[4], d4[4];
 #pragma unroll
-         for (uint32_t w2 = 0; w2 < ZH_MF_WAVES; w2++) c[w2] = hist[w2 * 256 + tid];
-         uint32_t run = dbase[tid];
+      for (uint32_t u = 0; u < 4; u++) {
+         const uint32_t idx = base4 + u * 64 + lane;
+         e4[u] = 0;
+         d4[u] = 0xffffffffu;
+         if (idx < hi) ZH_MF_FETCH(idx, e4[u], d4[u]);
+      }
 #pragma unroll
-         for (uint32_t w2 = 0; w2 < ZH_MF_WAVES; w2++) {
-            if (c[w2]) hist[w2 * 256 + tid] = run;
-            run += c[w2];
+      for (uint32_t u = 0; u < 4; u++) {
+         const uint32_t idx = base4 + u * 64 + lane;
+         const uint32_t e = e4[u], d = d4[u];
+         const bool valid = idx < hi && d != 0xffffffffu;
+         const uint32_t slot = valid ? hist[wave * 256 + d] : 0;
+         uint64_t peers = zh_ballot(valid);
+         for (int bit = 0; bit < 8; bit++) {
+            const bool one = (d >> bit) & 1u;
+            const uint64_t m = zh_ballot(valid && one);
+            peers &= one ? m : ~m;
          }
-         dbase[tid] = run;
+         if (valid) {
+            dst[slot + (uint32_t)zh_popc64(peers & lt_mask)] = e;
+            if ((peers & lt_mask) == 0) hist[wave * 256 + d] = slot + (uint32_t)zh_popc64(peers);
+         }
+         zh_ballot(true);   // orders the counter update before the next step's read (lock-step anyway on the GPU)
       }
-      __syncthreads();
-      if (valid) dst[hist[wave * 256 + d] + (uint32_t)zh_popc64(peers & lt_mask)] = e;
-      zh_wave_sync();   // every lane of the wave has read its offset
-      if (leader) hist[wave * 256 + d] = 0;
    }
 #undef ZH_MF_FETCH
    __threadfence_block();
