@@ -202,6 +202,7 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
    uint32_t nseen = 0;
    uint32_t best = 0xFFFFFFFFu;
    int best_gain = 0;
+   uint32_t left_upto = 0xFFFFFFFFu;   // this wave's left histogram covers tokens [t0, left_upto); all ones = not started
 
    for (uint32_t j0 = 0; j0 < ncp; j0 += ZH_SPLIT_MAXCP) {
       const uint32_t nj = min((uint32_t)ZH_SPLIT_MAXCP, ncp - j0);
@@ -237,16 +238,24 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
          seen += fr;
          nseen += nfresh;
       }
-      // the triggered evaluations, dealt to the waves: left = tokens before the previous checkpoint, right = the rest (:732-750)
+      // the triggered evaluations, dealt to the waves: left = tokens before the previous checkpoint, right = the rest (:732-750).
+      // A wave's evaluations come in ascending checkpoint order, so its left histogram grows from one to the next
+      // instead of being recounted from the range start.
       uint32_t k = 0;
       for (uint32_t jj = 0; jj < nj; jj++) {
          if (!((trig[jj >> 6] >> (jj & 63)) & 1ull)) continue;
          if ((k++ % ZH_SPLIT_WAVES) != wave) continue;
          const uint32_t cp = c0 + 256 * (j0 + jj - 1);
-         for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws->left_lit[s] = 0;
-         if (lane < ZH_NDIST) ws->left_dist[lane] = 0;
+         if (left_upto == 0xFFFFFFFFu) {
+            for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws->left_lit[s] = 0;
+            if (lane < ZH_NDIST) ws->left_dist[lane] = 0;
+            left_upto = t0;
+         }
+         else if (lane == 0)
+            ws->left_lit[ZH_EOB] = 0;   // the end-of-block symbol of the previous evaluation
          zh_wave_sync();
-         zh_token_histogram_wave(ti, t0, cp, ws->left_lit, ws->left_dist);
+         zh_token_histogram_wave(ti, left_upto, cp, ws->left_lit, ws->left_dist);
+         left_upto = cp;
          for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws->cur_lit[s] = sh->tot_lit[s] - ws->left_lit[s];
          if (lane < ZH_NDIST) ws->cur_dist[lane] = sh->tot_dist[lane] - ws->left_dist[lane];
          zh_wave_sync();
