@@ -42,7 +42,7 @@
 #define ZH_MF_SENTINEL 0xffffffffu   // "no entry": marked, and farther than any legal distance
 
 #define ZH_MF_NONE 0xffffffffu       // prev.x: no earlier occurrence of the trigram
-#define ZH_MF_GROUP_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1) * 4)   // dynamic LDS bytes of zh_mf_group
+#define ZH_MF_GROUP_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + 2 * ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1) * 4)   // dynamic LDS bytes of zh_mf_group
 #define ZH_MF_FRONTIER_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + 8 * ZH_MF_THREADS + 1) * 4)              // ... of zh_mf_frontier
 #define ZH_MF_HELP_WINDOW 4096u       // zh_mf_frontier: a workgroup out of tickets looks at the last 4096 segments for one to help
 #ifndef ZH_MF_HELP_MIN
@@ -79,17 +79,27 @@ __device__ inline void zh_stage_window(uint32_t *lwin32, const uint8_t *gwin, ui
 // MODE 5/6/7: byte 3/4/5 of the string at the position: a stable pass over the k-gram order gives the (k+1)-gram classes,
 // contiguous and ascending in position (the classes come out ordered by their last byte first, which nobody minds).
 // Mode 0 reads the identity permutation and the window linearly (win); the others gather through gwin.
-template <int MODE>
+// HAVE: hist already holds this pass's per-(wave, digit) counts — the previous pass counted them while it scattered
+// (its outputs are this pass's inputs), which saves this pass one read of its input and one digit gather per element.
+// NEXT >= 0: count the digits of pass mode NEXT into hist_next the same way (M_next = number of elements this pass writes).
+__device__ __forceinline__ uint32_t zh_mf_slice(uint32_t M) { return (((M + ZH_MF_WAVES - 1) / ZH_MF_WAVES) + 63) & ~63u; }
+
+template <int MODE, bool HAVE = false, int NEXT = -1>
 __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, uint32_t M, const uint32_t *src, uint32_t *dst, uint32_t *hist,
-                                       uint32_t *wave_tot, uint32_t W = 0) {
+                                       uint32_t *wave_tot, uint32_t W = 0, uint32_t *hist_next = nullptr, uint32_t M_next = 0) {
    const uint32_t tid = threadIdx.x;
    const uint32_t lane = tid & 63, wave = tid >> 6;
-   const uint32_t seg = (((M + ZH_MF_WAVES - 1) / ZH_MF_WAVES) + 63) & ~63u;
+   const uint32_t seg = zh_mf_slice(M);
    const uint32_t lo = wave * seg;
    const uint32_t hi = min(M, lo + seg);
    const uint64_t lt_mask = (1ull << lane) - 1;
+   const uint32_t seg_next = NEXT >= 0 ? zh_mf_slice(M_next) : 1u;
+   const float inv_seg_next = 1.0f / (float)seg_next;
 
-   for (uint32_t k = tid; k < ZH_MF_WAVES * 256; k += ZH_MF_THREADS) hist[k] = 0;
+   if (!HAVE)
+      for (uint32_t k = tid; k < ZH_MF_WAVES * 256; k += ZH_MF_THREADS) hist[k] = 0;
+   if (NEXT >= 0)
+      for (uint32_t k = tid; k < ZH_MF_WAVES * 256; k += ZH_MF_THREADS) hist_next[k] = 0;
    __syncthreads();
 
    // element and digit of slice index idx
@@ -110,7 +120,7 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
    } while (0)
 
    // per-wave digit histogram of the wave's contiguous slice; four independent fetches in flight per lane
-   for (uint32_t base = lo; base < hi; base += 256) {
+   for (uint32_t base = lo; base < hi && !HAVE; base += 256) {
       uint32_t e[4], d[4];
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
@@ -170,8 +180,20 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
             peers &= one ? m : ~m;
          }
          if (valid) {
-            dst[slot + (uint32_t)zh_popc64(peers & lt_mask)] = e;
+            const uint32_t out = slot + (uint32_t)zh_popc64(peers & lt_mask);
+            dst[out] = e;
             if ((peers & lt_mask) == 0) hist[wave * 256 + d] = slot + (uint32_t)zh_popc64(peers);
+            if (NEXT >= 0) {
+               // the next pass's digit of this element, counted for the wave whose slice position `out` will fall into
+               const bool has = NEXT < 5 || e + (uint32_t)(NEXT - 2) < W;
+               if (has) {
+                  const uint32_t d2 = gwin[e + (NEXT == 1 ? 1u : (NEXT == 2 ? 0u : (uint32_t)(NEXT - 2)))];
+                  uint32_t w2 = min((uint32_t)((float)out * inv_seg_next), (uint32_t)ZH_MF_WAVES - 1u);
+                  w2 -= (w2 * seg_next > out) ? 1u : 0u;
+                  w2 += ((w2 + 1) * seg_next <= out) ? 1u : 0u;
+                  atomicAdd(&hist_next[w2 * 256 + d2], 1u);
+               }
+            }
          }
          zh_ballot(true);   // orders the counter update before the next step's read (lock-step anyway on the GPU)
       }
@@ -279,10 +301,11 @@ __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin,
 
    // ---- exact trigram order -> previous occurrence of every trigram -------------------------------------------
    if (stop == 1) return;
-   zh_mf_sort_pass<0>(win, gwin, M3, nullptr, A, hist, wave_tot);
+   uint32_t *hist2 = hist + ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1;   // second counter table, behind the kernel's small variables
+   zh_mf_sort_pass<0, false, 1>(win, gwin, M3, nullptr, A, hist, wave_tot, W, hist2, M3);
    if (stop == 2) return;
-   zh_mf_sort_pass<1>(win, gwin, M3, A, B, hist, wave_tot);
-   zh_mf_sort_pass<2>(win, gwin, M3, B, A, hist, wave_tot);
+   zh_mf_sort_pass<1, true, 2>(win, gwin, M3, A, B, hist2, wave_tot, W, hist, M3);
+   zh_mf_sort_pass<2, true, 5>(win, gwin, M3, B, A, hist, wave_tot, W, hist2, M3);
    if (stop == 3) return;
    {
       // only block positions need it (history positions get no rows); four entries per thread keep the loads overlapped
@@ -315,11 +338,11 @@ __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin,
    // matches of 6 and more are found by walking a class, and 6-gram classes are several times smaller than 4-gram
    // classes (on text the walk shrinks 2.3x, on source code 1.5x).
    const uint32_t M5 = min(Qn, W >= 5 ? W - 4 : 0u), M6 = min(Qn, W >= 6 ? W - 5 : 0u);
-   zh_mf_sort_pass<5>(win, gwin, M3, A, B, hist, wave_tot, W);   // B: 4-gram order, M4 entries
+   zh_mf_sort_pass<5, true, 6>(win, gwin, M3, A, B, hist2, wave_tot, W, hist, M4);   // B: 4-gram order, M4 entries
    zh_mf_prev_level<4>(B, M4, gwin, first_needed, prev);
-   zh_mf_sort_pass<6>(win, gwin, M4, B, A, hist, wave_tot, W);   // A: 5-gram order, M5 entries
+   zh_mf_sort_pass<6, true, 7>(win, gwin, M4, B, A, hist, wave_tot, W, hist2, M5);   // A: 5-gram order, M5 entries
    zh_mf_prev_level<5>(A, M5, gwin, first_needed, prev);
-   zh_mf_sort_pass<7>(win, gwin, M5, A, B, hist, wave_tot, W);   // B: 6-gram order, M6 entries
+   zh_mf_sort_pass<7, true>(win, gwin, M5, A, B, hist2, wave_tot, W);                // B: 6-gram order, M6 entries
    if (stop == 5) return;
    {
       const uint32_t *__restrict__ Br = B;
