@@ -49,6 +49,11 @@
 // (either can be reached from the other by literals), so candidate costs relative to cost[p+1], biased by 2^14, stay
 // inside 15 bits and compare exactly like the reference's 32-bit sums.
 #define ZH_KEY_BIAS (1u << 14)
+// The cost ring of a row: a step reads cost[p+3 .. p+258] and writes cost[p], so 259 entries are live; 320 (not 512) keeps
+// the kernel's LDS at 6.7 KB per wave, i.e. 24 instead of 19 resident waves per CU (measured: the kernel's time is
+// 8.6 ms + 136 ms / waves per CU). Indices are kept reduced: x < 2 * ZH_RING wraps with one subtract and one unsigned min.
+#define ZH_RING 320u
+__device__ __forceinline__ uint32_t zh_ring_wrap(uint32_t x) { return min(x, x - ZH_RING); }
 
 // sub-block work item produced by zh_plan_subblocks
 struct zh_work_t {
@@ -141,7 +146,7 @@ __device__ inline void zh_walk_histogram_wave(uint32_t *hist /* ZH_NSYM, zeroed 
 // ---- the parse kernel ---------------------------------------------------------------------------------------------
 struct zh_parse_ws_t {
    union {
-      uint16_t ring[4][512];         // per row: cost[p & 511] mod 2^16 of its current piece (the reference's cost[], blockdeflate.c:255)
+      uint16_t ring[4][ZH_RING];     // per row: cost[p mod ZH_RING] mod 2^16 of its current piece (the reference's cost[], blockdeflate.c:255)
       uint32_t hist[ZH_NSYM];        // after the parse: histogram of the task
    };
    uint4 rec[4][16];                 // per staged position: x = bitmap of short slot lengths 3..34, y/z = running minima
@@ -198,14 +203,14 @@ __device__ __forceinline__ void zh_stage_position(zh_parse_ws_t &ws, uint32_t ro
 // This lane's best match candidate for the position at p with record R (tile entries at tile[trow][tslot]), costs in
 // `ring`: lane s prices length 3+s, and in the rarely executed section (taken by the whole wave when any position needs
 // it) lengths 19+s, 35+s and long slot s. Key = (cost - base) << 9 | slot << 6 | (39 - k).
-__device__ __forceinline__ uint32_t zh_lane_key(zh_parse_ws_t &ws, const uint16_t *ring, uint32_t trow, uint32_t tslot, const uint4 &R, uint32_t p, uint32_t s,
-                                                uint32_t base, uint32_t lc0, uint32_t lc1, uint32_t lc2, uint32_t sb_end) {
+__device__ __forceinline__ uint32_t zh_lane_key(zh_parse_ws_t &ws, const uint16_t *ring, uint32_t trow, uint32_t tslot, const uint4 &R, uint32_t p, uint32_t pm,
+                                                uint32_t s, uint32_t base, uint32_t lc0, uint32_t lc1, uint32_t lc2, uint32_t sb_end) {
    const uint32_t kmax = ZH_REC_KMAX(R.w), nlong = ZH_REC_NLONG(R.w), nhi = ZH_REC_NHI(R.w);
    uint32_t key = 0xFFFFFFFFu;
    if (3 + s <= kmax) {
       const uint32_t sel = (uint32_t)__popc(R.x >> s) + nhi - 1u;            // index of the last short slot reaching 3+s
       const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
-      const uint32_t c = (lc0 + (b >> 3) + (uint32_t)ring[(p + 3 + s) & 511] - base) & 0xffffu;
+      const uint32_t c = (lc0 + (b >> 3) + (uint32_t)ring[zh_ring_wrap(pm + 3 + s)] - base) & 0xffffu;
       key = (c << 9) | ((b & 7u) << 6) | (36u - s);                          // 39 - k
    }
    // rarely needed: lengths 19..39, and slots stored with length >= 40
@@ -213,13 +218,13 @@ __device__ __forceinline__ uint32_t zh_lane_key(zh_parse_ws_t &ws, const uint16_
       if (19 + s <= kmax) {
          const uint32_t sel = (uint32_t)__popc(R.x >> (16 + s)) + nhi - 1u;
          const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
-         const uint32_t c = (lc1 + (b >> 3) + (uint32_t)ring[(p + 19 + s) & 511] - base) & 0xffffu;
+         const uint32_t c = (lc1 + (b >> 3) + (uint32_t)ring[zh_ring_wrap(pm + 19 + s)] - base) & 0xffffu;
          key = min(key, (c << 9) | ((b & 7u) << 6) | (20u - s));
       }
       if (s < 5 && 35 + s <= kmax) {
          const uint32_t sel = (uint32_t)__popc((R.w & 31u) >> s) - 1u;
          const uint32_t b = ((sel < 4 ? R.y : R.z) >> ((sel & 3u) * 8u)) & 0xffu;
-         const uint32_t c = (lc2 + (b >> 3) + (uint32_t)ring[(p + 35 + s) & 511] - base) & 0xffffu;
+         const uint32_t c = (lc2 + (b >> 3) + (uint32_t)ring[zh_ring_wrap(pm + 35 + s)] - base) & 0xffffu;
          key = min(key, (c << 9) | ((b & 7u) << 6) | (4u - s));
       }
       if (s < nlong) {                                                        // long slot s: full (clamped) length only
@@ -227,7 +232,7 @@ __device__ __forceinline__ uint32_t zh_lane_key(zh_parse_ws_t &ws, const uint16_
          const uint32_t mlen = min(e & 511u, sb_end - p);
          uint32_t enc = mlen - ZH_MIN_MATCH;                                  // wraps below 3, then saturates (:289, :216-219)
          if (enc > 255) enc = 255;
-         const uint32_t c = ((uint32_t)ws.lencost[enc] + ((e >> 9) & 31u) + (uint32_t)ring[(p + mlen) & 511] - base) & 0xffffu;
+         const uint32_t c = ((uint32_t)ws.lencost[enc] + ((e >> 9) & 31u) + (uint32_t)ring[zh_ring_wrap(pm + mlen)] - base) & 0xffffu;
          key = min(key, (c << 9) | (s << 6));
       }
    }
@@ -344,7 +349,8 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       // ---- stage the tile: every lane digests the 8 slots of its own position (lanes beyond the tile's count digest
       //      zeros into their own, unused, record) ---------------------------------------------------------------------
       zh_stage_position(ws, row, s, regs, sb_end - (c_lo + s));
-      if (c_top && s == 0) ws.ring[row][(c_lo + c_cnt) & 511] = 0;   // cost[piece end] = 0
+      const uint32_t c_lo_m = c_lo % ZH_RING;   // once per tile; the steps below keep indices reduced
+      if (c_top && s == 0) ws.ring[row][zh_ring_wrap(c_lo_m + c_cnt)] = 0;   // cost[piece end] = 0
       if (c_top) cost_next = 0;
       zh_sync();
       ZH_NEXT_TILE();   // the next tile's loads complete while this one is priced
@@ -358,7 +364,8 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          uint4 R = ws.rec[row][a];
          if (!act) R.w = 0;
          const uint32_t base = cost_next - ZH_KEY_BIAS;   // key cost = (candidate cost - base) mod 2^16, below 2^15
-         const uint32_t key = zh_lane_key(ws, ws.ring[row], row, a, R, p, s, base, lc0, lc1, lc2, sb_end);
+         const uint32_t pm = zh_ring_wrap(c_lo_m + a);
+         const uint32_t key = zh_lane_key(ws, ws.ring[row], row, a, R, p, pm, s, base, lc0, lc1, lc2, sb_end);
          const uint32_t rkey = zh_row_min(key);   // every lane of a row now holds that row's best match candidate
          // literal first; a match must be strictly cheaper (:292,:307). An absent candidate (all ones) prices at 2^23-1,
          // above any literal (5 bits + bias).
@@ -367,7 +374,7 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          const uint32_t c = (base + (take ? mc : lit)) & 0xffffu;
          if (act) {
             if (s == 0) {
-               ws.ring[row][p & 511] = (uint16_t)c;
+               ws.ring[row][pm] = (uint16_t)c;
                ws.bt[row][a] = take ? rkey : 0xFFFFFFFFu;
             }
             cost_next = c;
