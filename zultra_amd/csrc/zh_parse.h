@@ -151,8 +151,9 @@ struct zh_parse_ws_t {
    };
    uint4 rec[4][16];                 // per staged position: x = bitmap of short slot lengths 3..34, y/z = running minima
                                      // (distance price << 3 | slot) per short slot, w = see ZH_REC_* below
-   uint32_t tile[4][16][ZH_NMATCH];  // per staged position and slot: len(9) | distance price(5) << 9 | offset << 16
-   uint32_t bt[4][16];               // winning key per staged position (all ones = literal)
+   uint16_t tile[4][16][ZH_NMATCH];  // per staged position and slot: len(9) | distance price(5) << 9 (the offset is re-read
+                                     // from the match row when the winner is decoded: LDS is allocated in 2 KiB granules on
+                                     // gfx950, and at <= 6 KiB 26 instead of 20 of these workgroups fit a CU)
    uint32_t bnd[ZH_MAXPIECES + 1];   // piece boundaries of the task
    uint8_t litprice[ZH_NLIT];        // code lengths with the 9-bit fill (blockdeflate.c:873-876)
    uint8_t lencost[256];             // price of length e+3 incl. extra bits (blockdeflate.c:216-219,263-264)
@@ -182,7 +183,7 @@ __device__ __forceinline__ void zh_stage_position(zh_parse_ws_t &ws, uint32_t ro
       const bool is_long = len >= ZH_LEAVE_ALONE;
       const bool is_short = valid && !is_long;
       const uint32_t oc = (uint32_t)ws.distcost[zh_dist_sym(valid ? off : 1u)];
-      ws.tile[row][slot][m] = valid ? (len | (oc << 9) | (off << 16)) : 0u;
+      ws.tile[row][slot][m] = valid ? (uint16_t)(len | (oc << 9)) : (uint16_t)0;
       nlong += is_long ? 1u : 0u;
       kmax = max(kmax, is_short ? len : 0u);               // the first short slot is the longest
       lmask |= is_short ? (1ull << (len - ZH_MIN_MATCH)) : 0ull;
@@ -239,13 +240,14 @@ __device__ __forceinline__ uint32_t zh_lane_key(zh_parse_ws_t &ws, const uint16_
    return key;
 }
 
-// decode the winning (slot, length) of a staged position into the parse entry
-__device__ __forceinline__ uint32_t zh_decode_pick(zh_parse_ws_t &ws, uint32_t trow, uint32_t tslot, uint32_t kk, uint32_t room) {
+// decode the winning (slot, length) of a staged position into the parse entry; `row8` = the position's match row (8 x
+// len | offset << 16), which the same lane loaded one tile earlier (an L2 hit)
+__device__ __forceinline__ uint32_t zh_decode_pick(zh_parse_ws_t &ws, uint32_t trow, uint32_t tslot, uint32_t kk, uint32_t room, const uint32_t *row8) {
    if (kk == 0xFFFFFFFFu) return 0;
    const uint32_t m = (kk >> 6) & 7u;
-   const uint32_t e = ws.tile[trow][tslot][m];
+   const uint32_t e = row8[m];
    const uint32_t nlong = ZH_REC_NLONG(ws.rec[trow][tslot].w);
-   const uint32_t len = (m < nlong) ? min(e & 511u, room) : (39u - (kk & 63u));
+   const uint32_t len = (m < nlong) ? min(e & 0xffffu, room) : (39u - (kk & 63u));
    return len | (e & 0xffff0000u);
 }
 
@@ -375,14 +377,15 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          if (act) {
             if (s == 0) {
                ws.ring[row][pm] = (uint16_t)c;
-               ws.bt[row][a] = take ? rkey : 0xFFFFFFFFu;
+               ws.rec[row][a].x = take ? rkey : 0xFFFFFFFFu;   // the record's length bitmap is dead now: its place takes the winning key
             }
             cost_next = c;
          }
       }
       zh_sync();
       // ---- flush: decode the winning (slot, length) of each position and store the parse --------------------------
-      if (s < c_cnt) best[(c_lo + s) - prev] = zh_decode_pick(ws, row, s, ws.bt[row][s], sb_end - (c_lo + s));
+      if (s < c_cnt)
+         best[(c_lo + s) - prev] = zh_decode_pick(ws, row, s, ws.rec[row][s].x, sb_end - (c_lo + s), (const uint32_t *)(rows + (uint64_t)(c_lo + s - prev) * 2));
       zh_sync();
    }
 #undef ZH_NEXT_TILE
