@@ -146,12 +146,15 @@ __device__ inline void zh_walk_histogram_wave(uint32_t *hist /* ZH_NSYM, zeroed 
 // ---- the parse kernel ---------------------------------------------------------------------------------------------
 struct zh_parse_ws_t {
    union {
-      uint16_t ring[4][ZH_RING];     // per row: cost[p mod ZH_RING] mod 2^16 of its current piece (the reference's cost[], blockdeflate.c:255)
+      uint16_t ring[4][ZH_RING + 16]; // per row (+32 B, likewise rec and tile +16 B: the four rows of a wave access their arrays at
+                                     // the same offsets in the same instruction; with row strides that are multiples of 128 B
+                                     // they would all hit the same LDS banks)
+                                     // per row: cost[p mod ZH_RING] mod 2^16 of its current piece (the reference's cost[], blockdeflate.c:255)
       uint32_t hist[ZH_NSYM];        // after the parse: histogram of the task
    };
-   uint4 rec[4][16];                 // per staged position: x = bitmap of short slot lengths 3..34, y/z = running minima
+   uint4 rec[4][17];                 // per staged position: x = bitmap of short slot lengths 3..34, y/z = running minima
                                      // (distance price << 3 | slot) per short slot, w = see ZH_REC_* below
-   uint16_t tile[4][16][ZH_NMATCH];  // per staged position and slot: len(9) | distance price(5) << 9 (the offset is re-read
+   uint16_t tile[4][17][ZH_NMATCH];  // per staged position and slot: len(9) | distance price(5) << 9 (the offset is re-read
                                      // from the match row when the winner is decoded: LDS is allocated in 2 KiB granules on
                                      // gfx950, and at <= 6 KiB 26 instead of 20 of these workgroups fit a CU)
    uint32_t bnd[ZH_MAXPIECES + 1];   // piece boundaries of the task
