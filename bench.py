@@ -19,6 +19,10 @@ import os
 import sys
 import time
 
+# the library's streams need their own hardware queues (zh_device.hip: zh_runtime_hints); torch initialises HIP before the
+# library is loaded here, so the hint has to be in the environment already
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -228,6 +228,13 @@ extern "C" int zultra_hip_traffic_probe(size_t nbytes) {
    return e == hipSuccess ? 0 : -2;
 }
 
+// The pipeline uses up to five streams per context (two runs, a side stream each for zh_parse_huge, one for the stitcher) next
+// to the application's own. The HIP runtime multiplexes streams onto 4 hardware queues by default, and two streams that
+// share a queue run strictly one after the other: measured, a run's zh_parse_huge then blocks the other run's kernels
+// (source code, three runs: 89 ms per 50 MB with 4 queues, 60 ms with 8). The variable is read when the runtime
+// initialises, so it is set when the library is loaded — unless the application chose a value or initialised HIP earlier.
+__attribute__((constructor)) static void zh_runtime_hints(void) { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" int zultra_hip_device_count(void) {
    int n = 0;
    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
