@@ -133,3 +133,22 @@ def test_files_mode_each_input_is_its_own_stream(emu, oracle):
             assert emu.crc32_append(0, lin, len(files[k])) == zlib.crc32(files[k].tobytes())
     finally:
         ctx.close()
+
+
+def test_edge_sizes_and_tiny_alphabets_vs_oracle(emu, oracle):
+    # every size 1..48 over alphabets of 1, 2 and 3 symbols: window ends, the last five positions of a window (not in the
+    # 6-gram order), byte runs of every residue (the GPU suite runs the full grid: test_gpu_parity.py)
+    rs = np.random.RandomState(7)
+    files = [rs.randint(97, 97 + k, size=n).astype(np.uint8) for n in range(1, 49) for k in (1, 2, 3)]
+    sizes = [len(f) for f in files]
+    ctx = emu.files_context(4096, len(files))
+    try:
+        fo = ctx.compress_files(np.concatenate(files), np.cumsum([0] + sizes[:-1]), sizes)
+        stream = ctx.stream_read(int(fo[-1]))
+        for k, f in enumerate(files):
+            assert stream[int(fo[k]):int(fo[k + 1])].tobytes() == oracle.memory_compress(f, 0, 32768), (k, sizes[k])
+    finally:
+        ctx.close()
+    hist = np.concatenate(files)[-3000:]
+    for f in files[60::9]:
+        check_window(emu, oracle, np.concatenate([hist, f, f]), len(hist), 2 * len(f), tag="edge_tail_%d" % len(f))

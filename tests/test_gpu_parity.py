@@ -169,6 +169,43 @@ def test_files_mode_graph_replay_vs_oracle(gpu, oracle):
         ctx.close()
 
 
+def _edge_inputs():
+    """Every size 1..160 and a spread of larger ones, over alphabets of 1, 2, 3 and 5 symbols and a run-heavy mix: window
+    ends, the last five positions of a window (which the 6-gram order does not hold), byte runs of every residue, and
+    all the short-length record rules of the matchfinder in many combinations."""
+    rs = np.random.RandomState(7)
+    out = []
+    for n in list(range(1, 161)) + [200, 255, 256, 257, 258, 259, 260, 300, 511, 512, 513, 777, 1024, 2047, 4095, 4096]:
+        for k in (1, 2, 3, 5):
+            out.append(rs.randint(97, 97 + k, size=n).astype(np.uint8))
+        runs = bytearray()
+        while len(runs) < n:
+            runs += bytes([int(rs.randint(97, 100))]) * int(rs.randint(1, 12))
+        out.append(np.frombuffer(bytes(runs[:n]), dtype=np.uint8).copy())
+    return out
+
+
+def test_edge_sizes_and_tiny_alphabets_vs_oracle(gpu, oracle):
+    files = _edge_inputs()
+    sizes = [len(f) for f in files]
+    ctx = gpu.files_context(4096, len(files))
+    try:
+        data = np.concatenate(files)
+        offs = np.cumsum([0] + sizes[:-1])
+        fo = ctx.compress_files(data, offs, sizes)
+        stream = ctx.stream_read(int(fo[-1]))
+        for k, f in enumerate(files):
+            got = stream[int(fo[k]):int(fo[k + 1])].tobytes()
+            assert got == oracle.memory_compress(f, 0, 32768), (k, sizes[k])
+    finally:
+        ctx.close()
+    # the same strings as the tail of a window with history: the end-of-window rules with earlier occurrences in reach
+    hist = np.concatenate(files[-40:])[-30000:]
+    for f in files[100:400:7]:
+        d = np.concatenate([hist, f, f])
+        check_window(gpu, oracle, d, len(hist), 2 * len(f), max_block=32768, tag="edge_tail_%d" % len(f))
+
+
 def _image_files(pattern, limit):
     import glob
     buf = bytearray()
