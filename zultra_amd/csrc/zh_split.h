@@ -103,7 +103,9 @@ zh_tokenize(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blo
 // depends on the 18-bin statistics before and inside its interval, and an evaluation prices "tokens before the previous
 // checkpoint" against "the rest". So: the interval statistics are gathered by all waves, every wave then replays the cheap
 // trigger scan, the triggered evaluations (four Huffman length builds and two table costs each — what the kernel's time
-// goes into) are dealt round-robin to the waves, and the reference's selection rule runs over the gains in order.
+// goes into) are pulled by the waves from a counter, and the reference's selection rule runs over the gains in order.
+// The histogram and the price of the whole range are needed only once a checkpoint triggers; the price is then computed by
+// one wave next to the evaluations (measured before: all eight waves pricing it took 33-73 % of the kernel's wave-cycles).
 #ifndef ZH_SPLIT_WAVES
 #define ZH_SPLIT_WAVES 8
 #endif
@@ -122,7 +124,9 @@ struct zh_split_wave_ws_t {   // private to one wave
 struct zh_split_shared_t {
    int32_t tot_lit[ZH_NLIT], tot_dist[ZH_NDIST];
    uint32_t fresh[ZH_SPLIT_MAXCP][18];
-   int32_t gain[ZH_SPLIT_MAXCP];
+   int32_t gain[ZH_SPLIT_MAXCP];   // per triggered checkpoint: price of the two halves
+   int32_t total_cost;             // price of the whole range (wave 0)
+   uint32_t next_eval;             // the next triggered checkpoint to hand to a wave
 };
 
 // blockdeflate.c:577-618 for the histogram in (lit, dist): unlimited lengths, body bits, header bits, +3.
@@ -172,22 +176,6 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
                                               uint32_t t1, uint32_t start_pos, uint32_t end_pos) {
    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-   // histogram and price of the whole range
-   for (uint32_t s = tid; s < ZH_NLIT; s += ZH_SPLIT_THREADS) sh->tot_lit[s] = 0;
-   if (tid < ZH_NDIST) sh->tot_dist[tid] = 0;
-   __syncthreads();
-   for (uint32_t t = t0 + tid; t < t1; t += ZH_SPLIT_THREADS) {
-      const uint32_t info = ti[t];
-      const uint32_t s = ZH_TOK_SYM(info);
-      atomicAdd(&sh->tot_lit[s], 1);
-      if (s > 256) atomicAdd(&sh->tot_dist[ZH_TOK_DSYM(info)], 1);
-   }
-   __syncthreads();
-   if (tid == 0) sh->tot_lit[ZH_EOB] += 1;
-   __syncthreads();
-   // (every wave prices it for itself, on its own scratch: no hand-over needed)
-   const int total_cost = zh_dynamic_cost_wave(sh->tot_lit, sh->tot_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl, &ws->tmp, &ws->sc, true);
-
    // checkpoints: the first boundary c0 with >= 256 tokens and >= 512 bytes since the range start, then every 256 tokens (:705)
    uint32_t c0 = t0 + 256;
    if (c0 > t1) return 0xFFFFFFFFu;
@@ -203,11 +191,14 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
    uint32_t best = 0xFFFFFFFFu;
    int best_gain = 0;
    uint32_t left_upto = 0xFFFFFFFFu;   // this wave's left histogram covers tokens [t0, left_upto); all ones = not started
+   bool have_total = false;            // histogram and price of the whole range: only needed once a checkpoint triggers
 
    for (uint32_t j0 = 0; j0 < ncp; j0 += ZH_SPLIT_MAXCP) {
       const uint32_t nj = min((uint32_t)ZH_SPLIT_MAXCP, ncp - j0);
+      __syncthreads();   // the previous chunk's statistics have been read
       // 18-bin statistics of every interval of the chunk: interval j = tokens [c(j-1), c(j)), c(-1) = t0, c(j) = c0 + 256 j
       for (uint32_t k = tid; k < nj * 18; k += ZH_SPLIT_THREADS) sh->fresh[k / 18][k % 18] = 0;
+      if (tid == 0) sh->next_eval = 0;
       __syncthreads();
       for (uint32_t jj = wave; jj < nj; jj += ZH_SPLIT_WAVES) {
          const uint32_t j = j0 + jj;
@@ -238,13 +229,46 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
          seen += fr;
          nseen += nfresh;
       }
-      // the triggered evaluations, dealt to the waves: left = tokens before the previous checkpoint, right = the rest (:732-750).
-      // A wave's evaluations come in ascending checkpoint order, so its left histogram grows from one to the next
-      // instead of being recounted from the range start.
-      uint32_t k = 0;
-      for (uint32_t jj = 0; jj < nj; jj++) {
-         if (!((trig[jj >> 6] >> (jj & 63)) & 1ull)) continue;
-         if ((k++ % ZH_SPLIT_WAVES) != wave) continue;
+      if (!(trig[0] | trig[1] | trig[2] | trig[3])) continue;   // nothing to evaluate (the common case on homogeneous data)
+
+      if (!have_total) {
+         // histogram of the whole range (all waves), its price (wave 0 alone, while the others start on the evaluations)
+         have_total = true;
+         for (uint32_t s = tid; s < ZH_NLIT; s += ZH_SPLIT_THREADS) sh->tot_lit[s] = 0;
+         if (tid < ZH_NDIST) sh->tot_dist[tid] = 0;
+         __syncthreads();
+         for (uint32_t t = t0 + tid; t < t1; t += ZH_SPLIT_THREADS) {
+            const uint32_t info = ti[t];
+            const uint32_t s = ZH_TOK_SYM(info);
+            atomicAdd(&sh->tot_lit[s], 1);
+            if (s > 256) atomicAdd(&sh->tot_dist[ZH_TOK_DSYM(info)], 1);
+         }
+         __syncthreads();
+         if (tid == 0) sh->tot_lit[ZH_EOB] += 1;
+         __syncthreads();
+         if (wave == 0) {
+            const int tc = zh_dynamic_cost_wave(sh->tot_lit, sh->tot_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl, &ws->tmp, &ws->sc, true);
+            if (lane == 0) sh->total_cost = tc;
+         }
+      }
+      // the triggered evaluations: left = tokens before the previous checkpoint, right = the rest (:732-750). The waves pull
+      // them from a counter, in ascending checkpoint order, so a wave's left histogram grows from one evaluation to the
+      // next instead of being recounted from the range start.
+      uint32_t scan_jj = 0, scan_cnt = 0;   // triggered checkpoints below scan_jj: scan_cnt
+      for (;;) {
+         uint32_t want = 0;
+         if (lane == 0) want = atomicAdd(&sh->next_eval, 1u);
+         want = zh_readfirstlane(want);
+         uint32_t jj = nj;
+         while (scan_jj < nj) {
+            const bool set = (trig[scan_jj >> 6] >> (scan_jj & 63)) & 1ull;
+            const uint32_t at = scan_jj++;
+            if (set && scan_cnt++ == want) {
+               jj = at;
+               break;
+            }
+         }
+         if (jj >= nj) break;
          const uint32_t cp = c0 + 256 * (j0 + jj - 1);
          if (left_upto == 0xFFFFFFFFu) {
             for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws->left_lit[s] = 0;
@@ -266,20 +290,21 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
          zh_wave_sync();
          const int lcost = zh_dynamic_cost_wave(ws->left_lit, ws->left_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl, &ws->tmp, &ws->sc, true);
          const int rcost = zh_dynamic_cost_wave(ws->cur_lit, ws->cur_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl, &ws->tmp, &ws->sc, true);
-         if (lane == 0) sh->gain[jj] = total_cost - (lcost + rcost);
+         if (lane == 0) sh->gain[jj] = lcost + rcost;
       }
       __syncthreads();
       // the reference keeps the first non-negative gain, then only strictly larger ones (:751-757)
+      const int total_cost = sh->total_cost;
       for (uint32_t jj = 0; jj < nj; jj++) {
          if (!((trig[jj >> 6] >> (jj & 63)) & 1ull)) continue;
-         const int gain = sh->gain[jj];
+         const int gain = total_cost - sh->gain[jj];
          if (gain >= 0 && (best == 0xFFFFFFFFu || best_gain < gain)) {
             best = c0 + 256 * (j0 + jj - 1);
             best_gain = gain;
          }
       }
-      __syncthreads();
    }
+   __syncthreads();   // the caller may start the next search: shared state is free
    return best;
 }
 
