@@ -198,6 +198,7 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
       __syncthreads();   // the previous chunk's statistics have been read
       // 18-bin statistics of every interval of the chunk: interval j = tokens [c(j-1), c(j)), c(-1) = t0, c(j) = c0 + 256 j
       for (uint32_t k = tid; k < nj * 18; k += ZH_SPLIT_THREADS) sh->fresh[k / 18][k % 18] = 0;
+      for (uint32_t k = tid; k < nj; k += ZH_SPLIT_THREADS) sh->gain[k] = 0;
       if (tid == 0) sh->next_eval = 0;
       __syncthreads();
       for (uint32_t jj = wave; jj < nj; jj += ZH_SPLIT_WAVES) {
@@ -252,23 +253,32 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
          }
       }
       // the triggered evaluations: left = tokens before the previous checkpoint, right = the rest (:732-750). The waves pull
-      // them from a counter, in ascending checkpoint order, so a wave's left histogram grows from one evaluation to the
-      // next instead of being recounted from the range start.
+      // HALF evaluations (one side of one checkpoint: two Huffman length builds and a table cost) from a counter — a search
+      // triggers only two or three evaluations on average, so this halves its latency — in ascending checkpoint order, so a
+      // wave's left histogram grows from one item to the next instead of being recounted from the range start.
       uint32_t scan_jj = 0, scan_cnt = 0;   // triggered checkpoints below scan_jj: scan_cnt
+      uint32_t last_k = 0xFFFFFFFFu, last_jj = nj;
       for (;;) {
          uint32_t want = 0;
          if (lane == 0) want = atomicAdd(&sh->next_eval, 1u);
          want = zh_readfirstlane(want);
+         const uint32_t side = want & 1u;
+         want >>= 1;
          uint32_t jj = nj;
-         while (scan_jj < nj) {
-            const bool set = (trig[scan_jj >> 6] >> (scan_jj & 63)) & 1ull;
-            const uint32_t at = scan_jj++;
-            if (set && scan_cnt++ == want) {
-               jj = at;
-               break;
+         if (want == last_k)
+            jj = last_jj;
+         else
+            while (scan_jj < nj) {
+               const bool set = (trig[scan_jj >> 6] >> (scan_jj & 63)) & 1ull;
+               const uint32_t at = scan_jj++;
+               if (set && scan_cnt++ == want) {
+                  jj = at;
+                  break;
+               }
             }
-         }
          if (jj >= nj) break;
+         last_k = want;
+         last_jj = jj;
          const uint32_t cp = c0 + 256 * (j0 + jj - 1);
          if (left_upto == 0xFFFFFFFFu) {
             for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws->left_lit[s] = 0;
@@ -280,17 +290,24 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
          zh_wave_sync();
          zh_token_histogram_wave(ti, left_upto, cp, ws->left_lit, ws->left_dist);
          left_upto = cp;
-         for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws->cur_lit[s] = sh->tot_lit[s] - ws->left_lit[s];
-         if (lane < ZH_NDIST) ws->cur_dist[lane] = sh->tot_dist[lane] - ws->left_dist[lane];
-         zh_wave_sync();
-         if (lane == 0) {
-            ws->left_lit[ZH_EOB] = 1;
-            ws->cur_lit[ZH_EOB] = 1;
+         int cost;
+         if (side) {
+            for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws->cur_lit[s] = sh->tot_lit[s] - ws->left_lit[s];
+            if (lane < ZH_NDIST) ws->cur_dist[lane] = sh->tot_dist[lane] - ws->left_dist[lane];
+            zh_wave_sync();
+            if (lane == 0) {
+               ws->left_lit[ZH_EOB] = 1;   // (reset before the histogram grows again)
+               ws->cur_lit[ZH_EOB] = 1;
+            }
+            zh_wave_sync();
+            cost = zh_dynamic_cost_wave(ws->cur_lit, ws->cur_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl, &ws->tmp, &ws->sc, true);
          }
-         zh_wave_sync();
-         const int lcost = zh_dynamic_cost_wave(ws->left_lit, ws->left_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl, &ws->tmp, &ws->sc, true);
-         const int rcost = zh_dynamic_cost_wave(ws->cur_lit, ws->cur_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl, &ws->tmp, &ws->sc, true);
-         if (lane == 0) sh->gain[jj] = lcost + rcost;
+         else {
+            if (lane == 0) ws->left_lit[ZH_EOB] = 1;
+            zh_wave_sync();
+            cost = zh_dynamic_cost_wave(ws->left_lit, ws->left_dist, ws->lit_len, ws->dist_len, ws->lens, &ws->cl, &ws->tmp, &ws->sc, true);
+         }
+         if (lane == 0) atomicAdd(&sh->gain[jj], cost);
       }
       __syncthreads();
       // the reference keeps the first non-negative gain, then only strictly larger ones (:751-757)
