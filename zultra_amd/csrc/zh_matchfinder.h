@@ -546,45 +546,17 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
    uint32_t cmask = 1;
    while (cmask < nchunks) cmask <<= 1;
    cmask -= 1;
-   // Three loads stand between a wave and a chunk's work, each needing the one before: the ticket (a device-scope atomic,
-   // microseconds away), the chunk's 64 sorted entries, and the prev records of their positions (a gather, a sector per
-   // lane). They are pipelined over three chunks: while chunk n is scanned, the prev records of chunk n+1, the entries
-   // of chunk n+2 and the ticket of chunk n+3 are in flight.
-   const uint32_t tlimit = (cmask + 1) * 64u;
-#define ZH_MF_CHUNK(tk) ((tk) >= tlimit ? 0xffffffffu : ((((tk) >> 6) * 40503u + 12345u) & cmask) << 6)
-#define ZH_MF_OWN(c) (((c) != 0xffffffffu && (c) + lane < M) ? S[(c) + lane] : ZH_MF_SENTINEL)
-   uint32_t req = 0;                                     // lane 0: the ticket asked for last
-   if (lane == 0) req = atomicAdd(ctr, 64u);
-   uint32_t tk0 = zh_readfirstlane(req);
-   if (lane == 0) req = atomicAdd(ctr, 64u);
-   uint32_t tk1 = zh_readfirstlane(req);
-   if (lane == 0) req = atomicAdd(ctr, 64u);            // tk2: read at the top of the first iteration
-   uint32_t own0 = ZH_MF_OWN(ZH_MF_CHUNK(tk0)), own1 = ZH_MF_OWN(ZH_MF_CHUNK(tk1));
-   uint2 pv0;
-   pv0.x = ZH_MF_NONE;
-   pv0.y = 0xffffffffu;
-   if (own0 != ZH_MF_SENTINEL && (own0 & ZH_MF_POS_MASK) >= prev) pv0 = prevs[own0 & ZH_MF_POS_MASK];
+   uint32_t c_next = 0;
+   if (lane == 0) c_next = atomicAdd(ctr, 64u);
    for (;;) {
-      if (tk0 >= tlimit) break;   // tickets only grow: the ones in flight are past the end too
-      const uint32_t tk2 = zh_readfirstlane(req);
-      if (lane == 0) req = atomicAdd(ctr, 64u);
-      const uint32_t own2 = ZH_MF_OWN(ZH_MF_CHUNK(tk2));
-      uint2 pv1;
-      pv1.x = ZH_MF_NONE;
-      pv1.y = 0xffffffffu;
-      if (own1 != ZH_MF_SENTINEL && (own1 & ZH_MF_POS_MASK) >= prev) pv1 = prevs[own1 & ZH_MF_POS_MASK];
-      // this iteration's chunk
-      const uint32_t c = ZH_MF_CHUNK(tk0);
-      const uint32_t own = own0;
-      const uint2 pv = pv0;
-      tk0 = tk1;
-      tk1 = tk2;
-      own0 = own1;
-      own1 = own2;
-      pv0 = pv1;
-      if (c >= M) continue;   // (also the chunks of the power-of-two padding)
+      const uint32_t ticket = zh_readfirstlane(c_next);
+      if (ticket >= (cmask + 1) * 64u) break;
+      if (lane == 0) c_next = atomicAdd(ctr, 64u);
+      const uint32_t c = ((((ticket >> 6) * 40503u + 12345u) & cmask)) << 6;
+      if (c >= M) continue;
 
       const uint32_t t = c + lane;
+      const uint32_t own = t < M ? S[t] : ZH_MF_SENTINEL;
       const uint32_t i = own & ZH_MF_POS_MASK;
       const bool mine = t < M && i >= prev;
       const uint32_t maxlen = t < M ? min((uint32_t)ZH_MAX_MATCH, W - i) : 0;   // >= 4
@@ -598,6 +570,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       if (mine) {
          // nearest occurrence of the trigram: without it there is no match at all; if its 4th byte differs it is the
          // (only) length-3 entry. Likewise the nearest occurrences of the 4-gram and the 5-gram.
+         const uint2 pv = prevs[i];
          const uint32_t p3 = pv.x;
          if (p3 != ZH_MF_NONE && i - p3 <= ZH_MAX_DIST) {
             d4 = pv.y & 0xffffu;
@@ -798,8 +771,6 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
          r[1] = b2;
       }
    }
-#undef ZH_MF_CHUNK
-#undef ZH_MF_OWN
 
    __syncthreads();   // every wave is done with the window in LDS
    }
