@@ -423,6 +423,16 @@ __device__ __forceinline__ uint32_t zh_load32_at(const uint32_t *w32, uint32_t x
    const uint32_t sh = (x & 3u) * 8u;
    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
 }
+// the 16 bytes at byte offset x: five aligned words, all in flight together
+__device__ __forceinline__ void zh_load128_at(const uint32_t *w32, uint32_t x, uint32_t out[4]) {
+   const uint32_t *p = w32 + (x >> 2);
+   const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4];
+   const uint32_t sh = (x & 3u) * 8u;
+   out[0] = (uint32_t)((((uint64_t)a1 << 32) | a0) >> sh);
+   out[1] = (uint32_t)((((uint64_t)a2 << 32) | a1) >> sh);
+   out[2] = (uint32_t)((((uint64_t)a3 << 32) | a2) >> sh);
+   out[3] = (uint32_t)((((uint64_t)a4 << 32) | a3) >> sh);
+}
 
 
 template <bool LDS_WIN>
@@ -564,7 +574,18 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       uint32_t *myring = mring + threadIdx.x;
       uint32_t cur = ZH_MIN_MATCH - 1;
       bool alive = false;
-      const uint32_t first4 = mine ? (LDS_WIN ? zh_load32_at(lwin32, i) : zh_ld32(win + i)) : 0;
+      // the lane's own first 16 bytes stay in registers: a candidate's match length up to 16 (most are shorter) then costs
+      // one round of five LDS reads instead of a dependent pair of reads per four bytes — the walk is where the kernel's
+      // time goes (80 % of its wave-cycles on text), and in the walk it is these length computations, serialised over the
+      // lanes that have one, that take it (measured: 2000 cycles per walk step)
+      uint32_t own16[4] = {0, 0, 0, 0};
+      if (mine) {
+         if (LDS_WIN)
+            zh_load128_at(lwin32, i, own16);
+         else
+            own16[0] = zh_ld32(win + i);
+      }
+      const uint32_t first4 = own16[0];
       bool has4 = false;
       uint32_t d4 = 0xffffu, d5 = 0xffffu;
       if (mine) {
@@ -705,8 +726,17 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       if ((LDS_WIN ? zh_load32_at(lwin32, (Q) + fo) : zh_ld32(win + (Q) + fo)) == ci) {                           \
          uint32_t l = 0;                                                                                          \
          if (LDS_WIN) {                                                                                           \
-            /* four bytes per probe pair; bytes past the window end are garbage but l is clamped to maxlen */     \
-            while (l < maxlen) {                                                                                  \
+            /* bytes past the window end are garbage but l is clamped to maxlen */                                 \
+            uint32_t c16_[4];                                                                                     \
+            zh_load128_at(lwin32, (Q), c16_);                                                                     \
+            const uint32_t x0_ = c16_[0] ^ own16[0], x1_ = c16_[1] ^ own16[1], x2_ = c16_[2] ^ own16[2], x3_ = c16_[3] ^ own16[3]; \
+            if (x0_) l = (uint32_t)(__ffs((int)x0_) - 1) >> 3;                                                    \
+            else if (x1_) l = 4u + ((uint32_t)(__ffs((int)x1_) - 1) >> 3);                                        \
+            else if (x2_) l = 8u + ((uint32_t)(__ffs((int)x2_) - 1) >> 3);                                        \
+            else if (x3_) l = 12u + ((uint32_t)(__ffs((int)x3_) - 1) >> 3);                                       \
+            else l = 16;                                                                                          \
+            /* beyond 16: four bytes per probe pair */                                                            \
+            while (l >= 16 && l < maxlen) {                                                                       \
                const uint32_t x = zh_load32_at(lwin32, (Q) + l) ^ zh_load32_at(lwin32, i + l);                    \
                if (x) {                                                                                           \
                   l += (uint32_t)(__ffs((int)x) - 1) >> 3;                                                        \
