@@ -423,15 +423,6 @@ __device__ __forceinline__ uint32_t zh_load32_at(const uint32_t *w32, uint32_t x
    const uint32_t sh = (x & 3u) * 8u;
    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
 }
-// number of leading bytes (0..16) in which the 16-byte strings c and o agree
-__device__ __forceinline__ uint32_t zh_len16(const uint32_t c[4], const uint32_t o[4]) {
-   const uint32_t x0 = c[0] ^ o[0], x1 = c[1] ^ o[1], x2 = c[2] ^ o[2], x3 = c[3] ^ o[3];
-   if (x0) return (uint32_t)(__ffs((int)x0) - 1) >> 3;
-   if (x1) return 4u + ((uint32_t)(__ffs((int)x1) - 1) >> 3);
-   if (x2) return 8u + ((uint32_t)(__ffs((int)x2) - 1) >> 3);
-   if (x3) return 12u + ((uint32_t)(__ffs((int)x3) - 1) >> 3);
-   return 16u;
-}
 // the 16 bytes at byte offset x: five aligned words, all in flight together
 __device__ __forceinline__ void zh_load128_at(const uint32_t *w32, uint32_t x, uint32_t out[4]) {
    const uint32_t *p = w32 + (x >> 2);
@@ -731,23 +722,42 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       // most, the 4-byte probe nearly all of the rest, the survivors get their true match length from byte 0 (an
       // entry of a neighbouring class met after the class head fails there). Both probes of an
       // iteration are issued before either is used; a probe taken before `cur` grew stays a valid pre-filter.
-      // match length of candidate Q beyond its first 16 bytes (four bytes per probe pair; bytes past the window end are garbage
-      // but lengths are clamped to maxlen)
-#define ZH_MF_EXTEND(Q, l)                                                                                        \
-      while ((l) >= 16 && (l) < maxlen) {                                                                         \
-         const uint32_t x = zh_load32_at(lwin32, (Q) + (l)) ^ zh_load32_at(lwin32, i + (l));                      \
-         if (x) {                                                                                                 \
-            (l) += (uint32_t)(__ffs((int)x) - 1) >> 3;                                                            \
-            break;                                                                                                \
+#define ZH_MF_VERIFY(Q, D)                                                                                        \
+      if ((LDS_WIN ? zh_load32_at(lwin32, (Q) + fo) : zh_ld32(win + (Q) + fo)) == ci) {                           \
+         uint32_t l = 0;                                                                                          \
+         if (LDS_WIN) {                                                                                           \
+            /* bytes past the window end are garbage but l is clamped to maxlen */                                 \
+            uint32_t c16_[4];                                                                                     \
+            zh_load128_at(lwin32, (Q), c16_);                                                                     \
+            const uint32_t x0_ = c16_[0] ^ own16[0], x1_ = c16_[1] ^ own16[1], x2_ = c16_[2] ^ own16[2], x3_ = c16_[3] ^ own16[3]; \
+            if (x0_) l = (uint32_t)(__ffs((int)x0_) - 1) >> 3;                                                    \
+            else if (x1_) l = 4u + ((uint32_t)(__ffs((int)x1_) - 1) >> 3);                                        \
+            else if (x2_) l = 8u + ((uint32_t)(__ffs((int)x2_) - 1) >> 3);                                        \
+            else if (x3_) l = 12u + ((uint32_t)(__ffs((int)x3_) - 1) >> 3);                                       \
+            else l = 16;                                                                                          \
+            /* beyond 16: four bytes per probe pair */                                                            \
+            while (l >= 16 && l < maxlen) {                                                                       \
+               const uint32_t x = zh_load32_at(lwin32, (Q) + l) ^ zh_load32_at(lwin32, i + l);                    \
+               if (x) {                                                                                           \
+                  l += (uint32_t)(__ffs((int)x) - 1) >> 3;                                                        \
+                  break;                                                                                          \
+               }                                                                                                  \
+               l += 4;                                                                                            \
+            }                                                                                                     \
+            l = min(l, maxlen);                                                                                   \
          }                                                                                                        \
-         (l) += 4;                                                                                                \
-      }
-#define ZH_MF_ACCEPT(l, D)                                                                                        \
-      if ((l) > cur) {                                                                                            \
-         myring[(nm & 7u) * ZH_MF_THREADS] = (l) | ((D) << 16); /* offset 32768 needs all 16 bits */              \
-         nm++;                                                                                                    \
-         cur = (l);                                                                                               \
-         grew = true;                                                                                             \
+         else {                                                                                                   \
+            while (l < maxlen && win[(Q) + l] == win[i + l]) l++;                                                 \
+         }                                                                                                        \
+         if (l > cur) {                                                                                           \
+            myring[(nm & 7u) * ZH_MF_THREADS] = l | ((D) << 16); /* offset 32768 needs all 16 bits */            \
+            nm++;                                                                                                 \
+            cur = l;                                                                                              \
+            if (cur < maxlen) {                                                                                   \
+               fo = cur - 3;                                                                                      \
+               ci = LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo);                               \
+            }                                                                                                     \
+         }                                                                                                        \
       }
 
       while (zh_ballot(alive)) {
@@ -771,40 +781,13 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
             const uint32_t pb1 = LDS_WIN ? zh_load32_at(lwin32, a1) : zh_ld32(win + a1);
             const uint32_t pb2 = LDS_WIN ? zh_load32_at(lwin32, a2) : zh_ld32(win + a2);
             const uint32_t tgt = ci;
-            // The survivors of both probes get their lengths in ONE divergent region, both 16-byte loads in flight together:
-            // which lanes have a survivor differs from step to step, so nearly every step pays this latency once (not twice).
-            const bool v1 = ok1 && pb1 == tgt, v2 = ok2 && pb2 == tgt;
-            if (v1 || v2) {
-               uint32_t l1 = 0, l2 = 0;
-               if (LDS_WIN) {
-                  uint32_t a16[4], b16[4];
-                  zh_load128_at(lwin32, v1 ? q1 : i, a16);
-                  zh_load128_at(lwin32, v2 ? q2 : i, b16);
-                  l1 = zh_len16(a16, own16);
-                  l2 = zh_len16(b16, own16);
-                  if (v1) { ZH_MF_EXTEND(q1, l1) }
-                  if (v2) { ZH_MF_EXTEND(q2, l2) }
-               }
-               else {
-                  if (v1) while (l1 < maxlen && win[q1 + l1] == win[i + l1]) l1++;
-                  if (v2) while (l2 < maxlen && win[q2 + l2] == win[i + l2]) l2++;
-               }
-               l1 = v1 ? min(l1, maxlen) : 0u;
-               l2 = v2 ? min(l2, maxlen) : 0u;
-               bool grew = false;
-               ZH_MF_ACCEPT(l1, d1)
-               ZH_MF_ACCEPT(l2, d2)
-               if (grew && cur < maxlen) {
-                  fo = cur - 3;
-                  ci = LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo);
-               }
-            }
+            if (ok1 && pb1 == tgt) { ZH_MF_VERIFY(q1, d1) }
+            if (ok2 && pb2 == tgt && cur < maxlen) { ZH_MF_VERIFY(q2, d2) }
             // the class ends at its head; beyond 32 KiB everything else is farther still; 258 (or the window end) cannot be beaten
             alive = ok1 && ok2 && !((c1 | c2) & ZH_MF_HEAD) && cur < maxlen;
          }
       }
-#undef ZH_MF_EXTEND
-#undef ZH_MF_ACCEPT
+#undef ZH_MF_VERIFY
       if (mine) {
          // rows are longest first: the ring read backwards from the last accepted match
          uint32_t m[8];
