@@ -62,6 +62,8 @@ struct zultra_hip_ctx_s {
    uint32_t *d_tok_pos;
    uint16_t *d_tok_info;
    uint32_t *d_ntok, *d_split_tok, *d_split_cnt, *d_sub_base;
+   uint32_t *d_chunkmax, *d_spanstart, *d_spancnt;   // per chunk of ZH_TOK_CHUNK positions (zh_split.h: barriers and token chain)
+   uint32_t chunks_per_block;
    uint32_t *d_best;
    zh_work_t *d_work;
    zh_subblock_t *d_results;
@@ -262,6 +264,9 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_tok_pos);
    (void)hipFree(c->d_tok_info);
    (void)hipFree(c->d_ntok);
+   (void)hipFree(c->d_chunkmax);
+   (void)hipFree(c->d_spanstart);
+   (void)hipFree(c->d_spancnt);
    (void)hipFree(c->d_split_tok);
    (void)hipFree(c->d_split_cnt);
    (void)hipFree(c->d_sub_base);
@@ -351,7 +356,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
        zh_alloc(c, &c->d_tok_pos, B * c->tok_stride) || zh_alloc(c, &c->d_tok_info, B * c->tok_stride) ||
-       zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_split_tok, B * (ZH_MAX_SPLITS + 1)) || zh_alloc(c, &c->d_split_cnt, B) ||
+       zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_chunkmax, B * c->chunks_per_block) || zh_alloc(c, &c->d_spanstart, B * c->chunks_per_block) ||
+       zh_alloc(c, &c->d_spancnt, B * c->chunks_per_block) || zh_alloc(c, &c->d_split_tok, B * (ZH_MAX_SPLITS + 1)) || zh_alloc(c, &c->d_split_cnt, B) ||
        zh_alloc(c, &c->d_sub_base, B) || zh_alloc(c, &c->d_best, B * c->best_stride) || zh_alloc(c, &c->d_work, B * c->max_subs) ||
        zh_alloc(c, &c->d_results, B * c->max_subs) || zh_alloc(c, &c->d_payload, B * c->slot_stride) ||
        zh_alloc(c, &c->d_items, B * c->max_subs) || zh_alloc(c, &c->d_crc, B) || zh_alloc(c, &c->d_adler, 2 * B) || zh_alloc(c, &c->d_crc_tables, 256 + 1024))
@@ -404,6 +410,7 @@ static zultra_hip_ctx_t *zh_create(int device, uint32_t max_block, uint32_t max_
    c->run_stride = c->sort_stride + 576;   // start[Q] length[Q] first[256] end[256] count, Q = W/4 + 1
    c->match_stride = (uint64_t)c->max_block * ZH_NMATCH;
    c->tok_stride = ((uint64_t)c->max_block + 63) & ~63ull;
+   c->chunks_per_block = (c->max_block + ZH_TOK_CHUNK - 1) / ZH_TOK_CHUNK;
    c->best_stride = c->tok_stride;
    c->slot_stride = (((uint64_t)c->max_block + 64 * c->max_subs + 64) + 63) & ~63ull;
    c->data_cap = (size_t)c->W + (size_t)(max_blocks - 1) * c->max_block;
@@ -478,6 +485,22 @@ static int zh_build_segments(zultra_hip_ctx_t *c, const zultra_hip_block_t *bloc
    return 0;
 }
 
+// barrier bitmap and greedy token chain of `nb` max-blocks starting at batch block b0, in chunks (zh_split.h)
+static int zh_enqueue_tokenize(zultra_hip_ctx_t *c, hipStream_t st, const zh_block_t *blk, uint32_t b0, uint32_t nb) {
+   const uint32_t cpb = c->chunks_per_block;
+   const zh_match_t *match = c->d_match + (uint64_t)b0 * c->match_stride;
+   uint64_t *bars = c->d_bars + (uint64_t)b0 * c->bar_stride;
+   uint32_t *tp = c->d_tok_pos + (uint64_t)b0 * c->tok_stride;
+   uint16_t *ti = c->d_tok_info + (uint64_t)b0 * c->tok_stride;
+   uint32_t *cmax = c->d_chunkmax + (uint64_t)b0 * cpb, *sstart = c->d_spanstart + (uint64_t)b0 * cpb, *scnt = c->d_spancnt + (uint64_t)b0 * cpb;
+   ZH_LAUNCH(zh_barriers, nb * cpb, 64, st, blk, match, c->match_stride, bars, c->bar_stride, cmax, cpb);
+   if (cpb > 1) ZH_LAUNCH(zh_barriers_fix, (nb + 63) / 64, 64, st, blk, nb, bars, c->bar_stride, (const uint32_t *)cmax, cpb);
+   ZH_LAUNCH(zh_tokenize_spans, nb * cpb, 64, st, c->cur_data, blk, match, c->match_stride, tp, ti, c->tok_stride, (const uint64_t *)bars, c->bar_stride, sstart, scnt,
+             cpb);
+   ZH_LAUNCH(zh_tokens_compact, nb, ZH_COMPACT_THREADS, st, blk, tp, ti, c->tok_stride, (const uint32_t *)sstart, (const uint32_t *)scnt, cpb, c->d_ntok + b0);
+   return 0;
+}
+
 // files mode: what zh_split would report for an input below its 8192-byte threshold — one sub-block spanning all tokens
 __global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, uint32_t *split_tok, uint32_t *split_cnt, uint32_t *sub_base) {
    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -498,8 +521,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
              c->run_stride, 0, nb, c->d_chunk_ctr + (size_t)nb * 2 + 1);
    ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, (const zh_seg_t *)c->d_segs, (const uint32_t *)c->d_sort_a,
              (const uint2 *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
-   ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, c->d_tok_pos, c->d_tok_info, c->tok_stride, c->d_ntok,
-             c->d_bars, c->bar_stride);
+   if (zh_enqueue_tokenize(c, st, blk, 0, nb) != 0) return -1;
    ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
    ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 8 * sizeof(uint32_t), st));
    ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, (size_t)nb * c->slot_stride, st));
@@ -659,9 +681,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint2 *)p3, (const uint32_t *)rn,
                 c->sort_stride, c->run_stride, c->d_match, c->match_stride, ctr, nsg, 1u);
       ZH_CHECK(c, hipEventRecord(ev[3], st));
-      ZH_LAUNCH(zh_tokenize, nb, 64, st, c->cur_data, blk, (const zh_match_t *)(c->d_match + b0 * c->match_stride), c->match_stride,
-                c->d_tok_pos + b0 * c->tok_stride, c->d_tok_info + b0 * c->tok_stride, c->tok_stride, c->d_ntok + b0, c->d_bars + b0 * c->bar_stride,
-                c->bar_stride);
+      if (zh_enqueue_tokenize(c, st, blk, b0, nb) != 0) return -1;
       ZH_LAUNCH(zh_split, nb, ZH_SPLIT_THREADS, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride),
                 c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0);
       ZH_CHECK(c, hipMemcpyAsync(c->h_split_cnt + b0, c->d_split_cnt + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

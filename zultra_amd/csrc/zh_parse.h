@@ -77,20 +77,6 @@ struct zh_sbstate_t {
    uint32_t pad[3];
 };
 
-// first barrier at or after block-relative position r, limited to rend (returns rend if there is none before it)
-__device__ inline uint32_t zh_first_barrier(const uint64_t *bar, uint32_t r, uint32_t rend) {
-   if (r >= rend) return rend;
-   uint32_t w = r >> 6;
-   const uint32_t wend = (rend + 63) >> 6;
-   uint64_t m = bar[w] & (~0ull << (r & 63));
-   while (!m) {
-      if (++w >= wend) return rend;
-      m = bar[w];
-   }
-   const uint32_t q = w * 64 + (uint32_t)zh_ctz64(m);
-   return q < rend ? q : rend;
-}
-
 // boundary j of a sub-block's task list (window positions): 0 -> start, ntasks -> end
 __device__ inline uint32_t zh_task_boundary(const uint64_t *bar, uint32_t prev, uint32_t start, uint32_t end, uint32_t j, uint32_t ntasks) {
    if (j == 0) return start;

@@ -48,74 +48,185 @@ __device__ inline uint32_t zh_wave_incl_max(uint32_t v) {
    return v;
 }
 
-// Also produces the barrier bitmap of the max-block (zh_parse.h): bit r of bars is set when every match that starts
-// at a block position < r ends at or before r, i.e. when the running maximum of (r' + max(longest length at r', 1))
-// over r' < r equals r. Position 0 is a barrier by definition.
-__global__ void __launch_bounds__(64)
-zh_tokenize(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
-            const zh_match_t *__restrict__ match, uint64_t match_stride, uint32_t *tok_pos, uint16_t *tok_info,
-            uint64_t tok_stride, uint32_t *ntok_out, uint64_t *bars, uint64_t bar_stride) {
-   const zh_block_t blk = blocks[blockIdx.x];
-   const uint8_t *win = data + blk.win_off;
-   const uint32_t *rows = (const uint32_t *)(match + (uint64_t)blockIdx.x * match_stride);
-   uint32_t *tp = tok_pos + (uint64_t)blockIdx.x * tok_stride;
-   uint16_t *ti = tok_info + (uint64_t)blockIdx.x * tok_stride;
-   const uint32_t lane = zh_lane();
-   const uint32_t n = blk.n;
-   uint64_t *bar = bars + (uint64_t)blockIdx.x * bar_stride;
-   uint32_t ntok = 0, carry = 0;
-   uint32_t reach_before = 0;   // running maximum over all earlier tiles
+// first barrier at or after block-relative position r, limited to rend (returns rend if there is none before it)
+__device__ inline uint32_t zh_first_barrier(const uint64_t *bar, uint32_t r, uint32_t rend) {
+   if (r >= rend) return rend;
+   uint32_t w = r >> 6;
+   const uint32_t wend = (rend + 63) >> 6;
+   uint64_t m = bar[w] & (~0ull << (r & 63));
+   while (!m) {
+      if (++w >= wend) return rend;
+      m = bar[w];
+   }
+   const uint32_t q = w * 64 + (uint32_t)zh_ctz64(m);
+   return q < rend ? q : rend;
+}
 
-   // The chain is one wave per max-block, so nothing hides a load's latency but the wave itself: the rows of four tiles are
-   // in flight while one is processed (without that every tile paid a full HBM round trip: 3.2 ms per launch).
-   uint32_t pm[4], pb[4];
+// ---------------------------------------------------------------------------------------------------------
+// Barriers and the token chain, in chunks of ZH_TOK_CHUNK positions (a max-block of the reference's default size, 1 MiB,
+// would otherwise be one wave following one chain: 40 ms per 100 MB).
+//   zh_barriers        one wave per chunk: bit r of the barrier bitmap (zh_parse.h) is set when every match that starts at a
+//                      block position < r ends at or before r, i.e. when the running maximum of (r' + max(longest length at
+//                      r', 1)) over r' < r is <= r. A chunk computes it from its own positions and reports its maximum;
+//   zh_barriers_fix    what earlier chunks reach into a chunk (at most 257 positions) clears the bits below it;
+//   zh_tokenize_spans  every parse has a token boundary at a barrier, so the chain restarts exactly at the first barrier at
+//                      or after each chunk start: one wave per span, tokens staged at the span's position offset;
+//   zh_tokens_compact  one workgroup per max-block moves the spans' tokens together (in place: they only move down).
+#ifndef ZH_TOK_CHUNK
+#define ZH_TOK_CHUNK 16384u   // a multiple of 64 (the emulator build uses 1024, so that its small test windows span several chunks)
+#endif
+
+__global__ void __launch_bounds__(64)
+zh_barriers(const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride, uint64_t *bars, uint64_t bar_stride,
+            uint32_t *chunkmax, uint32_t cpb) {
+   const uint32_t b = blockIdx.x / cpb, c = blockIdx.x - b * cpb;
+   const zh_block_t blk = blocks[b];
+   const uint32_t n = blk.n, lo = c * ZH_TOK_CHUNK;
+   if (lo >= n) return;
+   const uint32_t hi = min(n, lo + ZH_TOK_CHUNK);
+   const uint32_t *rows = (const uint32_t *)(match + (uint64_t)b * match_stride);
+   uint64_t *bar = bars + (uint64_t)b * bar_stride;
+   const uint32_t lane = zh_lane();
+   uint32_t reach_before = 0;   // running maximum over the chunk's earlier tiles
+   uint32_t pm[4];              // the rows of four tiles are in flight while one is processed
 #pragma unroll
    for (uint32_t u = 0; u < 4; u++) {
-      const uint32_t r = u * 64 + lane;
-      pm[u] = 0;
-      pb[u] = 0;
-      if (r < n) {
-         pm[u] = rows[(uint64_t)r * ZH_NMATCH];   // slot 0 = longest match (matchfinder.c:221)
-         pb[u] = win[blk.prev + r];
-      }
+      const uint32_t r = lo + u * 64 + lane;
+      pm[u] = r < hi ? rows[(uint64_t)r * ZH_NMATCH] : 0u;   // slot 0 = longest match (matchfinder.c:221)
    }
-   for (uint32_t base4 = 0; base4 < n; base4 += 256) {
+   for (uint32_t base4 = lo; base4 < hi; base4 += 256) {
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
          const uint32_t base = base4 + u * 64;
-         if (base >= n) break;
-         const uint32_t limit = min(64u, n - base);
+         if (base >= hi) break;
+         const uint32_t r = base + lane;
+         const uint32_t len = pm[u] & 0xffffu;
+         pm[u] = r + 256 < hi ? rows[(uint64_t)(r + 256) * ZH_NMATCH] : 0u;
+         const uint32_t incl = zh_wave_incl_max(r < hi ? r + max(len, 1u) : 0u);
+         const uint32_t up = zh_shfl(incl, (int)((lane - 1) & 63));
+         const uint32_t excl = lane ? max(reach_before, up) : reach_before;
+         const uint64_t bm = zh_ballot(r < hi && excl <= r);
+         if (lane == 0) bar[base >> 6] = bm;
+         reach_before = max(reach_before, zh_readlane(incl, 63));
+      }
+   }
+   if (lane == 0) chunkmax[blockIdx.x] = reach_before;
+}
+
+__global__ void zh_barriers_fix(const zh_block_t *__restrict__ blocks, uint32_t nblocks, uint64_t *bars, uint64_t bar_stride, const uint32_t *__restrict__ chunkmax,
+                                uint32_t cpb) {
+   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+   if (b >= nblocks) return;
+   const uint32_t n = blocks[b].n;
+   uint64_t *bar = bars + (uint64_t)b * bar_stride;
+   uint32_t reach = 0;
+   for (uint32_t c = 1; c * ZH_TOK_CHUNK < n; c++) {
+      reach = max(reach, chunkmax[b * cpb + c - 1]);
+      const uint32_t lo = c * ZH_TOK_CHUNK;   // positions lo .. reach-1 have a match crossing them (reach <= lo + 257)
+      for (uint32_t w = lo >> 6; w * 64 < min(reach, n); w++) {
+         const uint32_t keep_from = reach - w * 64;   // bits below it are cleared
+         bar[w] &= keep_from >= 64 ? 0ull : (~0ull << keep_from);
+      }
+   }
+}
+
+__global__ void __launch_bounds__(64)
+zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
+                  uint32_t *tok_pos, uint16_t *tok_info, uint64_t tok_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride, uint32_t *spanstart,
+                  uint32_t *spancnt, uint32_t cpb) {
+   const uint32_t b = blockIdx.x / cpb, c = blockIdx.x - b * cpb;
+   const zh_block_t blk = blocks[b];
+   const uint32_t n = blk.n, lo = c * ZH_TOK_CHUNK;
+   const uint32_t lane = zh_lane();
+   const uint64_t *bar = bars + (uint64_t)b * bar_stride;
+   // the span of this chunk: from the first barrier at or after its start to the first barrier at or after its end
+   const uint32_t s0 = c == 0 ? 0u : zh_first_barrier(bar, lo, n);
+   const uint32_t s1 = (lo >= n || lo + ZH_TOK_CHUNK >= n) ? n : zh_first_barrier(bar, lo + ZH_TOK_CHUNK, n);
+   if (lo >= n || s0 >= s1) {
+      if (lane == 0) {
+         spanstart[blockIdx.x] = min(s0, n);
+         spancnt[blockIdx.x] = 0;
+      }
+      return;
+   }
+   const uint8_t *win = data + blk.win_off;
+   const uint32_t *rows = (const uint32_t *)(match + (uint64_t)b * match_stride);
+   uint32_t *tp = tok_pos + (uint64_t)b * tok_stride + s0;    // staged at the span's position offset (tokens <= positions)
+   uint16_t *ti = tok_info + (uint64_t)b * tok_stride + s0;
+   uint32_t ntok = 0, carry = 0;
+   uint32_t pm[4], pb[4];   // the rows of four tiles are in flight while one is processed
+#pragma unroll
+   for (uint32_t u = 0; u < 4; u++) {
+      const uint32_t r = s0 + u * 64 + lane;
+      pm[u] = 0;
+      pb[u] = 0;
+      if (r < s1) {
+         pm[u] = rows[(uint64_t)r * ZH_NMATCH];
+         pb[u] = win[blk.prev + r];
+      }
+   }
+   for (uint32_t base4 = s0; base4 < s1; base4 += 256) {
+#pragma unroll
+      for (uint32_t u = 0; u < 4; u++) {
+         const uint32_t base = base4 + u * 64;
+         if (base >= s1) break;
+         const uint32_t limit = min(64u, s1 - base);
          const uint32_t r = base + lane;
          const uint32_t m0 = pm[u], byte = pb[u];
-         {
-            const uint32_t nr = r + 256;
-            pm[u] = 0;
-            pb[u] = 0;
-            if (nr < n) {
-               pm[u] = rows[(uint64_t)nr * ZH_NMATCH];
-               pb[u] = win[blk.prev + nr];
-            }
+         pm[u] = 0;
+         pb[u] = 0;
+         if (r + 256 < s1) {
+            pm[u] = rows[(uint64_t)(r + 256) * ZH_NMATCH];
+            pb[u] = win[blk.prev + r + 256];
          }
          const uint32_t len = m0 & 0xffffu;
-         {
-            const uint32_t incl = zh_wave_incl_max(r < n ? r + max(len, 1u) : 0u);
-            const uint32_t up = zh_shfl(incl, (int)((lane - 1) & 63));
-            const uint32_t excl = lane ? max(reach_before, up) : reach_before;
-            const uint64_t bm = zh_ballot(r < n && excl <= r);
-            if (lane == 0) bar[base >> 6] = bm;
-            reach_before = max(reach_before, zh_readlane(incl, 63));
-         }
-         uint64_t mask = zh_chain_mask(len, carry, limit);
+         const uint64_t mask = zh_chain_mask(len, carry, limit);
          if ((mask >> lane) & 1ull) {
-            uint32_t idx = ntok + (uint32_t)zh_popc64(mask & ((1ull << lane) - 1));
-            uint32_t info = (len >= ZH_MIN_MATCH) ? ((257u + (uint32_t)zh_len_idx(len)) | ((uint32_t)zh_dist_sym(m0 >> 16) << 9)) : byte;
+            const uint32_t idx = ntok + (uint32_t)zh_popc64(mask & ((1ull << lane) - 1));
+            const uint32_t info = (len >= ZH_MIN_MATCH) ? ((257u + (uint32_t)zh_len_idx(len)) | ((uint32_t)zh_dist_sym(m0 >> 16) << 9)) : byte;
             tp[idx] = blk.prev + r;
             ti[idx] = (uint16_t)info;
          }
          ntok += (uint32_t)zh_popc64(mask);
       }
    }
-   if (lane == 0) ntok_out[blockIdx.x] = ntok;
+   if (lane == 0) {
+      spanstart[blockIdx.x] = s0;
+      spancnt[blockIdx.x] = ntok;
+   }
+}
+
+#define ZH_COMPACT_THREADS 256
+__global__ void __launch_bounds__(ZH_COMPACT_THREADS)
+zh_tokens_compact(const zh_block_t *__restrict__ blocks, uint32_t *tok_pos, uint16_t *tok_info, uint64_t tok_stride, const uint32_t *__restrict__ spanstart,
+                  const uint32_t *__restrict__ spancnt, uint32_t cpb, uint32_t *ntok_out) {
+   const uint32_t b = blockIdx.x, tid = threadIdx.x;
+   const uint32_t n = blocks[b].n;
+   uint32_t *tp = tok_pos + (uint64_t)b * tok_stride;
+   uint16_t *ti = tok_info + (uint64_t)b * tok_stride;
+   uint32_t total = 0;
+   for (uint32_t c = 0; c * ZH_TOK_CHUNK < n; c++) {
+      const uint32_t src = spanstart[b * cpb + c], m = spancnt[b * cpb + c];
+      if (m && src != total) {
+         // moving down in place: a step writes below what it has just read, and never above what later steps read
+         for (uint32_t off = 0; off < m; off += ZH_COMPACT_THREADS) {
+            const uint32_t k = off + tid;
+            uint32_t v = 0, w = 0;
+            if (k < m) {
+               v = tp[src + k];
+               w = ti[src + k];
+            }
+            __syncthreads();
+            if (k < m) {
+               tp[total + k] = v;
+               ti[total + k] = (uint16_t)w;
+            }
+            __syncthreads();
+         }
+      }
+      total += m;
+   }
+   if (tid == 0) ntok_out[b] = total;
 }
 
 // ---------------------------------------------------------------------------------------------------------
