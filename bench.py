@@ -184,7 +184,7 @@ def main():
         # per-kernel device times (HIP events on the library stream), averaged over the timed steps
         avg = {k: float(np.mean([t[k] for t in timings])) for k in timings[0]}
         kernels = {"zh_mf_group": avg["group_ms"], "zh_mf_frontier": avg["frontier_ms"],
-                   "zh_tokenize+zh_split": avg["tokenize_split_ms"], "zh_plan_subblocks+zh_sb_init": avg["init_ms"],
+                   "zh_barriers+zh_tokenize_spans+zh_split": avg["tokenize_split_ms"], "zh_plan_subblocks+zh_sb_init": avg["init_ms"],
                    "zh_parse_tasks+zh_parse_huge": avg["parse_ms"], "zh_sb_build": avg["build_ms"], "zh_post_tasks": avg["post_ms"],
                    "zh_emit_tasks": avg["emit_ms"], "zh_stitch": avg["stitch_ms"]}
         # the library runs a batch as `runs` staggered runs of max-blocks on separate streams (ZULTRA_HIP_STREAMS, default 2):

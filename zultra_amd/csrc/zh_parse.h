@@ -8,7 +8,7 @@
 // right of q, so the choices left of q depend on cost[q] only through an additive constant — restarting the recurrence
 // with cost[q] = 0 reproduces the reference's choices bit for bit (all comparisons are between sums that share the
 // constant); and (2) every parse, greedy or optimal, has a token boundary at q (a token starting before q cannot
-// jump over it). zh_tokenize computes the barrier bitmap of each max-block with one running prefix-max of
+// jump over it). zh_barriers (zh_split.h) computes the barrier bitmap of each max-block with a running prefix-max of
 // (position + longest length). On text a barrier falls every ~35 positions; on highly repetitive data they are rare
 // and the parse degrades gracefully to one serial chain per run.
 //

@@ -7,7 +7,7 @@
 // splitter's scan at each recursion level, the "left part" histograms, the per-sub-block initial entropy —
 // starts on a token boundary of the walk that started at the block start, because recursion ranges begin
 // at checkpoints and checkpoints are token ends. So there is exactly ONE greedy token chain per max-block.
-//   zh_tokenize  materialises it once (token position + packed symbols), 64 positions per step: the match
+//   zh_tokenize_spans  materialises it once (token position + packed symbols), 64 positions per step: the match
 //                lengths of a tile sit in one VGPR, the chain is followed on the scalar unit with
 //                v_readlane, and token lanes compact their record with a ballot prefix.
 //   zh_split     then works on token ranges: histograms are lane-parallel LDS atomics over tokens, the
