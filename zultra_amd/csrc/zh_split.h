@@ -209,17 +209,26 @@ zh_tokens_compact(const zh_block_t *__restrict__ blocks, uint32_t *tok_pos, uint
       const uint32_t src = spanstart[b * cpb + c], m = spancnt[b * cpb + c];
       if (m && src != total) {
          // moving down in place: a step writes below what it has just read, and never above what later steps read
-         for (uint32_t off = 0; off < m; off += ZH_COMPACT_THREADS) {
-            const uint32_t k = off + tid;
-            uint32_t v = 0, w = 0;
-            if (k < m) {
-               v = tp[src + k];
-               w = ti[src + k];
+         for (uint32_t off = 0; off < m; off += 8 * ZH_COMPACT_THREADS) {   // eight elements per thread in flight
+            uint32_t v[8], w[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+               const uint32_t k = off + u * ZH_COMPACT_THREADS + tid;
+               v[u] = 0;
+               w[u] = 0;
+               if (k < m) {
+                  v[u] = tp[src + k];
+                  w[u] = ti[src + k];
+               }
             }
             __syncthreads();
-            if (k < m) {
-               tp[total + k] = v;
-               ti[total + k] = (uint16_t)w;
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+               const uint32_t k = off + u * ZH_COMPACT_THREADS + tid;
+               if (k < m) {
+                  tp[total + k] = v[u];
+                  ti[total + k] = (uint16_t)w[u];
+               }
             }
             __syncthreads();
          }
