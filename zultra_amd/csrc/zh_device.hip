@@ -682,8 +682,14 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 c->sort_stride, c->run_stride, c->d_match, c->match_stride, ctr, nsg, 1u);
       ZH_CHECK(c, hipEventRecord(ev[3], st));
       if (zh_enqueue_tokenize(c, st, blk, b0, nb) != 0) return -1;
-      ZH_LAUNCH(zh_split, nb, ZH_SPLIT_THREADS, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride),
-                c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0);
+      if (c->max_block > 131072) {
+         ZH_LAUNCH(zh_split<16>, nb, 64 * 16, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride),
+                   c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0);
+      }
+      else {
+         ZH_LAUNCH(zh_split<8>, nb, 64 * 8, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride),
+                   c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0);
+      }
       ZH_CHECK(c, hipMemcpyAsync(c->h_split_cnt + b0, c->d_split_cnt + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipEventRecord(ev[4], st));
    }

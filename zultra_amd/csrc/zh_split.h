@@ -315,6 +315,7 @@ __device__ inline void zh_token_histogram_wave(const uint16_t *ti, uint32_t t0, 
 
 // Search the best split of token range [t0, t1) (blockdeflate.c:659-773). Returns the token index of the
 // split boundary, or 0xFFFFFFFF. All threads of the workgroup call; uniform result.
+template <int WAVES>
 __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wave_ws_t *ws, const uint32_t *tp, const uint16_t *ti, uint32_t t0,
                                               uint32_t t1, uint32_t start_pos, uint32_t end_pos) {
    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -340,11 +341,11 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
       const uint32_t nj = min((uint32_t)ZH_SPLIT_MAXCP, ncp - j0);
       __syncthreads();   // the previous chunk's statistics have been read
       // 18-bin statistics of every interval of the chunk: interval j = tokens [c(j-1), c(j)), c(-1) = t0, c(j) = c0 + 256 j
-      for (uint32_t k = tid; k < nj * 18; k += ZH_SPLIT_THREADS) sh->fresh[k / 18][k % 18] = 0;
-      for (uint32_t k = tid; k < nj; k += ZH_SPLIT_THREADS) sh->gain[k] = 0;
+      for (uint32_t k = tid; k < nj * 18; k += (64u * WAVES)) sh->fresh[k / 18][k % 18] = 0;
+      for (uint32_t k = tid; k < nj; k += (64u * WAVES)) sh->gain[k] = 0;
       if (tid == 0) sh->next_eval = 0;
       __syncthreads();
-      for (uint32_t jj = wave; jj < nj; jj += ZH_SPLIT_WAVES) {
+      for (uint32_t jj = wave; jj < nj; jj += (uint32_t)WAVES) {
          const uint32_t j = j0 + jj;
          const uint32_t lo = j == 0 ? t0 : c0 + 256 * (j - 1), hi = c0 + 256 * j;
          for (uint32_t t = lo + lane; t < hi; t += 64) {
@@ -378,10 +379,10 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
       if (!have_total) {
          // histogram of the whole range (all waves), its price (wave 0 alone, while the others start on the evaluations)
          have_total = true;
-         for (uint32_t s = tid; s < ZH_NLIT; s += ZH_SPLIT_THREADS) sh->tot_lit[s] = 0;
+         for (uint32_t s = tid; s < ZH_NLIT; s += (64u * WAVES)) sh->tot_lit[s] = 0;
          if (tid < ZH_NDIST) sh->tot_dist[tid] = 0;
          __syncthreads();
-         for (uint32_t t = t0 + tid; t < t1; t += ZH_SPLIT_THREADS) {
+         for (uint32_t t = t0 + tid; t < t1; t += (64u * WAVES)) {
             const uint32_t info = ti[t];
             const uint32_t s = ZH_TOK_SYM(info);
             atomicAdd(&sh->tot_lit[s], 1);
@@ -469,11 +470,14 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
 }
 
 // Output: split_tok[b*65 + k] token boundaries (k = 0..count, first = 0, last = ntok), split_cnt[b] = number of sub-blocks.
-__global__ void __launch_bounds__(ZH_SPLIT_THREADS)
+// WAVES = 8 measured best for 64 KiB max-blocks (4: +70 %, 16: +35 %); large max-blocks are few and their searches trigger
+// hundreds of evaluations, there 16 waves win
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
 zh_split(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ tok_pos, const uint16_t *__restrict__ tok_info,
          uint64_t tok_stride, const uint32_t *__restrict__ ntok_in, uint32_t *split_tok, uint32_t *split_cnt) {
    __shared__ zh_split_shared_t sh;
-   __shared__ zh_split_wave_ws_t wws[ZH_SPLIT_WAVES];
+   __shared__ zh_split_wave_ws_t wws[WAVES];
    zh_split_wave_ws_t *ws = &wws[threadIdx.x >> 6];
    const zh_block_t blk = blocks[blockIdx.x];
    const uint32_t *tp = tok_pos + (uint64_t)blockIdx.x * tok_stride;
@@ -503,7 +507,7 @@ zh_split(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ tok
             sp--;
             continue;
          }
-         const uint32_t b = zh_split_search_wg(&sh, ws, tp, ti, t0, t1, p0, p1);
+         const uint32_t b = zh_split_search_wg<WAVES>(&sh, ws, tp, ti, t0, t1, p0, p1);
          if (b == 0xFFFFFFFFu) {
             sp--;
             continue;
