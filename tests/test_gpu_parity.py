@@ -244,3 +244,12 @@ def test_full_size_properties_mixed_zlib_32k(gpu, oracle):
     for blk in (1, 100, 333, 511):
         lo = blk * 32768
         check_window(gpu, oracle, d[lo - 32768: lo + 32768], 32768, 32768, max_block=32768, tag="mixed_blk%d" % blk)
+
+
+def test_two_mib_max_block_of_real_text_stage_by_stage(gpu, oracle):
+    # the largest max-block the API allows (libzultra.c:91), source code: 128 chunks of the barrier / token kernels, 33
+    # matchfinder segments, the 16-wave splitter, tasks with barrier-free runs — every stage against the oracle
+    d = _image_files("/usr/lib/python3*/**/*.py", 3_300_000)
+    if len(d) < 3_300_000:
+        pytest.skip("not enough Python sources in this image")
+    check_window(gpu, oracle, d[1_100_000:], 32768, 2 << 20, max_block=2 << 20, tag="pysrc_2MiB")
