@@ -252,4 +252,4 @@ def test_two_mib_max_block_of_real_text_stage_by_stage(gpu, oracle):
     d = _image_files("/usr/lib/python3*/**/*.py", 3_300_000)
     if len(d) < 3_300_000:
         pytest.skip("not enough Python sources in this image")
-    check_window(gpu, oracle, d[1_100_000:], 32768, 2 << 20, max_block=2 << 20, tag="pysrc_2MiB")
+    check_window(gpu, oracle, d[1_100_000:1_100_000 + 32768 + (2 << 20)], 32768, 2 << 20, max_block=2 << 20, tag="pysrc_2MiB")
