@@ -326,14 +326,14 @@ __device__ inline void zh_cl_tokenize(const uint8_t *lens, int n, unsigned mask,
    }
 }
 
-// The same tokenizer over a precomputed run list (entry = value | run length << 4, runs of equal code lengths <= 15): the
+// The same tokenizer over a precomputed run list (entry = value | run length << 6, runs of equal code lengths <= 63): the
 // symbol-by-symbol version above rescans the rest of a run after every token it emits; on the run list every step emits
 // a token. Each iteration of the outer loops below is one iteration of the loop above applied to what is left of the run.
 template <typename Sink>
 __device__ inline void zh_cl_tokenize_runs(const uint16_t *runs, int nruns, unsigned mask, Sink &sink) {
    for (int q = 0; q < nruns; q++) {
-      const int v = runs[q] & 15;
-      int run = runs[q] >> 4;
+      const int v = runs[q] & 63;
+      int run = runs[q] >> 6;
       if (v == 0) {
          while (run > 0) {
             if (run >= 3) {
@@ -389,7 +389,8 @@ __device__ inline int zh_cl_make_runs(const uint8_t *lens, int n, uint16_t *runs
       const int v = lens[i];
       int run = 1;
       while (i + run < n && lens[i + run] == v) run++;
-      runs[nruns++] = (uint16_t)(v | (run << 4));   // v <= 15, run <= 320
+      // v <= 63 (the cost estimates price unlimited lengths: a 2 MiB sub-block of text reaches depth 20), run <= 320
+      runs[nruns++] = (uint16_t)(v | (run << 6));
       i += run;
    }
    return nruns;
