@@ -253,3 +253,21 @@ def test_two_mib_max_block_of_real_text_stage_by_stage(gpu, oracle):
     if len(d) < 3_300_000:
         pytest.skip("not enough Python sources in this image")
     check_window(gpu, oracle, d[1_100_000:1_100_000 + 32768 + (2 << 20)], 32768, 2 << 20, max_block=2 << 20, tag="pysrc_2MiB")
+
+
+@pytest.mark.parametrize("kind,flags,bs", [("x86", 1, 2 << 20), ("mixed", 2, 0), ("near_copies", 0, 262144), ("json", 2, 1 << 20)])
+def test_large_max_blocks_streams_vs_oracle(gpu, oracle, kind, flags, bs):
+    """Max-blocks of 256 KiB .. 2 MiB (the reference's default is 1 MiB): many matchfinder segments and token-chain chunks
+    per block, sub-blocks of a megabyte and more (deep unlimited Huffman trees in the cost estimates), the 16-wave splitter."""
+    if kind == "x86":
+        d = _image_files("/usr/lib/x86_64-linux-gnu/*.so*", 3_000_000)
+        if len(d) < 3_000_000:
+            pytest.skip("not enough shared objects in this image")
+    elif kind == "mixed":
+        d = corpus.mixed(3 << 20, 77)
+    elif kind == "near_copies":
+        d = corpus.duplicated(3_000_000, 3, 3000)
+    else:
+        d = corpus.json_like(3_000_000, 9)
+    got = gpu.memory_compress(d, flags, bs)
+    assert got == oracle.memory_compress(d, flags, bs)
