@@ -172,6 +172,20 @@ def duplicated(size, seed=1, edit_gap=400):
     return np.concatenate(out)[:size]
 
 
+def fibonacci_bytes(k=19, seed=1):
+    """Bytes whose counts are the Fibonacci numbers F(1)..F(k), shuffled: the unlimited Huffman tree of such a histogram is
+    a chain of depth k-1 (> 15 from k = 17: the cost estimates price code lengths the format cannot even encode). Matches
+    flatten the token histogram, so this only leans on the deep-tree paths; the regression test for code lengths above 15
+    in the cost estimates is the 2 MiB block of source code in test_gpu_parity.py."""
+    rs = np.random.RandomState(seed)
+    fib = [1, 1]
+    while len(fib) < k:
+        fib.append(fib[-1] + fib[-2])
+    d = np.concatenate([np.full(f, 33 + i, dtype=np.uint8) for i, f in enumerate(fib)])
+    rs.shuffle(d)
+    return d
+
+
 def mixed(size, seed=1):
     """Segments cycling through the self-test grid plus noise and constant runs (config 4 shape)."""
     rs = np.random.RandomState(seed)

@@ -44,6 +44,7 @@ def test_emu_is_not_the_product_library(emu):
     ("byte_runs", lambda: corpus.indented(7000, 11), 2000, 5000),
     ("byte_runs_first", lambda: corpus.indented(3000, 12), 0, 3000),
     ("near_copies", lambda: corpus.duplicated(14000, 3, 1500), 2000, 12000),
+    ("deep_huffman", lambda: corpus.fibonacci_bytes(19), 0, 10945),
 ], ids=lambda c: c[0])
 def test_stages_vs_oracle(emu, oracle, case):
     name, gen, prev, n = case

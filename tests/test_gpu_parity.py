@@ -49,6 +49,7 @@ def test_wave_primitives_selfcheck(gpu):
     ("byte_runs", lambda: corpus.indented(98304, 11), 32768, 65536, 65536),
     ("byte_runs_big", lambda: corpus.indented(300000, 13), 32768, 267232, 1 << 20),
     ("near_copies", lambda: corpus.duplicated(98304, 3), 32768, 65536, 65536),
+    ("deep_huffman", lambda: corpus.fibonacci_bytes(22), 0, 46367, 65536),
     ("near_copies_sparse_edits", lambda: corpus.duplicated(98304, 4, 5000), 32768, 65536, 65536),
     ("near_copies_split", lambda: corpus.duplicated(60000, 5, 700), 10000, 50000, 65536),
 ], ids=lambda c: c[0])
