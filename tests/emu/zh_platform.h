@@ -332,6 +332,15 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
    *s = nullptr;
    return 0;
 }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) {
+   *lo = 0;
+   *hi = 0;
+   return 0;
+}
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) {
+   *s = nullptr;
+   return 0;
+}
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline const char *hipGetErrorString(hipError_t) { return "emu"; }

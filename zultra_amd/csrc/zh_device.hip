@@ -336,7 +336,12 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       for (int k = 0; k < c->nlanes; k++) {
          ZH_CHECK(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
          for (int i = 0; i < 24; i++) ZH_CHECK(c, hipEventCreate(&c->lane_ev[k][i]));
-         ZH_CHECK(c, hipStreamCreateWithFlags(&c->side_stream[k], hipStreamNonBlocking));
+         {
+            // zh_parse_huge is a few workgroups following long chains: it should never queue behind the wide kernels
+            int lo_prio = 0, hi_prio = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+            ZH_CHECK(c, hipStreamCreateWithPriority(&c->side_stream[k], hipStreamNonBlocking, hi_prio));
+         }
          for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->side_ev[k][i]));
       }
       ZH_CHECK(c, hipEventCreate(&c->ev_input));
