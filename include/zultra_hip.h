@@ -70,6 +70,10 @@ int zultra_hip_selftest(void);
  * counters for this access width (profiles/, tools/pmc_traffic.py). Returns 0 on success. */
 int zultra_hip_traffic_probe(size_t nbytes);
 
+/* The second roofline denominator: measured bandwidth of a 16-byte-per-lane streaming copy of `nbytes`,
+ * `iters` launches timed with HIP events on the null stream. Returns GB/s (bytes read + bytes written), negative on errors. */
+double zultra_hip_copy_bandwidth(size_t nbytes, int iters);
+
 /* Create a context on `device` able to take batches of up to max_blocks max-blocks of up to max_block_size bytes
  * (clamped like libzultra.c:87-92). All device memory is allocated here and released by zultra_hip_destroy
  * (the reference allocates in zultra_stream_init and frees in zultra_stream_end, libzultra.c:82-166,521-565).
@@ -96,6 +100,14 @@ int zultra_hip_compress_blocks(zultra_hip_ctx_t *ctx, const void *data, size_t d
 const zultra_hip_subblock_t *zultra_hip_subblocks(const zultra_hip_ctx_t *ctx, uint32_t *count);
 const uint8_t *zultra_hip_payload(const zultra_hip_ctx_t *ctx, size_t *size);
 void zultra_hip_last_timing(const zultra_hip_ctx_t *ctx, zultra_hip_timing_t *t);
+
+/* Shape of the last batch: how the parse was decomposed. huge_* = tasks (and their positions) that hold a
+ * barrier-free run too long for the four-recurrences-per-wave kernel and went to the single-chain kernel instead. */
+typedef struct zultra_hip_stats_s {
+   uint64_t positions, huge_positions;
+   uint32_t blocks, subblocks, tasks, huge_tasks;
+} zultra_hip_stats_t;
+void zultra_hip_last_stats(const zultra_hip_ctx_t *ctx, zultra_hip_stats_t *out);
 
 /* Stage outputs of the last batch, for parity tests (copied device -> host on request).
  *   matches: n*8 entries {u16 length, u16 offset} of max-block `block`          (match[], private.h:59-62,97)

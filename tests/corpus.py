@@ -257,3 +257,83 @@ def text_like_fast(size, seed=1):
         out[pos:pos + take] = buf[:take]
         pos += take
     return out[:size]
+
+
+# ---- bulk generators in C (tests/gen/zgen.c): BASELINE.json configurations 4 and 5 at full size --------------------
+CONFIG4_SEED = 0x5EED
+CONFIG4_SEGMENT = 1 << 20
+_zgen = None
+
+
+def _zgen_lib():
+    global _zgen
+    if _zgen is None:
+        import ctypes as C
+        import os
+        import subprocess
+        here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gen")
+        so = os.path.join(here, "_build", "libzgen.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(here, "zgen.c")):
+            subprocess.run(["make", "-s", "-C", here], check=True)
+        L = C.CDLL(so)
+        L.zgen_mixed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.zgen_mixed.restype = None
+        L.zgen_json_files.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64]
+        L.zgen_json_files.restype = None
+        _zgen = L
+    return _zgen
+
+
+def mixed_config4(first_segment, nsegments, seed=CONFIG4_SEED, out=None):
+    """Segments [first_segment, first_segment + nsegments) of the configuration-4 stream (1 MiB each):
+    the self-test grid of alphabets x match probabilities, every 16th segment noise, every 16th one repeated byte.
+    Every segment depends only on (seed, its global index): ranks generate their own shard of the one 8 GiB stream."""
+    if out is None:
+        out = np.empty(nsegments * CONFIG4_SEGMENT, dtype=np.uint8)
+    assert out.dtype == np.uint8 and out.size >= nsegments * CONFIG4_SEGMENT and out.flags["C_CONTIGUOUS"]
+    _zgen_lib().zgen_mixed(out.ctypes.data, first_segment, nsegments, seed)
+    return out[: nsegments * CONFIG4_SEGMENT]
+
+
+def json_files(first_file, nfiles, file_size=4096, seed=5, out=None):
+    """Files [first_file, first_file + nfiles) of the configuration-5 corpus: independent JSON-like inputs of file_size bytes,
+    laid end to end."""
+    if out is None:
+        out = np.empty(nfiles * file_size, dtype=np.uint8)
+    assert out.dtype == np.uint8 and out.size >= nfiles * file_size and out.flags["C_CONTIGUOUS"]
+    _zgen_lib().zgen_json_files(out.ctypes.data, first_file, nfiles, file_size, seed)
+    return out[: nfiles * file_size]
+
+
+def real_text(size):
+    """Real text present in this image (and, identically, on the GPU box): the Python sources under /usr/lib/python3* and
+    /usr/local/lib/python3*, sorted by path and concatenated, cycled to `size` bytes (windows are 32 KiB: the tiling is
+    invisible to the compressor). Stands in for enwik8, which is not in the image."""
+    import glob
+    parts, total = [], 0
+    files = sorted(glob.glob("/usr/lib/python3*/**/*.py", recursive=True)) + sorted(glob.glob("/usr/local/lib/python3*/**/*.py", recursive=True))
+    for f in files:
+        try:
+            b = np.fromfile(f, dtype=np.uint8)
+        except OSError:
+            continue
+        if b.size:
+            parts.append(b)
+            total += b.size
+        if total >= size:
+            break
+    if not parts:
+        raise RuntimeError("no Python sources found for the real-text corpus")
+    d = np.concatenate(parts)
+    if d.size < size:
+        d = np.resize(d, size)
+    return d[:size].copy()
+
+
+BOOTSTRAP_JS = "/opt/conda/lib/python3.9/site-packages/notebook/static/components/bootstrap/dist/js/bootstrap.min.js"
+
+
+def bootstrap_js():
+    """BASELINE.json configuration 1 stand-in: the image's bootstrap.min.js v3.4.1, 39 680 bytes (the
+    48 944-byte file of the reference's README is not in the image). Raises FileNotFoundError where the image lacks it."""
+    return np.fromfile(BOOTSTRAP_JS, dtype=np.uint8)

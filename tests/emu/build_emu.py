@@ -18,8 +18,10 @@ def build(force=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-DZH_TOK_CHUNK=1024u",
            "-Wno-unknown-pragmas", "-I", HERE, "-I", CSRC, "-x", "c++", os.path.join(CSRC, "zh_device.hip"),
-           os.path.join(CSRC, "libzultra.cpp"), "-o", OUT]
-    subprocess.run(cmd, check=True)
+           os.path.join(CSRC, "libzultra.cpp"), "-o"]
+    tmp = "%s.%d.tmp" % (OUT, os.getpid())   # several test processes may build at once: each writes its own file, the rename is atomic
+    subprocess.run(cmd + [tmp], check=True)
+    os.replace(tmp, OUT)
     return OUT
 
 

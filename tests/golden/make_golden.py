@@ -45,6 +45,9 @@ def stream_cases():
         ("dict_raw_small", T + "[40000:100000]", 0, 65536, T + "[100:5000]"),
         ("json_4k", "corpus.json_like(4096, 3)", 2, 0, None),
         ("json_4k_b", "corpus.json_like(4096, 4)", 2, 0, None),
+        # BASELINE.json configuration 1 (known answer): the image's bootstrap.min.js v3.4.1 at the default block size
+        ("bootstrap_raw_default", "corpus.bootstrap_js()", 0, 0, None),
+        ("bootstrap_gzip_default", "corpus.bootstrap_js()", 2, 0, None),
     ]
     for a, p in [(1, 0.0), (2, 0.5), (3, 0.3), (15, 0.5), (56, 0.7), (137, 0.9), (255, 0.995), (256, 0.0)]:
         cases.append(("selftest_a%d_p%d" % (a, int(p * 1000)), "corpus.selftest_data(40000, %d, %d, %r)" % (123 + a, a, p), 1, 32768, None))

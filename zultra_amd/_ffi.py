@@ -54,6 +54,11 @@ class Timing(C.Structure):
                                          "group_ms", "frontier_ms", "stitch_ms", "init_ms", "parse_ms", "build_ms", "post_ms", "emit_ms")]
 
 
+class Stats(C.Structure):
+    _fields_ = [("positions", C.c_uint64), ("huge_positions", C.c_uint64), ("blocks", C.c_uint32), ("subblocks", C.c_uint32),
+                ("tasks", C.c_uint32), ("huge_tasks", C.c_uint32)]
+
+
 class BitState(C.Structure):
     _fields_ = [("acc", C.c_uint32), ("nacc", C.c_uint32)]
 
@@ -72,7 +77,7 @@ EXPORTS = [
     "zultra_hip_stitch", "zultra_hip_stitch_finish",
     "zultra_hip_stitch_device", "zultra_hip_stream_device", "zultra_hip_stream_read", "zultra_hip_block_crc32", "zultra_crc32_append", "zultra_crc32_append_many",
     "zultra_hip_create_files", "zultra_hip_compress_files", "zultra_hip_stitch_files", "zultra_hip_staging",
-    "zultra_hip_block_adler32", "zultra_adler32_append",
+    "zultra_hip_block_adler32", "zultra_adler32_append", "zultra_hip_copy_bandwidth", "zultra_hip_last_stats",
 ]
 
 
@@ -143,6 +148,12 @@ class Lib:
     def traffic_probe(self, nbytes):
         self.L.zultra_hip_traffic_probe.argtypes = [C.c_size_t]
         return self.L.zultra_hip_traffic_probe(nbytes)
+
+    def copy_bandwidth(self, nbytes=1 << 30, iters=5):
+        """Measured GB/s (read + written) of a 16 B/lane streaming copy: the roofline's second denominator."""
+        self.L.zultra_hip_copy_bandwidth.argtypes = [C.c_size_t, C.c_int]
+        self.L.zultra_hip_copy_bandwidth.restype = C.c_double
+        return self.L.zultra_hip_copy_bandwidth(nbytes, iters)
 
     def memory_bound(self, n, flags, max_block=0):
         return self.L.zultra_memory_bound(n, flags, max_block)
@@ -329,6 +340,13 @@ class HipContext:
         t = Timing()
         self.lib.L.zultra_hip_last_timing(self.h, C.byref(t))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def stats(self):
+        st = Stats()
+        self.lib.L.zultra_hip_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        self.lib.L.zultra_hip_last_stats.restype = None
+        self.lib.L.zultra_hip_last_stats(self.h, C.byref(st))
+        return {k: getattr(st, k) for k, _ in Stats._fields_}
 
     def matches(self, block):
         n = self._blocks[block][2]

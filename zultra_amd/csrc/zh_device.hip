@@ -72,7 +72,8 @@ struct zultra_hip_ctx_s {
    uint64_t bar_stride, max_tasks;
    zh_sbstate_t *d_states;
    uint2 *d_taskmap;
-   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: per run [0..3] tasks, [4..7] tasks listed for zh_parse_huge
+   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: per run [0..3] tasks, [4..7] tasks listed for zh_parse_huge, [8..11] their positions
+   uint32_t *h_ntasks;          // pinned mirror, read after the batch (zultra_hip_last_stats)
    uint32_t *d_hugelist;
    hipEvent_t ev2[16];
    // sub-batch pipelining: a batch runs as up to ZH_MAX_LANES contiguous runs of max-blocks, each on its own stream
@@ -80,6 +81,8 @@ struct zultra_hip_ctx_s {
    // never cut it, blockdeflate.c:646): no history, one sub-block and one task per block, no host decision anywhere in
    // the sequence -> stages 1-3 are captured once in a hipGraph and replayed per batch.
    int files_mode;
+   uint32_t max_file_size;      // files mode: the size the context was created for (inputs above it are rejected: from 8192 bytes on
+                                // the reference's splitter may cut an input, which the files pipeline never does)
    uint32_t max_subs;           // sub-blocks a max-block can have: 64, or 1 in files mode
    hipGraph_t graph;
    hipGraphExec_t graph_exec;
@@ -230,6 +233,40 @@ extern "C" int zultra_hip_traffic_probe(size_t nbytes) {
    return e == hipSuccess ? 0 : -2;
 }
 
+// Streaming copy with 16 B per lane (the widest access, what the guide's 6.29 TB/s "measured peak" was taken with): the
+// second denominator of the roofline. Returns GB/s of bytes read + bytes written, negative on errors.
+__global__ void __launch_bounds__(256) zh_probe_copy_x4(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+   for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) dst[k] = src[k];
+}
+
+extern "C" double zultra_hip_copy_bandwidth(size_t nbytes, int iters) {
+   uint4 *a = NULL, *b = NULL;
+   const size_t n16 = nbytes / 16;
+   if (!n16 || iters < 1) return -1.0;
+   if (hipMalloc((void **)&a, n16 * 16) != hipSuccess) return -1.0;
+   if (hipMalloc((void **)&b, n16 * 16) != hipSuccess) {
+      (void)hipFree(a);
+      return -1.0;
+   }
+   (void)hipMemset(a, 1, n16 * 16);
+   hipEvent_t e0 = NULL, e1 = NULL;
+   (void)hipEventCreate(&e0);
+   (void)hipEventCreate(&e1);
+   ZH_LAUNCH(zh_probe_copy_x4, 256 * 32, 256, 0, (const uint4 *)a, b, n16);   // warm-up
+   (void)hipEventRecord(e0, 0);
+   for (int i = 0; i < iters; i++) ZH_LAUNCH(zh_probe_copy_x4, 256 * 32, 256, 0, (const uint4 *)a, b, n16);
+   (void)hipEventRecord(e1, 0);
+   const hipError_t e = hipEventSynchronize(e1);
+   float ms = 0;
+   (void)hipEventElapsedTime(&ms, e0, e1);
+   (void)hipEventDestroy(e0);
+   (void)hipEventDestroy(e1);
+   (void)hipFree(a);
+   (void)hipFree(b);
+   if (e != hipSuccess || ms <= 0) return -2.0;
+   return 2.0 * (double)(n16 * 16) * iters / (ms * 1e-3) / 1e9;
+}
+
 // The pipeline uses up to five streams per context (two runs, a side stream each for zh_parse_huge, one for the stitcher) next
 // to the application's own. The HIP runtime multiplexes streams onto 4 hardware queues by default, and two streams that
 // share a queue run strictly one after the other: measured, a run's zh_parse_huge then blocks the other run's kernels
@@ -299,6 +336,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    if (c->h_split_cnt) (void)hipHostFree(c->h_split_cnt);
    if (c->h_sub_base) (void)hipHostFree(c->h_sub_base);
    if (c->h_crc) (void)hipHostFree(c->h_crc);
+   if (c->h_ntasks) (void)hipHostFree(c->h_ntasks);
    if (c->h_results) (void)hipHostFree(c->h_results);
    (void)hipFree(c->d_results_compact);
    (void)hipFree(c->d_items);
@@ -349,6 +387,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_split_cnt, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_sub_base, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_crc, B * sizeof(uint32_t), 0));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_ntasks, 16 * sizeof(uint32_t), 0));
+      memset(c->h_ntasks, 0, 16 * sizeof(uint32_t));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_adler, 2 * B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_results, B * c->max_subs * sizeof(zh_subblock_t), 0));
    }
@@ -356,7 +396,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
-       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, 8) || zh_alloc(c, &c->d_hugelist, c->max_tasks) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, 16) || zh_alloc(c, &c->d_hugelist, c->max_tasks) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
@@ -434,7 +474,9 @@ extern "C" zultra_hip_ctx_t *zultra_hip_create(int device, uint32_t max_block_si
 
 extern "C" zultra_hip_ctx_t *zultra_hip_create_files(int device, uint32_t max_file_size, uint32_t max_files) {
    if (max_file_size == 0 || max_file_size >= 8192) return NULL;   // larger inputs can be split: use the block interface
-   return zh_create(device, (max_file_size + 63u) & ~63u, max_files, 1);
+   zultra_hip_ctx_t *c = zh_create(device, (max_file_size + 63u) & ~63u, max_files, 1);
+   if (c) c->max_file_size = max_file_size;
+   return c;
 }
 
 // Pinned host buffers owned by the context (which = 0: input staging, 1: output staging), grown on demand and kept for
@@ -528,7 +570,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
              (const uint2 *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
    if (zh_enqueue_tokenize(c, st, blk, 0, nb) != 0) return -1;
    ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 8 * sizeof(uint32_t), st));
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 16 * sizeof(uint32_t), st));
    ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, (size_t)nb * c->slot_stride, st));
    ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)c->d_tok_pos, c->tok_stride, (const uint32_t *)c->d_ntok,
              (const uint32_t *)c->d_split_tok, (const uint32_t *)c->d_split_cnt, (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work, c->d_taskmap,
@@ -536,7 +578,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    ZH_LAUNCH(zh_sb_init, nb, 64, st, (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_states);
    const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap,
-             (const uint32_t *)c->d_ntasks, c->d_hugelist, c->d_ntasks + 4);
+             (const uint32_t *)c->d_ntasks, c->d_hugelist, c->d_ntasks + 4, c->d_ntasks + 8);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_huge: few workgroups, long) next to all the others
       hipStream_t side = c->side_stream[0];
@@ -561,6 +603,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    ZH_CHECK(c, hipMemcpyAsync(c->h_adler, c->d_adler, 2 * nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
    ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results, nb * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
    ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+   ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks, c->d_ntasks, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
    return 0;
 }
 
@@ -612,7 +655,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       return -1;
    }
    for (uint32_t b = 0; b < nblocks; b++) {
-      if (blocks[b].n == 0 || blocks[b].n > c->max_block || blocks[b].prev > ZH_HISTORY || (uint64_t)blocks[b].prev + blocks[b].n > c->W ||
+      if (blocks[b].n == 0 || blocks[b].n > c->max_block || (c->files_mode && (blocks[b].n > c->max_file_size || blocks[b].prev != 0)) || blocks[b].prev > ZH_HISTORY || (uint64_t)blocks[b].prev + blocks[b].n > c->W ||
           blocks[b].win_off + blocks[b].prev + blocks[b].n > data_size) {
          snprintf(c->err, sizeof(c->err), "block %u out of range", b);
          return -1;
@@ -708,7 +751,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    // ---- stage 3 of every run: the sub-block coder, one kernel per step over the run (zh_encode.h) -------------------
    uint32_t nsubs = 0;
    uint32_t lane_sub0[4], lane_nsubs[4];
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 8 * sizeof(uint32_t), st0));
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 16 * sizeof(uint32_t), st0));
    ZH_CHECK(c, hipEventRecord(c->ev2[0], st0));
    for (int k = 0; k < lanes; k++) {
       hipStream_t st = c->lane_stream[k];
@@ -751,7 +794,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
       ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
       ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)ntasks, hugelist,
-                ntasks + 4);
+                ntasks + 4, ntasks + 8);
       ZH_CHECK(c, hipEventRecord(ev[5], st));
       for (int pass = 0; pass <= 3; pass++) {
          // the tasks with barrier-free runs (zh_parse_huge: few workgroups, long) next to all the others
@@ -784,6 +827,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_CHECK(c, hipEventRecord(ev[16], st));
    }
    for (int k = 0; k < lanes; k++) ZH_CHECK(c, hipStreamSynchronize(c->lane_stream[k]));
+   ZH_CHECK(c, hipMemcpy(c->h_ntasks, c->d_ntasks, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
    ZH_CHECK(c, hipGetLastError());
    // sub-block descriptors in batch coordinates
    c->results.assign(c->h_results, c->h_results + nsubs);
@@ -954,6 +998,19 @@ extern "C" int zultra_hip_stream_read(zultra_hip_ctx_t *c, void *out, size_t off
 }
 extern "C" void zultra_hip_last_timing(const zultra_hip_ctx_t *c, zultra_hip_timing_t *t) {
    if (c && t) *t = c->timing;
+}
+
+extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stats_t *out) {
+   if (!c || !out) return;
+   memset(out, 0, sizeof(*out));
+   out->blocks = c->nblocks;
+   out->subblocks = c->nsubs;
+   for (int k = 0; k < 4; k++) {
+      out->tasks += c->h_ntasks[k];
+      out->huge_tasks += c->h_ntasks[4 + k];
+      out->huge_positions += c->h_ntasks[8 + k];
+   }
+   for (uint32_t b = 0; b < c->nblocks; b++) out->positions += c->blocks[b].n;
 }
 
 extern "C" int zultra_hip_get_matches(zultra_hip_ctx_t *c, uint32_t block, uint16_t *out) {

@@ -161,7 +161,8 @@ __device__ __forceinline__ uint32_t zh_huge_ring_at(const zh_huge_ws_t &ws, uint
 // the tasks zh_parse_tasks leaves alone: one wave per task, the same piece computation
 __global__ void __launch_bounds__(64)
 zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
-             const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total, uint32_t *hugelist, uint32_t *nhuge) {
+             const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total, uint32_t *hugelist, uint32_t *nhuge,
+             uint32_t *huge_positions) {
    __shared__ uint32_t bnd[ZH_MAXPIECES + 1];
    const uint32_t gt = blockIdx.x;
    if (gt >= *ntasks_total) return;
@@ -174,7 +175,10 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
    const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
    const uint32_t np = zh_task_pieces(bnd, bar, prev, t0, t1, lane);
    zh_sync();
-   if (zh_task_is_huge(bnd, np, lane) && lane == 0) hugelist[atomicAdd(nhuge, 1u)] = gt;
+   if (zh_task_is_huge(bnd, np, lane) && lane == 0) {
+      hugelist[atomicAdd(nhuge, 1u)] = gt;
+      atomicAdd(huge_positions, t1 - t0);   // statistics only (zultra_hip_last_stats)
+   }
 }
 
 __global__ void __launch_bounds__(ZH_HUGE_THREADS)

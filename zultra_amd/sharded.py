@@ -1,11 +1,19 @@
-"""Multi-GPU assembly: max-blocks shard across ranks with no exchange during compute; the only
-collectives are (1) an all-gather of the small per-sub-block descriptors, from which every rank derives the bit
-offset at which its shard starts in the stream (the stored-vs-compressed decision of libzultra.c:345-347 depends on
-the running bit phase, so offsets come from a dry run of the stitch planner over the preceding shards), and (2) one
-variable-length gather of the stitched shard bytes — stitched on each GPU by the zh_stitch kernel at the shard's true
-bit phase — to rank 0, which ORs the shared boundary bytes together.
+"""Multi-GPU assembly: max-blocks shard across ranks with no exchange during compute. What crosses
+ranks after the compute:
 
-`dist` is torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+  (1) one all-gather of a 160-byte *phase table* per rank. The stored-vs-compressed decision of libzultra.c:345-347
+      compares whole flushed bytes, so the bit length of a shard depends on the bit phase (0..7) it starts at. Every rank
+      dry-runs the stitch planner over its own sub-block descriptors for the eight possible start phases and publishes
+      (bits written, touched) per phase; chaining the tables of the ranks before it gives a rank its true start phase and
+      byte offset without any descriptor leaving its rank.
+  (2) each rank stitches its shard on its own GPU (zh_stitch) at that phase: byte 0 of its local stream carries only this
+      shard's bits.
+  (3) one gather of each shard's first byte, and exact-length point-to-point transfers (batch_isend_irecv: RCCL
+      send/recv over the direct xGMI link to rank 0 on the GPU box) straight into their final place in rank 0's stream
+      buffer. A shard that starts mid-byte shares that byte with its predecessor: it sends its bytes from the second one
+      on, and rank 0 ORs the two halves of the shared byte together from the boundary records.
+
+`dist` is torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
 """
 import ctypes as C
 
@@ -17,7 +25,7 @@ _SIZE_MAX = C.c_size_t(-1).value
 
 
 def shard_range(nblocks, rank, world):
-    """Contiguous max-block range of a rank."""
+    """Contiguous max-block range of a rank (empty when world > nblocks for some ranks)."""
     lo = (nblocks * rank) // world
     hi = (nblocks * (rank + 1)) // world
     return lo, hi
@@ -38,15 +46,24 @@ def _stream_tensor(ctx, torch, device, nbytes):
     return torch.from_numpy(np.ctypeslib.as_array(buf))
 
 
-def _plan_bits(lib, subs_arr, count, max_block, phase):
-    """Dry run of the stitcher over one shard's descriptors: (whole bytes, trailing bits)."""
-    st = BitState(0, phase)
+def phase_table(lib, ctx, max_block):
+    """int64[8, 2]: for start phase p, (end_bit, ok) of this rank's last batch, end_bit counted from the start of the byte
+    that holds the p pending bits (zh_stitch_plan's origin). An empty shard leaves the phase alone: end_bit = p."""
+    tab = np.zeros((8, 2), dtype=np.int64)
+    if ctx is None:
+        tab[:, 0] = np.arange(8)
+        tab[:, 1] = 1
+        return tab
+    p, cnt = ctx.subblocks_raw()
     dummy = (C.c_uint64 * 1)(0)
-    sp = subs_arr.ctypes.data_as(C.POINTER(SubBlock))
-    w = lib.L.zultra_hip_stitch(C.byref(st), sp, count, None, None, dummy, max_block, -1, None, 0)
-    if w == _SIZE_MAX:
-        raise RuntimeError("stitch planning failed (ZULTRA_ERROR_DST)")
-    return w, st.nacc
+    for ph in range(8):
+        st = BitState(0, ph)
+        w = lib.L.zultra_hip_stitch(C.byref(st), p, cnt, None, None, dummy, max_block, -1, None, 0)
+        if w == _SIZE_MAX:
+            tab[ph] = (ph, 0)   # the reference fails with ZULTRA_ERROR_DST at this phase; only an error if it is the true one
+        else:
+            tab[ph] = (8 * w + st.nacc, 1)
+    return tab
 
 
 _pinned = {}
@@ -64,69 +81,82 @@ def _to_host(torch, t):
     return buf[:n].numpy()
 
 
-def assemble(lib, ctx, max_block, dist, torch, device, is_stream_end_rank, nblocks_local):
+def assemble(lib, ctx, max_block, dist, torch, device, final_block_local):
     """Stitch this rank's last batch on its GPU at its true bit offset and gather the stream on rank 0.
+    ctx = None for a rank whose shard is empty (it still takes part in the collectives).
+    final_block_local = index (in this rank's batch) of the last max-block of the whole stream, or -1.
     Returns (stream bytes as a uint8 numpy array on rank 0 / None elsewhere, info dict)."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    p, cnt = ctx.subblocks_raw()
-    rec = C.sizeof(SubBlock)
-    mine = np.zeros((cnt, rec), dtype=np.uint8)
-    C.memmove(mine.ctypes.data, p, cnt * rec)
-
-    start_phase = 0
-    allsubs, counts = None, [cnt]
-    if world > 1:
-        # (1) descriptors of every rank (48 B per sub-block)
-        ct = torch.zeros(world, dtype=torch.int64, device=device)
-        ct[rank] = cnt
-        dist.all_reduce(ct)
-        counts = [int(x) for x in ct.cpu()]
-        pad = np.zeros((max(counts), rec), dtype=np.uint8)
-        pad[:cnt] = mine
-        send = torch.from_numpy(pad).to(device)
-        allsubs = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(allsubs, send)
-        allsubs = [t.cpu().numpy() for t in allsubs]
-        phase = 0
-        for r in range(rank):
-            _, phase = _plan_bits(lib, np.ascontiguousarray(allsubs[r][:counts[r]]), counts[r], max_block, phase)
-        start_phase = phase
-
-    # (2) stitch on the device at the shard's true phase: byte 0 carries only this shard's bits
-    end_bit, _ = ctx.stitch_device(nblocks_local - 1 if is_stream_end_rank else -1, phase=start_phase)
-    nbytes = (end_bit + 7) // 8
-    local = _stream_tensor(ctx, torch, device, nbytes)
 
     if world == 1:
-        return _to_host(torch, local), {"shard_bytes": nbytes, "start_phase": 0}
+        end_bit, _ = ctx.stitch_device(final_block_local, phase=0)
+        nbytes = (end_bit + 7) // 8
+        return _to_host(torch, _stream_tensor(ctx, torch, device, nbytes)), {"shard_bytes": nbytes, "start_phase": 0, "sent_bytes": 0}
 
-    # (3) variable-length gather of the stitched bytes to rank 0 (RCCL over xGMI on the GPU box)
-    lt = torch.zeros(world, dtype=torch.int64, device=device)
-    lt[rank] = nbytes
-    dist.all_reduce(lt)
-    lens = [int(x) for x in lt.cpu()]
-    maxl = max(lens)
-    sendb = torch.zeros(maxl, dtype=torch.uint8, device=device)
-    sendb[:nbytes] = local
-    if rank != 0:
-        dist.gather(sendb, None, dst=0)
-        return None, {"shard_bytes": nbytes, "start_phase": start_phase}
-    parts = [torch.empty(maxl, dtype=torch.uint8, device=device) for _ in range(world)]
-    dist.gather(sendb, parts, dst=0)
-
-    # rank 0: join on the device (a shard that starts mid-byte shares that byte with its predecessor), then one pinned D2H
-    total = sum(lens)
-    stream = torch.zeros(total + 1, dtype=torch.uint8, device=device)
-    pos = 0
-    phase = 0
+    # (1) phase tables of every rank -> start phase and byte offset of every shard
+    mine = torch.from_numpy(phase_table(lib, ctx, max_block)).to(device)
+    tabs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(tabs, mine)
+    tabs = [t.cpu().numpy() for t in tabs]
+    phase, off = 0, 0            # off = index of the byte that holds the pending bits (or the next free byte at phase 0)
+    starts = []
     for r in range(world):
-        b = parts[r][:lens[r]]
-        if phase:   # first byte overlaps the previous shard's last (partial) byte
-            stream[pos - 1] |= b[0]
-            stream[pos:pos + lens[r] - 1] = b[1:]
-            pos += lens[r] - 1
-        else:
-            stream[pos:pos + lens[r]] = b
-            pos += lens[r]
-        _, phase = _plan_bits(lib, np.ascontiguousarray(allsubs[r][:counts[r]]), counts[r], max_block, phase)
-    return _to_host(torch, stream[:pos]), {"shard_bytes": nbytes, "start_phase": 0}
+        end_bit, ok = int(tabs[r][phase][0]), int(tabs[r][phase][1])
+        if not ok:
+            raise RuntimeError("stream assembly overflows the reference's per-block buffer bound on rank %d (ZULTRA_ERROR_DST)" % r)
+        starts.append((phase, off, end_bit))
+        off += end_bit >> 3
+        phase = end_bit & 7
+    total_bytes = off + (1 if phase else 0)
+    my_phase, my_off, my_end = starts[rank]
+
+    # (2) stitch on the device at the shard's true phase: byte 0 carries only this shard's bits
+    nbytes = 0
+    local = None
+    if ctx is not None:
+        end_bit, _ = ctx.stitch_device(final_block_local, phase=my_phase)
+        assert end_bit == my_end, (end_bit, my_end)
+        nbytes = (end_bit + 7) // 8
+        local = _stream_tensor(ctx, torch, device, nbytes)
+
+    # (3) first byte of every shard, then exact-length transfers into place on rank 0
+    edge = torch.zeros(1, dtype=torch.uint8, device=device)
+    if nbytes:
+        edge[0] = local[0]
+    edges = [torch.empty_like(edge) for _ in range(world)] if rank == 0 else None
+    dist.gather(edge, edges, dst=0)
+
+    def touched(r):   # bytes shard r owns in the stream, and how many of them it transfers (all but a shared first byte)
+        ph, o, eb = starts[r]
+        n = (eb + 7) // 8 if eb != ph else 0   # an empty shard writes nothing
+        skip = 1 if (n and ph) else 0
+        return o, n, skip
+
+    info = {"shard_bytes": nbytes, "start_phase": my_phase, "sent_bytes": 0}
+    if rank != 0:
+        o, n, skip = touched(rank)
+        if n - skip > 0:
+            reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, local[skip:n], 0)])
+            for q in reqs:
+                q.wait()
+            info["sent_bytes"] = n - skip
+        return None, info
+
+    stream = torch.zeros(total_bytes + 1, dtype=torch.uint8, device=device)
+    ops = []
+    for r in range(1, world):
+        o, n, skip = touched(r)
+        if n - skip > 0:
+            ops.append(dist.P2POp(dist.irecv, stream[o + skip:o + n], r))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if nbytes:
+        stream[:nbytes] = local   # rank 0's own shard (phase 0, offset 0), while the transfers are in flight
+    for q in reqs:
+        q.wait()
+    # shared bytes: a shard that starts mid-byte ORs its first byte into the byte its predecessors left partial
+    edges = [e.cpu().numpy() for e in edges]
+    for r in range(1, world):
+        o, n, skip = touched(r)
+        if skip:
+            stream[o] |= int(edges[r][0])
+    return _to_host(torch, stream[:total_bytes]), info
