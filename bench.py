@@ -1,27 +1,43 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json metric: input MB/s of the per-block deflate hot path on MI355X, gzip, 64 KiB max-blocks,
-enwik8-sized text (config[1]); one JSON line on rank 0.
+"""bench.py — the BASELINE.json metric on MI355X: input MB/s of zultra's per-block deflate hot path, bit-exact with the
+CPU reference, one JSON line on rank 0.
 
-A "step" = one pass of the whole job over this rank's 100 MB shard, input already resident in HBM:
-   stage 1-3 kernels (match rows, token chain + splitter, sub-block coder: 4 x (task-parallel optimal parse, code
-   rebuild), literalisation, emission) -> per-sub-block bit strings
-   -> device stitch (zh_stitch) at the shard's true bit offset, per-block CRC-32 on the device (zh_crc32_blocks)
-   -> (N>1: descriptor all-gather and byte gather over RCCL) -> D2H of the finished deflate bytes on rank 0
-   -> gzip stream on rank 0 (header, deflate bits, CRC-32/ISIZE footer).
-N>1 is weak scaling: every rank compresses its own 100 MB shard of one N x 100 MB stream.
+    python bench.py [--config 1|2|3|4|5] [--gpus N] [--steps K] [--warmup W]
 
-Extra objects on the line: `roofline` for the dominant kernel (live HIP-event duration on the library's stream),
-`cpu_baseline` = the compiled reference (oracle/_ref, kind "reference") or the oracle port, timed on a bounded sample.
+--config selects one of BASELINE.json's configurations (default 2, the one the metric is quoted on):
+  1  bootstrap.min.js (the image's 39 680-byte v3.4.1 stands in), raw deflate, one max-block: known answer 10 523 B
+  2  enwik8-sized text, gzip, 64 KiB max-blocks. enwik8 is not in the image: `value` is measured on REAL text (the image's
+     Python sources, 100 MB), the kind seeded synthetic text of round 1 is reported beside it as `synthetic_text`
+  3  silesia/mozilla-sized binary (shared libraries of the image stand in), zlib framing, 32 KiB max-blocks, ratio vs zlib-9
+  4  the 8 GiB synthetic mixed-entropy corpus, 64 KiB max-blocks, 1 GiB (16 384 max-blocks) per GPU
+  5  1 000 000 x 4 KiB JSON-like inputs per GPU, each its own gzip stream, hipGraph-replayed batches
+
+A "step" = one pass of the whole job over this rank's shard, input already resident in HBM: stage 1-3 kernels -> device
+stitch at the shard's true bit offset + per-block checksums on the device -> (N>1: phase-table all-gather and exact-length
+transfers to rank 0 over RCCL) -> D2H of the finished deflate bytes on rank 0 -> frame on rank 0.
+--gpus N > 1: this process spawns N rank processes itself (one per GPU, RCCL) before anything touches a GPU — or runs as
+one rank when a launcher (torch.distributed.run) already set RANK/WORLD_SIZE; a WORLD_SIZE that differs from --gpus is an
+error, and so are fewer visible GPUs than N. Weak scaling: every rank takes its own shard of ONE N-times-larger stream.
+
+Every line carries `roofline` (dominant kernel, live HIP-event duration on the library's streams) and `cpu_baseline` (the
+compiled reference oracle/_ref — or the oracle port where it did not travel — on a bounded sample, rank 0, N=1).
+The process exits non-zero when the inflate round trip or the bit-exactness check fails.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+import zlib
 
 # the library's streams need their own hardware queues (zh_device.hip: zh_runtime_hints); torch initialises HIP before the
 # library is loaded here, so the hint has to be in the environment already
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 
@@ -29,13 +45,231 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
+HIST = 32768
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """--gpus N without a launcher: start N rank processes (fork + exec from a process that has not touched a GPU)."""
+    import torch
+    have = torch.cuda.device_count()   # counts devices without initialising the GPU (on this image)
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible — refusing to report a smaller job as N=%d\n" % (args.gpus, have, args.gpus))
+        return 2
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank(s) failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# corpora: every rank can produce any range of ONE global stream
+# ---------------------------------------------------------------------------------------------------------------------
+def find_enwik8():
+    for p in (os.environ.get("ZULTRA_ENWIK8"), os.path.join(ROOT, "data", "enwik8"), "/data/enwik8", os.path.expanduser("~/enwik8")):
+        if p and os.path.exists(p) and os.path.getsize(p) == 100_000_000:
+            return p
+    return None
+
+
+def _cyclic(base, start, size):
+    n = len(base)
+    start %= n
+    parts = []
+    while size > 0:
+        k = min(size, n - start)
+        parts.append(base[start:start + k])
+        size -= k
+        start = 0
+    return np.concatenate(parts) if len(parts) > 1 else parts[0].copy()
+
+
+def _files_corpus(patterns, need, cap=256 << 20):
+    """Files of the image matching `patterns`, sorted by path and concatenated until `need` (at most `cap`) bytes are there."""
+    parts, total = [], 0
+    for pat in patterns:
+        for f in sorted(glob.glob(pat, recursive=True)):
+            if total >= min(need, cap):
+                break
+            try:
+                if os.path.islink(f) or not os.path.isfile(f):
+                    continue
+                b = np.fromfile(f, dtype=np.uint8)
+            except OSError:
+                continue
+            if b.size:
+                parts.append(b)
+                total += b.size
+    if not parts:
+        raise RuntimeError("no files found for %s" % (patterns,))
+    return np.concatenate(parts)
+
+
+class CyclicCorpus:
+    """A byte corpus, cycled: windows are 32 KiB, so the tiling is invisible to the compressor."""
+
+    def __init__(self, name, base):
+        self.name, self.base = name, base
+
+    def shard(self, rank, size):
+        lead = _cyclic(self.base, rank * size - HIST, HIST) if rank else None
+        return lead, _cyclic(self.base, rank * size, size)
+
+
+class SyntheticText:
+    """Round 1's seeded Zipf word stream (tests/corpus.py: text_like_fast). Shard r ends with a 32 KiB piece of its own seed, so
+    rank r+1 regenerates only those 32 KiB for its history."""
+    name = "synthetic"
+
+    def shard(self, rank, size):
+        import corpus
+        body = corpus.text_like_fast(size - HIST, seed=1000 + rank)
+        tail = corpus.text_like_fast(HIST, seed=7000 + rank)
+        lead = corpus.text_like_fast(HIST, seed=7000 + rank - 1) if rank else None
+        return lead, np.concatenate([body, tail])
+
+
+class MixedConfig4:
+    name = "synthetic"
+
+    def shard(self, rank, size):
+        import corpus
+        seg = corpus.CONFIG4_SEGMENT
+        assert size % seg == 0
+        first = rank * (size // seg)
+        lead = corpus.mixed_config4(first - 1, 1)[-HIST:].copy() if rank else None
+        return lead, corpus.mixed_config4(first, size // seg)
+
+
+def text_corpus(world, size):
+    p = find_enwik8()
+    if p:
+        return CyclicCorpus("enwik8", np.fromfile(p, dtype=np.uint8)), "enwik8 (real file)"
+    need = world * size
+    base = _files_corpus(["/usr/lib/python3*/**/*.py", "/usr/local/lib/python3*/**/*.py"], need)
+    return CyclicCorpus("real_text", base), "real text: the image's Python sources, sorted by path, cycled to size (enwik8 absent)"
+
+
+def binary_corpus(world, size):
+    base = _files_corpus(["/usr/lib/x86_64-linux-gnu/*.so*", "/usr/bin/*"], world * size)
+    return CyclicCorpus("real_binary", base), "real binaries: shared libraries and executables of the image, sorted by path (silesia/mozilla absent)"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU side: reference baseline (before this process touches the GPU) and framing helpers
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_impl():
+    import zlibs
+    if zlibs.have_ref():
+        return zlibs.Ref(), "reference", "compiled reference oracle/_ref"
+    return zlibs.Oracle(), "port", "oracle/zultra_oracle.c"
+
+
+def cpu_baseline_stream(sample, flags, bs, what):
+    """Reference CPU path on a bounded sample, 1 thread, best of 3 -> (cpu_baseline object, compressed bytes)."""
+    impl, kind, label = cpu_impl()
+    runs = 3 if kind == "reference" else 1
+    best, out = None, None
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        out = impl.memory_compress(sample, flags, bs)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": round(len(sample) / best / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": kind, "nproc": os.cpu_count(), "cpu_model": cpu_model(),
+            "sample": "%s: first %d bytes of rank 0's shard, zultra_memory_compress flags=%d max block %d, 1 thread, best of %d, %s" % (
+                what, len(sample), flags, bs, runs, label)}, out
+
+
+def _files_worker(job):
+    data, size, flags = job
+    impl, _, _ = cpu_impl()
+    h = hashlib.sha256()
+    t0 = time.perf_counter()
+    for k in range(len(data) // size):
+        h.update(impl.memory_compress(data[k * size:(k + 1) * size], flags, 0))
+    return time.perf_counter() - t0, h.hexdigest()
+
+
+def cpu_baseline_files(sample, size, flags):
+    """Config 5: the reference on a bounded sample of files — one thread, then nproc processes over file shards (independent
+    inputs: still the reference's exact output). Must run before this process initialises the GPU (it forks)."""
+    import multiprocessing as mp
+    _, kind, label = cpu_impl()
+    nfiles = len(sample) // size
+    t1, digest = _files_worker((sample, size, flags))
+    nproc = os.cpu_count() or 1
+    per = (nfiles + nproc - 1) // nproc
+    jobs = [(sample[i * per * size:min(nfiles, (i + 1) * per) * size], size, flags) for i in range(nproc) if i * per < nfiles]
+    with mp.get_context("fork").Pool(len(jobs)) as pool:
+        tn = max(t for t, _ in pool.map(_files_worker, jobs))   # the slowest worker's own clock: process start-up is not compression time
+    return {"value": round(nfiles / t1, 1), "unit": "files/s", "cores": 1, "kind": kind, "nproc": nproc, "cpu_model": cpu_model(),
+            "all_cores_value": round(nfiles / tn, 1), "all_cores_processes": len(jobs),
+            "sample": "first %d files of rank 0's shard, one zultra_memory_compress (gzip) per file, 1 thread; then %d processes over file shards; %s" % (
+                nfiles, len(jobs), label)}, digest
+
+
+def frame(L, flags, body, checksum, total_in):
+    if flags == 2:
+        return bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 2, 255]) + body + int(checksum).to_bytes(4, "little") + int(total_in & 0xffffffff).to_bytes(4, "little")
+    if flags == 1:
+        return bytes([0x78, 0xda]) + body + int(checksum).to_bytes(4, "big")
+    return body
+
+
+def inflate_check(flags, framed, first_shard, total_in):
+    """Inflate the whole stream in chunks (zlib verifies the gzip CRC-32 / zlib Adler-32 footer over ALL ranks' bytes);
+    rank 0's own shard must come back byte for byte and the total length must be the input's."""
+    d = zlib.decompressobj({2: 31, 1: 15, 0: -15}[flags])
+    got, ok = 0, True
+    mv = memoryview(framed)
+    try:
+        for pos in range(0, len(mv), 8 << 20):
+            out = d.decompress(mv[pos:pos + (8 << 20)])
+            if got < len(first_shard):
+                k = min(len(out), len(first_shard) - got)
+                ok = ok and out[:k] == first_shard[got:got + k].tobytes()
+            got += len(out)
+        got += len(d.flush())
+    except zlib.error:
+        return False
+    return bool(ok and d.eof and got == total_in)
 
 
 def committed_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json, written by
     tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command), or None."""
-    import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
         return None, None
@@ -47,130 +281,79 @@ def committed_traffic(kernel):
     return int(k["hbm_bytes_per_launch"]), os.path.basename(files[-1])
 
 
-def find_enwik8():
-    for p in (os.environ.get("ZULTRA_ENWIK8"), os.path.join(ROOT, "data", "enwik8"), "/data/enwik8", os.path.expanduser("~/enwik8")):
-        if p and os.path.exists(p) and os.path.getsize(p) == 100_000_000:
-            return p
-    return None
+class OneRank:   # N == 1: same code path without a process group
+    @staticmethod
+    def get_rank():
+        return 0
+
+    @staticmethod
+    def get_world_size():
+        return 1
 
 
-def make_shard(size, rank):
-    """This rank's shard of the stream plus the 32 KiB that precede it (history of its first max-block)."""
-    import corpus
-    p = find_enwik8()
-    if p and rank == 0:
-        return np.fromfile(p, dtype=np.uint8)[:size], "enwik8"
-    return corpus.text_like_fast(size, seed=1000 + rank), "synthetic"
-
-
-def cpu_baseline(sample, flags, bs):
-    """Reference CPU path (or the oracle port when oracle/_ref did not travel) on a bounded sample, 1 thread."""
-    import zlibs
-    if zlibs.have_ref():
-        impl, kind = zlibs.Ref(), "reference"
-    else:
-        impl, kind = zlibs.Oracle(), "port"
-    best = None
-    out = None
-    for _ in range(2 if kind == "reference" else 1):
-        t0 = time.perf_counter()
-        out = impl.memory_compress(sample, flags, bs)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return {"value": round(len(sample) / best / 1e6, 3), "unit": "MB/s", "cores": 1, "kind": kind,
-            "sample": "first %d bytes of rank 0's shard, zultra_memory_compress gzip %d-byte blocks, best of %d, %s" % (
-                len(sample), bs, 2 if kind == "reference" else 1,
-                "compiled reference oracle/_ref" if kind == "reference" else "oracle/zultra_oracle.c")}, out
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=100_000_000, help="bytes per GPU (enwik8 = 100 000 000)")
-    ap.add_argument("--block", type=int, default=65536)
-    ap.add_argument("--cpu-sample", type=int, default=32 << 20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-run", action="store_true",
-                    help="for rocprofv3 passes: only the steps (no round-trip / ratio / CPU extras that would add dispatches), then the PMC calibration probe")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-
-    import zultra_amd
+# ---------------------------------------------------------------------------------------------------------------------
+# one leg of a stream configuration (2, 3, 4): compress this rank's shard `steps` times, assemble on rank 0
+# ---------------------------------------------------------------------------------------------------------------------
+def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
+    L, torch, dist, device, rank, world = env["L"], env["torch"], env["dist"], env["device"], env["rank"], env["world"]
     from zultra_amd import sharded
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-
-    L = zultra_amd.lib()   # raises if libzultra_amd.so is missing: there is no fallback path
-    if L.device_count() < 1:
-        raise RuntimeError("no HIP device")
-
-    bs, flags = args.block, 2
-    shard, data_kind = make_shard(args.size, rank)
+    import ctypes as C
     n = len(shard)
-    # history of this shard's first max-block = tail of the previous rank's shard (one continuous stream)
-    if rank > 0:
-        import corpus
-        prev_tail = corpus.text_like_fast(args.size, seed=1000 + rank - 1)[-32768:]
-        host = np.concatenate([prev_tail, shard])
-        lead = 32768
-    else:
-        host, lead = shard, 0
+    host = np.concatenate([lead, shard]) if lead is not None else shard
+    nlead = len(lead) if lead is not None else 0
     nblocks = (n + bs - 1) // bs
     blocks = []
     for b in range(nblocks):
-        prev = 32768 if (b > 0 or lead) else 0
-        blocks.append((lead + b * bs - prev, prev, min(bs, n - b * bs)))
-    raw_offs = [b * bs for b in range(nblocks)]
+        prev = HIST if (b > 0 or nlead) else 0
+        blocks.append((nlead + b * bs - prev, prev, min(bs, n - b * bs)))
     block_lens = np.array([b[2] for b in blocks], dtype=np.uint32)
 
     d_data = torch.from_numpy(host).to(device)   # input resident in HBM before the timed region
     torch.cuda.synchronize()
-    ctx = L.context(bs, nblocks, device=local_rank)
-
-    class OneRank:   # N == 1: same code path without a process group
-        @staticmethod
-        def get_rank():
-            return 0
-
-        @staticmethod
-        def get_world_size():
-            return 1
-
+    ctx = L.context(bs, nblocks, device=env["local_rank"])
     D = dist if world > 1 else OneRank
+    L.L.zultra_adler32_append.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t]
+    L.L.zultra_adler32_append.restype = C.c_uint32
+    L.L.zultra_hip_block_adler32.argtypes = [C.c_void_p, C.c_void_p]
     timings = []
+
+    def shard_checksum():
+        """This shard's checksum contribution from the per-max-block values the device computed next to the compression, as
+        what a zero initial state becomes: gzip -> linear CRC-32 state, zlib -> (A, B) sums."""
+        if flags == 2:
+            # running value v of zultra_crc32_append is the finalized CRC; the raw register is ~v: start it at 0 -> v = ~0
+            v = L.crc32_append_many(0xFFFFFFFF, ctx.block_crc32(), block_lens)
+            return (~v) & 0xFFFFFFFF
+        if flags == 1:
+            ab = np.zeros(2 * nblocks, dtype=np.uint32)
+            L.L.zultra_hip_block_adler32(ctx.h, ab.ctypes.data)
+            a = 0
+            for b in range(nblocks):
+                a = L.L.zultra_adler32_append(a, int(ab[2 * b]), int(ab[2 * b + 1]), int(block_lens[b]))
+            return a
+        return 0
 
     def step():
         ctx.compress_blocks(d_data.data_ptr(), blocks, data_on_device=True, data_size=d_data.numel())
-        timings.append(ctx.timing())
-        # gzip footer CRC-32: per-max-block values computed on the device next to the compression, folded on the host
-        crc = L.crc32_append_many(0, ctx.block_crc32(), block_lens)
-        body, info = sharded.assemble(L, ctx, bs, D, torch, device, is_stream_end_rank=(rank == world - 1), nblocks_local=nblocks)
-        timings[-1]["stitch_ms"] = ctx.timing()["stitch_ms"]
-        return body, crc
+        t = ctx.timing()
+        extra = np.array([shard_checksum(), n], dtype=np.int64)
+        body, info = sharded.assemble(L, ctx, bs, D, torch, device, nblocks - 1 if rank == world - 1 else -1, extra=extra)
+        t["stitch_ms"] = ctx.timing()["stitch_ms"]
+        timings.append(t)
+        return body, info
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     timings.clear()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        body, crc = step()
+    for _ in range(steps):
+        body, info = step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -178,10 +361,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    res = {"n": n, "nblocks": nblocks, "dt": dt, "stats": ctx.stats(), "ctx": ctx, "d_data": d_data}
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        total_in = n * world
-        # per-kernel device times (HIP events on the library stream), averaged over the timed steps
+        # fold the ranks' checksum contributions in stream order
+        total_in, chk = 0, (0 if flags == 2 else 1)
+        for ex in info["extras"]:
+            c, ln = int(ex[0]), int(ex[1])
+            if flags == 2:
+                chk = L.crc32_append(chk, c, ln)
+            elif flags == 1:
+                chk = L.L.zultra_adler32_append(chk, c & 0xffff, c >> 16, ln)
+            total_in += ln
         avg = {k: float(np.mean([t[k] for t in timings])) for k in timings[0]}
         kernels = {"zh_mf_group": avg["group_ms"], "zh_mf_frontier": avg["frontier_ms"],
                    "zh_barriers+zh_tokenize_spans+zh_split": avg["tokenize_split_ms"], "zh_plan_subblocks+zh_sb_init": avg["init_ms"],
@@ -202,55 +392,335 @@ def main():
         launch_ms = kernels[dom] / launches[dom]
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         traffic, traffic_src = committed_traffic(dom)
-        line = {
-            "metric": "input MB/s, gzip 64 KiB max-blocks, enwik8-sized text, bit-exact vs CPU zultra",
-            "value": round(total_in / (dt / args.steps) / 1e6, 3), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8/int32", "data": data_kind,
-            "config": {"workload": "%s %d B per GPU, gzip (nFlags=2), nMaxBlockSize=%d, %d max-blocks per GPU" % (
-                "enwik8" if data_kind == "enwik8" else "enwik8-sized seeded text-like synthetic (enwik8 absent)", n, bs, nblocks),
-                "parallelism": "blocks sharded over %d GPU(s), descriptor all-gather + byte gather to rank 0" % world},
-            "kernel_ms": {k: round(v, 3) for k, v in kernels.items()},
+        st = res["stats"]
+        res.update({
+            "body": body, "checksum": chk, "total_in": total_in, "ms_per_step": dt / steps * 1e3,
+            "MBps": total_in / (dt / steps) / 1e6, "kernel_ms": {k: round(v, 3) for k, v in kernels.items()},
             "device_pipeline_ms": round(avg["total_ms"], 3), "d2h_ms": round(avg["d2h_ms"], 3),
             "kernel_only_MBps": round(n / (sum(kernels.values()) * 1e-3) / 1e6, 3),
-            "compressed_bytes_per_gpu": int(out_bytes),
+            "sub_blocks_per_block": round(st["subblocks"] / max(1, st["blocks"]), 3),
+            "parse_huge_share_of_positions": round(st["huge_positions"] / max(1, st["positions"]), 4),
+            "parse_tasks": st["tasks"], "parse_huge_tasks": st["huge_tasks"],
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(launch_ms, 3),
                          "launches_per_step": launches[dom]},
+        })
+    return res
+
+
+def summarize_leg(r):
+    return {k: r[k] for k in ("ms_per_step", "kernel_ms", "device_pipeline_ms", "d2h_ms", "kernel_only_MBps", "sub_blocks_per_block",
+                              "parse_huge_share_of_positions", "parse_tasks", "parse_huge_tasks")}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def prepare_stream_config(args, rank, world):
+    """CPU side of configurations 2-4, before this process touches the GPU: this rank's shard and the CPU reference timing."""
+    cfg = args.config
+    if cfg == 2:
+        flags, bs, size = 2, args.block or 65536, args.size or 100_000_000
+        corp, data_note = text_corpus(world, size)
+        metric = "input MB/s, gzip 64 KiB max-blocks, enwik8-sized text, bit-exact vs CPU zultra"
+    elif cfg == 3:
+        flags, bs, size = 1, args.block or 32768, args.size or 51_220_480
+        corp, data_note = binary_corpus(world, size)
+        metric = "input MB/s + size vs zlib-9, zlib framing 32 KiB max-blocks, silesia/mozilla-sized binary, bit-exact vs CPU zultra"
+    else:
+        flags, bs, size = 2, args.block or 65536, args.size or (1 << 30)
+        corp, data_note = MixedConfig4(), "synthetic 8 GiB mixed-entropy corpus (tests/gen/zgen.c: splitmix64 seed 0x5EED, 1 MiB segments over the self-test grid, 1/16 noise, 1/16 constant): 1 GiB per GPU"
+        metric = "input MB/s, gzip 64 KiB max-blocks, synthetic mixed-entropy corpus 1 GiB per GPU, bit-exact vs CPU zultra"
+    lead, shard = corp.shard(rank, size)
+    cb = ref_out = None
+    sample = shard[: min(args.cpu_sample, len(shard))]
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.profile_run:
+        cb, ref_out = cpu_baseline_stream(sample, flags, bs, corp.name)
+    return dict(cfg=cfg, flags=flags, bs=bs, size=size, corp=corp, data_note=data_note, metric=metric, lead=lead, shard=shard, sample=sample, cb=cb,
+                ref_out=ref_out)
+
+
+def run_stream_config(args, env, prep):
+    L, rank, world = env["L"], env["rank"], env["world"]
+    cfg, flags, bs, size, corp, data_note, metric = (prep[k] for k in ("cfg", "flags", "bs", "size", "corp", "data_note", "metric"))
+    lead, shard, sample, cb, ref_out = (prep[k] for k in ("lead", "shard", "sample", "cb", "ref_out"))
+    head = run_stream_leg(env, lead, shard, flags, bs, args.steps, args.warmup)
+    line = None
+    failed = False
+    if rank == 0:
+        line = {
+            "metric": metric, "value": round(head["MBps"], 3), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(head["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32",
+            "data": "real" if corp.name.startswith(("enwik8", "real")) else "synthetic",
+            "config": {"workload": "config %d: %s, %d B per GPU, flags=%d, nMaxBlockSize=%d, %d max-blocks per GPU" % (cfg, data_note, size, flags, bs, head["nblocks"]),
+                       "parallelism": "blocks sharded over %d GPU(s), phase-table all-gather + exact-length transfers to rank 0" % world},
+            "rccl_ranks_seen": env["ranks_seen"],
         }
+        line.update(summarize_leg(head))
+        line["compressed_bytes_total"] = len(head["body"])
+        line["roofline"] = head["roofline"]
         if args.profile_run:
             L.traffic_probe(256 << 20)
-            print(json.dumps(line), flush=True)
-            ctx.close()
-            return
-        # outside the timed region: the stream must inflate to the input, and match zlib-9 ratio expectations
-        import zlib
-        hdr = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 2, 255])
-        footer = int(crc).to_bytes(4, "little") + int(n & 0xffffffff).to_bytes(4, "little")
-        body = body.tobytes()
-        if world == 1:
-            gz = hdr + body + footer
-            ok = zlib.decompress(gz, 31) == shard.tobytes()
-            line["inflate_roundtrip_ok"] = bool(ok)
-            z9 = len(zlib.compress(shard[: 8 << 20].tobytes(), 9))
-            mine = len(L.memory_compress(shard[: 8 << 20], 2, bs))
-            line["size_vs_zlib9_first_8MiB"] = round(mine / z9, 5)
-        else:
-            d = zlib.decompressobj(-15)
-            first = d.decompress(body, n)   # rank 0's shard must come back exactly
-            line["inflate_roundtrip_ok"] = bool(first == shard.tobytes())
-        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only
-            sample = shard[: min(args.cpu_sample, n)]
-            cb, ref_out = cpu_baseline(sample, flags, bs)
+            return line, False
+        bw = L.copy_bandwidth(1 << 30, 5)
+        if bw > 0:
+            line["roofline"]["peak_measured"] = round(bw, 1)
+            line["roofline"]["frac_of_measured"] = round(head["roofline"]["achieved"] / bw, 6)
+        framed = frame(L, flags, head["body"].tobytes(), head["checksum"], head["total_in"])
+        ok = inflate_check(flags, framed, shard, head["total_in"])
+        line["inflate_roundtrip_ok"] = ok
+        failed |= not ok
+    ctx, d_data = head.pop("ctx"), head.pop("d_data")
+    ctx.close()
+    del d_data
+
+    if rank == 0 and world == 1:
+        # whole-input ratio against zlib-9 (README.md:16-46 quotes sizes against zlib/zopfli)
+        t0 = time.perf_counter()
+        z9 = len(zlib.compress(shard.tobytes(), 9))
+        line["size_vs_zlib9"] = round(len(framed) / (z9 + (12 if flags == 2 else 0)), 5)
+        line["zlib9_MBps_1core"] = round(len(shard) / (time.perf_counter() - t0) / 1e6, 1)
+        # the drop-in entry on a host buffer: H2D, kernels, stitch, D2H, frame (PCIe-inclusive; never `value`)
+        best, out = None, None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            out = L.memory_compress(shard, flags, bs)
+            dtm = time.perf_counter() - t0
+            best = dtm if best is None else min(best, dtm)
+        line["end_to_end_MBps"] = round(len(shard) / best / 1e6, 1)
+        same = out == framed
+        line["memory_compress_equals_sharded_pipeline"] = bool(same)
+        failed |= not same
+        if cb is not None:
             line["cpu_baseline"] = cb
             gpu_out = L.memory_compress(sample, flags, bs)
             line["bit_exact_vs_cpu_on_sample"] = bool(gpu_out == ref_out)
-        print(json.dumps(line), flush=True)
+            failed |= gpu_out != ref_out
+        if cfg == 2 and not args.no_synthetic:
+            # round 1's headline corpus, for continuity: Zipf words without repeated phrases (never splits, never hits the chain parse)
+            slead, sshard = SyntheticText().shard(0, size)
+            syn = run_stream_leg(env, slead, sshard, flags, bs, args.steps, args.warmup)
+            sframed = frame(L, flags, syn["body"].tobytes(), syn["checksum"], syn["total_in"])
+            sok = inflate_check(flags, sframed, sshard, syn["total_in"])
+            failed |= not sok
+            syn.pop("ctx").close()
+            syn.pop("d_data")
+            line["synthetic_text"] = dict(summarize_leg(syn), MBps=round(syn["MBps"], 3), inflate_roundtrip_ok=sok,
+                                          roofline_frac=syn["roofline"]["frac"], compressed_bytes=len(syn["body"]))
+    return line, failed
 
+
+def prepare_config1(args, rank, world):
+    import corpus
+    data = corpus.bootstrap_js()
+    cb, ref_out = cpu_baseline_stream(data, 0, 0, "bootstrap.min.js v3.4.1")
+    return dict(data=data, cb=cb, ref_out=ref_out)
+
+
+def run_config1(args, env, prep):
+    """Plumbing: one small file, raw deflate, default block size; known answer from the compiled reference (tests/golden)."""
+    import golden_util
+    L = env["L"]
+    data, cb, ref_out = prep["data"], prep["cb"], prep["ref_out"]
+    case_raw, case_gz = golden_util.stream_case("bootstrap_raw_default"), golden_util.stream_case("bootstrap_gzip_default")
+    out = L.memory_compress(data, 0, 0)
+    for _ in range(args.warmup):
+        L.memory_compress(data, 0, 0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = L.memory_compress(data, 0, 0)
+    dt = (time.perf_counter() - t0) / args.steps
+    gz = L.memory_compress(data, 2, 0)
+    ok = out == case_raw["out"] and gz == case_gz["out"] and out == ref_out and zlib.decompress(out, -15) == data.tobytes()
+    ctx = L.context(0, 1)
+    ctx.compress_blocks(data, [(0, 0, len(data))])
+    ctx.compress_blocks(data, [(0, 0, len(data))])
+    t = ctx.timing()
+    kern = {k: t[k] for k in ("group_ms", "frontier_ms", "tokenize_split_ms", "init_ms", "parse_ms", "build_ms", "post_ms", "emit_ms")}
+    dom = max(kern, key=lambda k: kern[k])
+    nl = 4 if dom in ("parse_ms", "build_ms") else 1
+    achieved = (len(data) + len(out)) / (kern[dom] / nl * 1e-3) / 1e9
     ctx.close()
+    line = {"metric": "input MB/s, bootstrap.min.js raw deflate, one max-block, known answer", "value": round(len(data) / dt / 1e6, 3), "unit": "MB/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/int32", "data": "real",
+            "config": {"workload": "config 1: the image's bootstrap.min.js v3.4.1 (39 680 B; the README's 48 944-byte file is absent), raw deflate, default block size, through zultra_memory_compress (host buffer, PCIe-inclusive: a single latency-bound call)"},
+            "compressed_bytes": len(out), "expected_bytes_raw": case_raw["out_len"], "gzip_bytes": len(gz), "expected_bytes_gzip": case_gz["out_len"],
+            "known_answer_ok": bool(ok), "device_ms": {k: round(v, 3) for k, v in kern.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 5), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 8),
+                         "traffic": None, "launch_ms": round(kern[dom] / nl, 3), "launches_per_step": nl},
+            "cpu_baseline": cb}
+    return line, not ok
+
+
+def prepare_config5(args, rank, world):
+    import corpus
+    size, nfiles = 4096, args.files
+    host = corpus.json_files(rank * nfiles, nfiles, size)
+    cb = digest = None
+    ncpu = min(nfiles, args.cpu_files)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.profile_run:
+        cb, digest = cpu_baseline_files(host[: ncpu * size], size, 2)   # forks: must precede any GPU call of this process
+    return dict(host=host, cb=cb, digest=digest, ncpu=ncpu)
+
+
+def run_config5(args, env, prep):
+    """1 000 000 x 4 KiB JSON-like inputs per GPU, each its own gzip stream: files mode, one hipGraph replay per batch."""
+    L, torch, dist, device, rank, world = env["L"], env["torch"], env["dist"], env["device"], env["rank"], env["world"]
+    size, nfiles, batch = 4096, args.files, args.batch
+    host, cb, digest, ncpu = prep["host"], prep["cb"], prep["digest"], prep["ncpu"]
+    d = torch.from_numpy(host).to(device)
+    torch.cuda.synchronize()
+    ctx = L.files_context(size, batch, device=env["local_rank"])
+    nb = (nfiles + batch - 1) // batch
+    sizes_full = np.full(batch, size, dtype=np.uint32)
+    timings = []
+    keep = {}
+
+    def step(collect=False):
+        out_bytes = 0
+        for b in range(nb):
+            k = min(batch, nfiles - b * batch)
+            offs = (np.arange(k, dtype=np.uint64) + np.uint64(b * batch)) * np.uint64(size)   # absolute: one base pointer -> one captured graph
+            fo = ctx.compress_files(d.data_ptr(), offs, sizes_full[:k], data_on_device=True, data_size=d.numel())
+            stream = ctx.stream_read(int(fo[-1]))
+            crcs = ctx.block_crc32()
+            out_bytes += int(fo[-1]) + 18 * k
+            timings.append(ctx.timing())
+            if collect and b == 0:
+                keep.update(fo=fo.copy(), stream=stream.copy(), crcs=crcs.copy())
+        return out_bytes
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):   # the first pass captures the graphs
+        step()
+    timings.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_bytes = step()
+    barrier()
+    dt = time.perf_counter() - t0
     if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    step(collect=True)
+    line, failed = None, False
+    if rank == 0:
+        # checks on the first batch: every file framed as gzip inflates to its input; the first files equal the CPU reference
+        fo, stream, crcs = keep["fo"], keep["stream"], keep["crcs"]
+        k0 = min(batch, nfiles)
+        hdr = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 2, 255])
+        h = hashlib.sha256()
+        ok = True
+        for k in range(min(k0, max(ncpu, 2048))):
+            raw = stream[int(fo[k]):int(fo[k + 1])].tobytes()
+            gz = hdr + raw + int(L.crc32_append(0, crcs[k], size)).to_bytes(4, "little") + int(size).to_bytes(4, "little")
+            if k < ncpu:
+                h.update(gz)
+            if zlib.decompress(gz, 31) != host[k * size:(k + 1) * size].tobytes():
+                ok = False
+        failed |= not ok
+        avg_graph = float(np.mean([t["encode_ms"] for t in timings]))
+        avg_stitch = float(np.mean([t["stitch_ms"] for t in timings]))
+        in_b, out_b = min(batch, nfiles) * size, out_bytes / nb
+        achieved = (in_b + out_b) / (avg_graph * 1e-3) / 1e9
+        line = {"metric": "files/s, 4 KiB JSON-like inputs, one gzip stream each, bit-exact vs CPU zultra", "value": round(world * nfiles / (dt / args.steps), 1),
+                "unit": "files/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+                "config": {"workload": "config 5: %d x %d B JSON-like inputs per GPU (tests/gen/zgen.c), each its own gzip stream, batches of %d inputs, one hipGraph replay + one stitch launch per batch" % (nfiles, size, batch)},
+                "rccl_ranks_seen": env["ranks_seen"], "input_MBps": round(world * nfiles * size / (dt / args.steps) / 1e6, 2),
+                "ratio": round(out_bytes / (nfiles * size), 4), "graph_ms_per_batch": round(avg_graph, 3), "stitch_ms_per_batch": round(avg_stitch, 3),
+                "gzip_roundtrip_ok_first_files": bool(ok),
+                "roofline": {"bound": "hbm", "kernel": "hipGraph of stages 1-3 (dominant: zh_parse_tasks)", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                             "algorithmic_bytes_per_launch": int(in_b + out_b), "launch_ms": round(avg_graph, 3), "launches_per_step": nb}}
+        if args.profile_run:
+            L.traffic_probe(256 << 20)
+        elif cb is not None:
+            line["cpu_baseline"] = cb
+            line["bit_exact_vs_cpu_on_sample"] = bool(h.hexdigest() == digest)
+            failed |= h.hexdigest() != digest
+    ctx.close()
+    return line, failed
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5], help="BASELINE.json configuration (default 2: the one the metric is quoted on)")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=0, help="bytes per GPU (default: the configuration's own size)")
+    ap.add_argument("--block", type=int, default=0, help="nMaxBlockSize (default: the configuration's own)")
+    ap.add_argument("--files", type=int, default=1_000_000, help="config 5: inputs per GPU")
+    ap.add_argument("--batch", type=int, default=1 << 16, help="config 5: inputs per device batch")
+    ap.add_argument("--cpu-sample", type=int, default=32 << 20, help="bytes of the shard the CPU reference is timed on")
+    ap.add_argument("--cpu-files", type=int, default=4096, help="config 5: files the CPU reference is timed on")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-synthetic", action="store_true", help="config 2: skip the synthetic-text leg")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for rocprofv3 passes: only the steps (no round-trip / ratio / CPU extras that would add dispatches), then the PMC calibration probe")
+    args = ap.parse_args()
+
+    have_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not have_launcher:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0")) if have_launcher else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank))) if have_launcher else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if have_launcher else 1
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d\n" % (args.gpus, world))
+        sys.exit(2)
+    if args.config == 1 and world > 1:
+        sys.stderr.write("bench.py: configuration 1 is a single 39 680-byte input: there is nothing to shard\n")
+        sys.exit(2)
+
+    # ---- CPU side first: corpus generation and the CPU reference timing (config 5 forks worker processes) -------------------
+    prep = {1: prepare_config1, 5: prepare_config5}.get(args.config, prepare_stream_config)(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+
+    import zultra_amd
+
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d needs GPU %d but %d GPU(s) are visible\n" % (rank, local_rank, torch.cuda.device_count()))
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    ranks_seen = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        one = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(one)   # every rank present and reachable over RCCL
+        ranks_seen = int(one.item())
+        if ranks_seen != world:
+            sys.stderr.write("bench.py: %d ranks answered, %d expected\n" % (ranks_seen, world))
+            sys.exit(2)
+
+    L = zultra_amd.lib()   # raises if libzultra_amd.so is missing: there is no fallback path
+    if L.device_count() < 1:
+        raise RuntimeError("no HIP device")
+    env = {"L": L, "torch": torch, "dist": dist, "device": device, "rank": rank, "local_rank": local_rank, "world": world, "ranks_seen": ranks_seen}
+
+    line, failed = {1: run_config1, 5: run_config5}.get(args.config, run_stream_config)(args, env, prep)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int64, device=device)
+        dist.all_reduce(flag)
+        failed = bool(flag.item())
         dist.destroy_process_group()
+    if failed:
+        sys.stderr.write("bench.py: a correctness check failed (see the JSON line)\n")
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -220,6 +220,7 @@ inline uint32_t zh_wave_min(uint32_t v) {
       return m;
    });
 }
+inline uint32_t zh_wave_min_bcast(uint32_t v) { return zh_wave_min(v); }
 inline uint32_t zh_wave_sum(uint32_t v) {
    using namespace zh_emu;
    return (uint32_t)collect(v, [] {

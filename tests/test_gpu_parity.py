@@ -272,3 +272,109 @@ def test_large_max_blocks_streams_vs_oracle(gpu, oracle, kind, flags, bs):
         d = corpus.json_like(3_000_000, 9)
     got = gpu.memory_compress(d, flags, bs)
     assert got == oracle.memory_compress(d, flags, bs)
+
+
+def test_config4_one_gib_shard(gpu, oracle):
+    """BASELINE configuration 4, one GPU's share: 1 GiB (16 384 max-blocks of 64 KiB) of the mixed-entropy corpus of
+    tests/gen/zgen.c as ONE batch. Inflate round trip of the whole gzip stream (zlib checks the
+    CRC-32 folded from the device's per-block values), and eight random max-blocks stage by stage against the oracle."""
+    d = corpus.mixed_config4(0, 1024)
+    n, bs = len(d), 65536
+    nb = n // bs
+    blocks = [(b * bs - (32768 if b else 0), 32768 if b else 0, bs) for b in range(nb)]
+    ctx = gpu.context(bs, nb)
+    try:
+        ctx.compress_blocks(d, blocks)   # (host buffer: torch cannot initialise its own HIP runtime in a process where the library did first)
+        crc = gpu.crc32_append_many(0, ctx.block_crc32(), np.full(nb, bs, dtype=np.uint32))
+        end_bit, _ = ctx.stitch_device(nb - 1, phase=0)
+        body = ctx.stream_read((end_bit + 7) // 8).tobytes()
+        st = ctx.stats()
+        assert st["blocks"] == nb and st["positions"] == n
+    finally:
+        ctx.close()
+    gz = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 2, 255]) + body + int(crc).to_bytes(4, "little") + int(n & 0xffffffff).to_bytes(4, "little")
+    dec = zlib.decompressobj(31)
+    pos = 0
+    for off in range(0, len(gz), 16 << 20):
+        out = dec.decompress(gz[off:off + (16 << 20)])
+        assert out == d[pos:pos + len(out)].tobytes(), "inflated bytes differ near %d" % pos
+        pos += len(out)
+    assert dec.eof and pos == n
+    rs = np.random.RandomState(4)
+    for blk in sorted(int(x) for x in rs.randint(1, nb, size=8)):
+        lo = blk * bs
+        check_window(gpu, oracle, d[lo - 32768: lo + bs], 32768, bs, max_block=bs, tag="config4_blk%d" % blk)
+
+
+def test_files_context_rejects_inputs_above_its_declared_size(gpu):
+    """A files context never splits an input; from 8192 bytes on the reference's splitter may (blockdeflate.c:646), so an
+    input larger than the size the context was created for must be refused, not compressed differently."""
+    import zultra_amd
+    ctx = gpu.files_context(8191, 4)
+    try:
+        d = np.concatenate([corpus.text_like(4000, 3), corpus.noise(4192, 5)])
+        with pytest.raises(zultra_amd.ZultraError):
+            ctx.compress_files(d, [0], [8192])
+        fo = ctx.compress_files(d, [0], [8191])
+        assert fo[-1] > 0
+    finally:
+        ctx.close()
+
+
+def test_two_threads_compress_different_streams(gpu, oracle):
+    """The reference is re-entrant (no globals): two host threads with a stream each must not disturb one another."""
+    import threading
+    inputs = [np.concatenate([corpus.text_like(400000, 41), corpus.noise(70000, 6)]), corpus.mixed(450000, 42)]
+    params = [(2, 65536), (1, 32768)]
+    want = [oracle.memory_compress(d, f, b) for d, (f, b) in zip(inputs, params)]
+    got = [[None] * 3, [None] * 3]
+
+    def work(i):
+        for rep in range(3):
+            got[i][rep] = gpu.memory_compress(inputs[i], params[i][0], params[i][1])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        for rep in range(3):
+            assert got[i][rep] == want[i], (i, rep)
+
+
+def test_bench_refuses_more_gpus_than_present(gpu):
+    """`bench.py --gpus N` must never report a smaller job as N: on a box with fewer GPUs it fails loudly."""
+    import os
+    import subprocess
+    import sys
+
+    n = gpu.device_count()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode != 0
+    assert b"n_gpus" not in p.stdout
+    assert b"GPU(s) visible" in p.stderr
+    # a launcher whose WORLD_SIZE disagrees with --gpus is an error too
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode != 0 and b"WORLD_SIZE" in p.stderr
+
+
+def test_bench_config1_known_answer():
+    """BASELINE configuration 1 through bench.py: the image's bootstrap.min.js -> 10 523 bytes of raw deflate (golden from the
+    compiled reference), on the GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if not os.path.exists(corpus.BOOTSTRAP_JS):
+        pytest.skip("bootstrap.min.js is not in this image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["known_answer_ok"] and line["compressed_bytes"] == 10523 and line["gzip_bytes"] == 10541
+    assert "roofline" in line and "cpu_baseline" in line

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzultra_amd.so")
 SOURCES = ["zh_device.hip", "libzultra.cpp"]
-HEADERS = ["zh_platform.h", "zh_common.h", "zh_matchfinder.h", "zh_huffman.h", "zh_split.h", "zh_parse.h", "zh_parse_huge.h", "zh_encode.h", "zh_stitch.h"]
+HEADERS = ["zh_platform.h", "zh_common.h", "zh_matchfinder.h", "zh_huffman.h", "zh_split.h", "zh_parse.h", "zh_parse_chain.h", "zh_encode.h", "zh_stitch.h"]
 
 
 def hipcc_path():

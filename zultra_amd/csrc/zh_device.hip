@@ -30,7 +30,7 @@
 #include "zh_huffman.h"
 #include "zh_matchfinder.h"
 #include "zh_parse.h"
-#include "zh_parse_huge.h"
+#include "zh_parse_chain.h"
 #include "zh_split.h"
 #include "zh_stitch.h"
 
@@ -72,7 +72,7 @@ struct zultra_hip_ctx_s {
    uint64_t bar_stride, max_tasks;
    zh_sbstate_t *d_states;
    uint2 *d_taskmap;
-   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: per run [0..3] tasks, [4..7] tasks listed for zh_parse_huge, [8..11] their positions
+   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: per run [0..3] tasks, [4..7] tasks listed for zh_parse_chain, [8..11] their positions, [16 + 4 run + pass] its tickets
    uint32_t *h_ntasks;          // pinned mirror, read after the batch (zultra_hip_last_stats)
    uint32_t *d_hugelist;
    hipEvent_t ev2[16];
@@ -92,7 +92,7 @@ struct zultra_hip_ctx_s {
    int nlanes;
    hipStream_t lane_stream[4];
    hipEvent_t lane_ev[4][24];
-   hipStream_t side_stream[4];     // per run: zh_parse_huge runs next to zh_parse_tasks
+   hipStream_t side_stream[4];     // per run: zh_parse_chain runs next to zh_parse_tasks
    hipEvent_t side_ev[4][8];       // per pass: fork, join
    hipEvent_t ev_input;
    zh_subblock_t *d_results_compact;
@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(64) zh_selftest_kernel(uint32_t seed, uint32_t
          if ((k >> 4) == (lane >> 4)) rmn = min(rmn, v[k]);
       }
       if (zh_wave_min(x) != mn) errors++;
+      if (zh_wave_min_bcast(x) != mn) errors++;
       if (zh_wave_sum(x) != sm) errors++;
       if (zh_wave_excl_sum(x) != ex) errors++;
       if (zh_row_min(x) != rmn) errors++;
@@ -267,9 +268,9 @@ extern "C" double zultra_hip_copy_bandwidth(size_t nbytes, int iters) {
    return 2.0 * (double)(n16 * 16) * iters / (ms * 1e-3) / 1e9;
 }
 
-// The pipeline uses up to five streams per context (two runs, a side stream each for zh_parse_huge, one for the stitcher) next
+// The pipeline uses up to five streams per context (two runs, a side stream each for zh_parse_chain, one for the stitcher) next
 // to the application's own. The HIP runtime multiplexes streams onto 4 hardware queues by default, and two streams that
-// share a queue run strictly one after the other: measured, a run's zh_parse_huge then blocks the other run's kernels
+// share a queue run strictly one after the other: measured, a run's zh_parse_chain then blocks the other run's kernels
 // (source code, three runs: 89 ms per 50 MB with 4 queues, 60 ms with 8). The variable is read when the runtime
 // initialises, so it is set when the library is loaded — unless the application chose a value or initialised HIP earlier.
 __attribute__((constructor)) static void zh_runtime_hints(void) { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
@@ -375,7 +376,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
          ZH_CHECK(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
          for (int i = 0; i < 24; i++) ZH_CHECK(c, hipEventCreate(&c->lane_ev[k][i]));
          {
-            // zh_parse_huge is a few workgroups following long chains: it should never queue behind the wide kernels
+            // zh_parse_chain is a few workgroups following long chains: it should never queue behind the wide kernels
             int lo_prio = 0, hi_prio = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
             ZH_CHECK(c, hipStreamCreateWithPriority(&c->side_stream[k], hipStreamNonBlocking, hi_prio));
@@ -396,7 +397,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
-       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, 16) || zh_alloc(c, &c->d_hugelist, c->max_tasks) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, 32) || zh_alloc(c, &c->d_hugelist, c->max_tasks) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
@@ -570,7 +571,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
              (const uint2 *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
    if (zh_enqueue_tokenize(c, st, blk, 0, nb) != 0) return -1;
    ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 16 * sizeof(uint32_t), st));
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 32 * sizeof(uint32_t), st));
    ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, (size_t)nb * c->slot_stride, st));
    ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)c->d_tok_pos, c->tok_stride, (const uint32_t *)c->d_ntok,
              (const uint32_t *)c->d_split_tok, (const uint32_t *)c->d_split_cnt, (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work, c->d_taskmap,
@@ -580,13 +581,14 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap,
              (const uint32_t *)c->d_ntasks, c->d_hugelist, c->d_ntasks + 4, c->d_ntasks + 8);
    for (int pass = 0; pass <= 3; pass++) {
-      // the tasks with barrier-free runs (zh_parse_huge: few workgroups, long) next to all the others
+      // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       hipStream_t side = c->side_stream[0];
       ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass], st));
       ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[0][2 * pass], 0));
-      ZH_LAUNCH(zh_parse_huge, min(nb, (uint32_t)ZH_HUGE_GRID), ZH_HUGE_THREADS, side, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride,
+      ZH_LAUNCH(zh_parse_chain, min(nb, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride,
                 (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_hugelist,
-                (const uint32_t *)(c->d_ntasks + 4), (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride, c->d_hist_part, pass);
+                (const uint32_t *)(c->d_ntasks + 4), (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride, c->d_hist_part, pass,
+                c->d_ntasks + 16 + pass);
       ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass + 1], side));
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride,
                 (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
@@ -751,7 +753,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    // ---- stage 3 of every run: the sub-block coder, one kernel per step over the run (zh_encode.h) -------------------
    uint32_t nsubs = 0;
    uint32_t lane_sub0[4], lane_nsubs[4];
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 16 * sizeof(uint32_t), st0));
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 32 * sizeof(uint32_t), st0));
    ZH_CHECK(c, hipEventRecord(c->ev2[0], st0));
    for (int k = 0; k < lanes; k++) {
       hipStream_t st = c->lane_stream[k];
@@ -797,13 +799,13 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 ntasks + 4, ntasks + 8);
       ZH_CHECK(c, hipEventRecord(ev[5], st));
       for (int pass = 0; pass <= 3; pass++) {
-         // the tasks with barrier-free runs (zh_parse_huge: few workgroups, long) next to all the others
+         // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
          hipStream_t side = c->side_stream[k];
          ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
          ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
-         ZH_LAUNCH(zh_parse_huge, ZH_HUGE_GRID, ZH_HUGE_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+         ZH_LAUNCH(zh_parse_chain, ZH_CHAIN_GRID, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                    (const uint2 *)taskmap, (const uint32_t *)hugelist, (const uint32_t *)(ntasks + 4), (const zh_sbstate_t *)states, best, c->best_stride,
-                   hist_part, pass);
+                   hist_part, pass, c->d_ntasks + 16 + 4 * k + pass);
          ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
          ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                    (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass);

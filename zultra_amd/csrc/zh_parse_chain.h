@@ -1,0 +1,363 @@
+// zh_parse_chain.h — the optimal parse (zh_parse.h) of a barrier-free run as ONE chain: repeated boilerplate, near-copies of
+// earlier data, constant padding — a 64 KiB max-block of such data can be a single run, and then the recurrence
+// cost[p] <- cost[p+1 .. p+258] (reference src/blockdeflate.c:254-323) is the whole run time of the batch. One wave alone on a
+// SIMD issues an instruction every 4-5 cycles whatever it is (measured, tools/probes), so what decides the speed of the chain
+// is the instruction count of one position's step on the wave that carries the recurrence — everything that does not depend
+// on the costs is done by other waves of the workgroup.
+//
+// Workgroup = 4 waves, one chain at a time:
+//   producers (waves 1, 2)  digest the match rows of the NEXT tile of 32 positions (loads issued a tile period earlier) and write
+//                           one 32-bit descriptor per (position, candidate): price of the candidate in the bits the costs are
+//                           kept in, below it the (slot, length) bits that break ties the way the reference's evaluation order
+//                           does, and — for the slots stored with length >= 40, tried at full length only
+//                           (blockdeflate.c:286-297) — above it the cost-ring entry that holds cost[p + length];
+//   flusher   (wave 3)      turns the winning keys of the PREVIOUS tile into parse entries and stores them;
+//   consumer  (wave 0)      one position per step, candidate = lane: lane j < 37 prices length 3+j, lanes 40..47 the long slots.
+//                           The costs live in REGISTERS across the lanes: lane j holds cost[p+3+j], and moving to p-1 is one DPP
+//                           wave shift with cost[p+2] — known two steps earlier — entering at lane 0. So a step is: one LDS read
+//                           (descriptor), one LDS gather for the long slots, select, add, a wave-wide minimum (six DPP steps and a
+//                           readlane), and the scalar literal-or-match decision: ~22 instructions, none of which touches the cost
+//                           ring on the way from cost[p+1] to cost[p]. (The previous kernel priced three positions per step with the
+//                           costs in an LDS ring: 185 cycles per position, 40 % of them LDS traffic for the ring.)
+// Costs are kept as cost << 9 in 32 bits, absolute from the chain's end; every tile the consumer dumps its 32 new costs into
+// a 512-entry LDS ring for the long slots (whose targets are >= 40 positions away, i.e. always in an earlier tile) and, when the
+// costs approach 2^30, subtracts a common base from registers and ring. Ring entry i stores cost - (i << 23): a long
+// descriptor carries its ring index in bits 23..31, where it doubles as the address of the gather (descriptor >> 21) and
+// cancels out when descriptor and gathered value are added.
+#pragma once
+#include "zh_parse.h"
+
+#define ZH_CHAIN_THREADS 256
+#define ZH_CHAIN_TILE 32u
+#define ZH_CHAIN_RING 512u
+// price field of a candidate that does not exist: above every real difference between two costs at most 258 positions apart
+// (258 x 15 bits) plus any price, so it never beats the literal — and its bits 21..22 are clear (the gather address stays aligned)
+#define ZH_CHAIN_NOPRICE (4095u << 9)
+#define ZH_CHAIN_LONG0 40u           // consumer lane of long slot 0
+#define ZH_CHAIN_REBASE (1u << 30)
+
+struct zh_chain_ws_t {
+   union {
+      struct {
+         uint32_t ring[ZH_CHAIN_RING];                    // entry i: (cost << 9) - (i << 23) of the position p with p % 512 == i
+         uint32_t desc[2][ZH_CHAIN_TILE][65];             // [tile parity][position, top first][consumer lane]; the odd row stride spreads
+                                                          // the producers' stores (16 positions per store instruction) over the LDS banks
+         uint32_t bt[2][ZH_CHAIN_TILE];                   // winning key per position; low 9 bits zero = literal
+      } p;
+      uint32_t hist[ZH_NSYM];                             // after the parse: histogram of the range
+   };
+   uint8_t litprice[ZH_NLIT];
+   uint8_t lencost[256];
+   uint8_t distcost[ZH_NDIST];
+};
+
+// what a producer thread loads from HBM for one position (issued a whole tile period before it is digested)
+struct zh_chain_fetch_t {
+   uint4 a, b;
+   uint32_t byte;
+};
+
+// producer thread pl = 4 j + part: position thi-1-j of the tile [thi - cnt, thi)
+__device__ __forceinline__ void zh_chain_fetch(zh_chain_fetch_t &f, const uint4 *rows, const uint8_t *win, uint32_t prev, uint32_t thi, uint32_t cnt, uint32_t pl) {
+   const uint32_t j = pl >> 2;
+   const uint32_t pos = j < cnt ? thi - 1 - j : thi - 1;   // clamped: the loads are always legal
+   f.a = rows[(uint64_t)(pos - prev) * 2];
+   f.b = rows[(uint64_t)(pos - prev) * 2 + 1];
+   f.byte = win[pos];
+}
+
+// producer: stage tile [thi - cnt, thi) into parity `buf`. Thread pl = 4 j + part writes the 16 descriptors of consumer lanes
+// 16 part .. 16 part + 15 of position thi-1-j (part 0: lengths 3..18, 1: 19..34, 2: 35..39, 3: the slots stored with length >= 40).
+__device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, const zh_chain_fetch_t &f, uint32_t thi, uint32_t cnt, uint32_t sb_end, uint32_t pl) {
+   const uint32_t j = pl >> 2, part = pl & 3u;
+   uint32_t *d = &ws.p.desc[buf][j][16u * part];
+   const bool ok = j < cnt;
+   const uint32_t pos = ok ? thi - 1 - j : thi - 1;
+   const uint32_t room = sb_end - pos;
+   const uint32_t raw[ZH_NMATCH] = {ok ? f.a.x : 0u, ok ? f.a.y : 0u, ok ? f.a.z : 0u, ok ? f.a.w : 0u, ok ? f.b.x : 0u, ok ? f.b.y : 0u, ok ? f.b.z : 0u, ok ? f.b.w : 0u};
+   // the same digest as zh_stage_position: bitmap of short slot lengths, running minima of (distance price, slot)
+   uint32_t nlong = 0, nshort = 0, kmax = 0, run = 0xFFu;
+   uint64_t pm = 0, lmask = 0;
+   uint32_t oc[ZH_NMATCH];
+#pragma unroll
+   for (uint32_t m = 0; m < ZH_NMATCH; m++) {
+      const uint32_t len = raw[m] & 0xffffu, off = raw[m] >> 16;
+      const bool valid = len >= ZH_MIN_MATCH;
+      const bool is_long = len >= ZH_LEAVE_ALONE;
+      const bool is_short = valid && !is_long;
+      oc[m] = (uint32_t)ws.distcost[zh_dist_sym(valid ? off : 1u)];
+      nlong += is_long ? 1u : 0u;
+      kmax = max(kmax, is_short ? len : 0u);               // the first short slot is the longest
+      lmask |= is_short ? (1ull << (len - ZH_MIN_MATCH)) : 0ull;
+      run = is_short ? min(run, (oc[m] << 3) | m) : run;
+      pm |= is_short ? ((uint64_t)run << (8 * nshort)) : 0ull;
+      nshort += is_short ? 1u : 0u;
+   }
+   kmax = min(kmax, room);                                  // end clamp (blockdeflate.c:283-284)
+   if (part < 3) {
+      // lengths k = 3 + 16 part + s (part 2: lanes 32..39, of which lengths 35..39 exist): the last short slot reaching k has
+      // the cheapest distance among those that can provide it
+      const uint32_t e0 = 16u * part;
+      const uint32_t w = (uint32_t)(lmask >> e0);                              // lengths e0+3 .. e0+34
+      const uint32_t above = (uint32_t)__popcll(lmask >> (e0 + 16u) >> 16u);   // slots longer than that window
+      const uint32_t pm_lo = (uint32_t)pm, pm_hi = (uint32_t)(pm >> 32);
+      const uint32_t nl = part == 2 ? 8u : 16u;
+#pragma unroll
+      for (uint32_t i = 0; i < 16; i++) {
+         if (i >= nl) break;
+         const uint32_t s = i;
+         const uint32_t k = ZH_MIN_MATCH + e0 + s;
+         const uint32_t sel = (uint32_t)__popc(w >> s) + above - 1u;
+         const uint32_t bb = ((sel < 4 ? pm_lo : pm_hi) >> ((sel & 3u) * 8u)) & 0xffu;
+         const uint32_t price = (uint32_t)ws.lencost[(e0 + s) & 255u] + (bb >> 3);
+         const uint32_t v = (price << 9) | (((bb & 7u) << 6) + (40u - k));   // tie bits: (slot, 39 - k) + 1, the literal's are 0
+         d[s] = (k <= kmax && k < ZH_LEAVE_ALONE) ? v : ZH_CHAIN_NOPRICE;
+      }
+   }
+   else {
+      // consumer lanes 40..47: the slots stored with length >= 40, tried at their full (clamped) length only; lanes 48..63 are
+      // unused (set once per chain)
+      uint32_t *dl = &ws.p.desc[buf][j][ZH_CHAIN_LONG0];
+#pragma unroll
+      for (uint32_t i = 0; i < ZH_NMATCH; i++) {
+         const uint32_t s = i;
+         const uint32_t rs = raw[s], os = oc[s];
+         const uint32_t mlen = min(rs & 0xffffu, room);
+         uint32_t enc = mlen - ZH_MIN_MATCH;                 // wraps below 3, then saturates (:289, :216-219)
+         if (enc > 255) enc = 255;
+         const uint32_t price = (uint32_t)ws.lencost[enc] + os;
+         const uint32_t v = (((pos + mlen) & (ZH_CHAIN_RING - 1u)) << 23) | (price << 9) | ((s << 6) + 1u);
+         // a slot that does not exist gathers the cost of the tile's top (dumped a tile ago, within 32 positions of p+1): harmless
+         dl[s] = s < nlong ? v : (((thi & (ZH_CHAIN_RING - 1u)) << 23) | ZH_CHAIN_NOPRICE);
+      }
+      ws.p.desc[buf][j][63] = ok ? (uint32_t)ws.litprice[f.byte & 0xffu] << 9 : 0u;   // lane 63: the literal
+   }
+}
+
+// flusher: the winning keys of a priced tile -> parse entries (zh_decode_pick). Thread i = position thi-1-i; the position's match
+// row is read again (an L2 hit: the producers loaded it two tile periods ago).
+__device__ __forceinline__ void zh_chain_flush(zh_chain_ws_t &ws, uint32_t buf, const uint4 *rows, uint32_t prev, uint32_t thi, uint32_t cnt, uint32_t sb_end, uint32_t i,
+                                               uint32_t *best) {
+   if (i >= cnt) return;
+   const uint32_t pos = thi - 1 - i;
+   const uint32_t kk = ws.p.bt[buf][i];
+   uint32_t pick = 0;
+   if (kk & 511u) {   // low 9 bits: 0 = literal, else (slot << 6 | 39 - length) + 1
+      const uint4 a = rows[(uint64_t)(pos - prev) * 2], b = rows[(uint64_t)(pos - prev) * 2 + 1];
+      const uint32_t raw[ZH_NMATCH] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      uint32_t nlong = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < ZH_NMATCH; q++) nlong += (raw[q] & 0xffffu) >= ZH_LEAVE_ALONE ? 1u : 0u;
+      const uint32_t tb = (kk & 511u) - 1u;
+      const uint32_t m = tb >> 6;
+      uint32_t e = raw[0];
+#pragma unroll
+      for (uint32_t q = 1; q < ZH_NMATCH; q++) e = (m == q) ? raw[q] : e;
+      const uint32_t len = (m < nlong) ? min(e & 0xffffu, sb_end - pos) : (39u - (tb & 63u));
+      pick = len | (e & 0xffff0000u);
+   }
+   best[pos - prev] = pick;
+}
+
+// consumer: the recurrence over one tile, one position per step, always ZH_CHAIN_TILE steps (positions below the range's start
+// are staged as "literal of price 0, no candidates": their costs are computed and never looked at). State:
+//   cv  lane j: cost9[p + 3 + j] for the position p priced next        c1, c2 (every lane): cost9[p + 1], cost9[p + 2]
+// Lane 63 prices the literal: its descriptor is the literal's price, its cost operand c1, its tie bits zero — below every
+// match's, so "literal first; a match must be strictly cheaper" (:292,:307) is the same minimum, and the step needs no compare.
+struct zh_chain_state_t {
+   uint32_t cv, c1, c2;
+};
+
+__device__ __forceinline__ void zh_chain_consume(zh_chain_ws_t &ws, uint32_t buf, uint32_t thi, zh_chain_state_t &st) {
+   const uint32_t lane = zh_lane();
+   const bool is_long = lane >= ZH_CHAIN_LONG0 && lane < ZH_CHAIN_LONG0 + ZH_NMATCH;
+   const bool is_lit = lane == 63;
+   const uint32_t *dp = &ws.p.desc[buf][0][lane];
+   const uint8_t *ring8 = (const uint8_t *)ws.p.ring;
+   uint32_t wv = 0;
+   uint32_t cv = st.cv, c1 = st.c1, c2 = st.c2;
+   // two-stage read-ahead: the descriptor of step t+2 and the gather of step t+1 are issued in step t
+   uint32_t d = dp[0], dn = dp[65];
+   uint32_t g = *(const uint32_t *)(ring8 + (d >> 21));
+#pragma unroll
+   for (uint32_t t = 0; t < ZH_CHAIN_TILE; t++) {
+      const uint32_t dnn = dp[65u * min(t + 2u, ZH_CHAIN_TILE - 1u)];
+      const uint32_t gn = *(const uint32_t *)(ring8 + (dn >> 21));
+      const uint32_t x = is_lit ? c1 : (is_long ? g : cv);
+      const uint32_t M = zh_wave_min_bcast(x + d);
+      const uint32_t c0 = M & ~511u;
+      wv = zh_wave_shr1(wv, M);   // the winning keys travel up the lanes like the costs: lane i = step 31 - i
+      cv = zh_wave_shr1(cv, c2);
+      c2 = c1;
+      c1 = c0;
+      d = dn;
+      dn = dnn;
+      g = gn;
+   }
+   // the tile's winners for the flusher, its costs for the long slots of later tiles: cost9[thi - 32 + i] is c1, c2, then cv from lane 0 on
+   if (lane < ZH_CHAIN_TILE) ws.p.bt[buf][ZH_CHAIN_TILE - 1u - lane] = wv;
+   const uint32_t dv = zh_wave_shr1(zh_wave_shr1(cv, c2), c1);
+   if (lane < ZH_CHAIN_TILE) {
+      const uint32_t idx = (thi - ZH_CHAIN_TILE + lane) & (ZH_CHAIN_RING - 1u);
+      ws.p.ring[idx] = dv - (idx << 23);
+   }
+   st.cv = cv;
+   st.c1 = c1;
+   st.c2 = c2;
+}
+
+// every cost the consumer holds — registers and ring — minus a common base, before the 32-bit keys could wrap
+__device__ __forceinline__ void zh_chain_rebase(zh_chain_ws_t &ws, zh_chain_state_t &st) {
+   const uint32_t lane = zh_lane();
+   const uint32_t delta = (st.c1 - (1u << 24)) & ~511u;   // the live costs lie within 258 x 15 bits of c1: none goes negative
+   st.cv -= delta;
+   st.c1 -= delta;
+   st.c2 -= delta;
+   for (uint32_t k = lane; k < ZH_CHAIN_RING; k += 64) ws.p.ring[k] -= delta;
+}
+
+// Parse [t0, t1) of a sub-block as one chain, t1 a barrier or the sub-block end (cost[t1] = 0). All ZH_CHAIN_THREADS threads call.
+// ws.litprice / lencost / distcost hold the prices of the pass.
+__device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, const uint8_t *win, uint32_t prev, uint32_t t0, uint32_t t1, uint32_t sb_end,
+                                      uint32_t *best) {
+   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+   const uint32_t ntiles = t1 > t0 ? (t1 - t0 + ZH_CHAIN_TILE - 1) / ZH_CHAIN_TILE : 0u;
+   if (!ntiles) return;
+   const bool stager = wave == 1 || wave == 2;
+   const uint32_t pl = tid - 64;   // stagers: 0..127
+   zh_chain_fetch_t fnext;
+   fnext.a.x = fnext.a.y = fnext.a.z = fnext.a.w = fnext.b.x = fnext.b.y = fnext.b.z = fnext.b.w = fnext.byte = 0;
+   if (stager) {
+      zh_chain_fetch_t f0;
+      zh_chain_fetch(f0, rows, win, prev, t1, min(ZH_CHAIN_TILE, t1 - t0), pl);
+      if (ntiles > 1) zh_chain_fetch(fnext, rows, win, prev, t1 - ZH_CHAIN_TILE, min(ZH_CHAIN_TILE, t1 - ZH_CHAIN_TILE - t0), pl);
+      zh_chain_stage(ws, 0, f0, t1, min(ZH_CHAIN_TILE, t1 - t0), sb_end, pl);
+   }
+   else if (wave == 0) {
+      // cost[t1] = 0; entries above it are never asked for (t1 is a barrier or the end: no candidate reaches past it)
+      for (uint32_t k = lane; k < ZH_CHAIN_RING; k += 64) ws.p.ring[k] = 0u - (k << 23);
+   }
+   else {
+      // consumer lanes 48..62 price nothing (lane 63 is the literal)
+      for (uint32_t k = lane; k < 2u * ZH_CHAIN_TILE * 16u; k += 64)
+         if ((k & 15u) != 15u) ws.p.desc[k / (ZH_CHAIN_TILE * 16u)][(k / 16u) % ZH_CHAIN_TILE][48u + (k & 15u)] = ZH_CHAIN_NOPRICE;
+   }
+   __syncthreads();
+
+   zh_chain_state_t st;
+   st.cv = 0;   // lane j: cost9[t1 + 2 + j]: beyond the end; lane 0 receives cost9[t1] = 0 when position t1-2 is priced
+   st.c1 = 0;   // cost9[t1]
+   st.c2 = 0;
+   for (uint32_t k = 0; k < ntiles; k++) {
+      const uint32_t thi = t1 - k * ZH_CHAIN_TILE;
+      const uint32_t cnt = min(ZH_CHAIN_TILE, thi - t0);
+      const uint32_t buf = k & 1u;
+      if (wave == 0) {
+         if (st.c1 >= ZH_CHAIN_REBASE) zh_chain_rebase(ws, st);
+         zh_chain_consume(ws, buf, thi, st);
+      }
+      else if (stager) {
+         if (k + 1 < ntiles) {
+            const uint32_t nhi = thi - ZH_CHAIN_TILE;
+            const zh_chain_fetch_t f = fnext;
+            if (k + 2 < ntiles) zh_chain_fetch(fnext, rows, win, prev, nhi - ZH_CHAIN_TILE, min(ZH_CHAIN_TILE, nhi - ZH_CHAIN_TILE - t0), pl);
+            zh_chain_stage(ws, buf ^ 1u, f, nhi, min(ZH_CHAIN_TILE, nhi - t0), sb_end, pl);
+         }
+      }
+      else if (k)
+         zh_chain_flush(ws, buf ^ 1u, rows, prev, thi + ZH_CHAIN_TILE, ZH_CHAIN_TILE, sb_end, lane, best);
+      __syncthreads();
+   }
+   if (wave == 3) {
+      const uint32_t k = ntiles - 1;
+      const uint32_t thi = t1 - k * ZH_CHAIN_TILE;
+      zh_chain_flush(ws, k & 1u, rows, prev, thi, thi - t0, sb_end, lane, best);
+   }
+}
+
+// the tasks zh_parse_tasks leaves alone: one wave per task, the same piece computation
+__global__ void __launch_bounds__(64)
+zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
+             const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total, uint32_t *hugelist, uint32_t *nhuge,
+             uint32_t *huge_positions) {
+   __shared__ uint32_t bnd[ZH_MAXPIECES + 1];
+   const uint32_t gt = blockIdx.x;
+   if (gt >= *ntasks_total) return;
+   const uint2 tm = taskmap[gt];
+   const zh_work_t wk = work[tm.x];
+   const uint32_t prev = blocks[wk.block].prev;
+   const uint64_t *bar = bars + (uint64_t)wk.block * bar_stride;
+   const uint32_t lane = zh_lane(), sb_end = wk.start + wk.size;
+   const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y, wk.ntasks);
+   const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
+   const uint32_t np = zh_task_pieces(bnd, bar, prev, t0, t1, lane);
+   zh_sync();
+   if (zh_task_is_huge(bnd, np, lane) && lane == 0) {
+      hugelist[atomicAdd(nhuge, 1u)] = gt;
+      atomicAdd(huge_positions, t1 - t0);   // statistics only (zultra_hip_last_stats)
+   }
+}
+
+// Persistent workgroups take the listed tasks from a ticket: the grid is small and fixed (ZH_CHAIN_GRID), so it is dispatched at
+// once — next to zh_parse_tasks' tens of thousands of waves — and every chain starts at the beginning of the pass.
+#define ZH_CHAIN_GRID 1024
+__global__ void __launch_bounds__(ZH_CHAIN_THREADS)
+zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
+               const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
+               const uint32_t *__restrict__ hugelist, const uint32_t *__restrict__ nhuge, const zh_sbstate_t *__restrict__ states, uint32_t *best_all,
+               uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket) {
+   __shared__ zh_chain_ws_t ws;
+   __shared__ uint32_t s_item;
+   const uint32_t tid = threadIdx.x, wave = tid >> 6;
+   const uint32_t count = *nhuge;
+   for (;;) {
+      __syncthreads();   // the previous task's histogram has left LDS, s_item has been read
+      if (tid == 0) s_item = atomicAdd(ticket, 1u);
+      __syncthreads();
+      const uint32_t item = s_item;
+      if (item >= count) return;
+      const uint32_t gt = hugelist[item];
+      const uint2 tm = taskmap[gt];
+      const zh_work_t wk = work[tm.x];
+      const zh_sbstate_t *st = states + tm.x;
+      if (st->failed) continue;
+      if (!st->is_dynamic && pass > 0) continue;   // static sub-blocks are parsed once (blockdeflate.c:836-858)
+      const zh_block_t blk = blocks[wk.block];
+      const uint8_t *win = data + blk.win_off;
+      const uint32_t prev = blk.prev;
+      const uint4 *rows = (const uint4 *)(match + (uint64_t)wk.block * match_stride);
+      const uint64_t *bar = bars + (uint64_t)wk.block * bar_stride;
+      uint32_t *best = best_all + (uint64_t)wk.block * best_stride;
+      const uint32_t sb_end = wk.start + wk.size;
+
+      // ---- prices of the codes in force; unused symbols price at 9 / 6 bits (blockdeflate.c:873-881) ---------------
+      for (uint32_t k = tid; k < ZH_NLIT; k += ZH_CHAIN_THREADS) {
+         const uint32_t l = st->lit_len[k];
+         ws.litprice[k] = (uint8_t)(l ? l : 9u);
+      }
+      if (tid < ZH_NDIST) {
+         const uint32_t l = st->dist_len[tid];
+         ws.distcost[tid] = (uint8_t)((l ? l : 6u) + (uint32_t)zh_dist_xbits((int)tid));
+      }
+      __syncthreads();
+      for (uint32_t e = tid; e < 256; e += ZH_CHAIN_THREADS) {
+         const int idx = zh_len_idx(e + 3);
+         ws.lencost[e] = (uint8_t)(ws.litprice[257 + idx] + zh_lenidx_xbits(idx));
+      }
+      const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y, wk.ntasks);
+      const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
+      __syncthreads();
+      zh_chain_parse(ws, rows, win, prev, t0, t1, sb_end, best);
+
+      // ---- histogram of the task's parse; the per-sub-block sum is taken by zh_sb_build -------------------------------
+      if (st->is_dynamic) {
+         __threadfence_block();
+         __syncthreads();
+         for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) ws.hist[k] = 0;
+         __syncthreads();
+         zh_walk_histogram_wave(ws.hist, win, prev, wave == 0 ? t0 : t1, t1, best);   // the other waves walk nothing (they join the barrier)
+         uint32_t *hp = hist_part + (uint64_t)gt * ZH_NSYM;
+         for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) hp[k] = ws.hist[k];
+      }
+   }
+}

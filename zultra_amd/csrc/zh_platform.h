@@ -85,6 +85,14 @@ __device__ __forceinline__ uint32_t zh_wave_min(uint32_t v) {
    uint32_t a = zh_readlane(v, 0), b = zh_readlane(v, 16), c = zh_readlane(v, 32), d = zh_readlane(v, 48);
    return min(min(a, b), min(c, d));
 }
+// whole-wave minimum by DPP alone: the four row minima are combined with row_bcast:15 / row_bcast:31 and arrive in lane 63
+// (one readlane instead of four and no scalar mins: the shortest instruction sequence for a wave that runs alone)
+__device__ __forceinline__ uint32_t zh_wave_min_bcast(uint32_t v) {
+   v = zh_row_min(v);
+   v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x142, 0xA, 0xF, false));   // rows 1, 3 <- lane 15 of rows 0, 2
+   v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x143, 0xC, 0xF, false));   // rows 2, 3 <- lane 31
+   return zh_readlane(v, 63);
+}
 __device__ __forceinline__ uint32_t zh_wave_sum(uint32_t v) {
    v = zh_row_sum(v);
    return zh_readlane(v, 0) + zh_readlane(v, 16) + zh_readlane(v, 32) + zh_readlane(v, 48);

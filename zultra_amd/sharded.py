@@ -1,7 +1,7 @@
 """Multi-GPU assembly: max-blocks shard across ranks with no exchange during compute. What crosses
 ranks after the compute:
 
-  (1) one all-gather of a 160-byte *phase table* per rank. The stored-vs-compressed decision of libzultra.c:345-347
+  (1) one all-gather of a 128-byte *phase table* per rank. The stored-vs-compressed decision of libzultra.c:345-347
       compares whole flushed bytes, so the bit length of a shard depends on the bit phase (0..7) it starts at. Every rank
       dry-runs the stitch planner over its own sub-block descriptors for the eight possible start phases and publishes
       (bits written, touched) per phase; chaining the tables of the ranks before it gives a rank its true start phase and
@@ -81,23 +81,28 @@ def _to_host(torch, t):
     return buf[:n].numpy()
 
 
-def assemble(lib, ctx, max_block, dist, torch, device, final_block_local):
+def assemble(lib, ctx, max_block, dist, torch, device, final_block_local, extra=None):
     """Stitch this rank's last batch on its GPU at its true bit offset and gather the stream on rank 0.
     ctx = None for a rank whose shard is empty (it still takes part in the collectives).
     final_block_local = index (in this rank's batch) of the last max-block of the whole stream, or -1.
+    extra = a small int64 vector per rank (same length everywhere) that rides along with the phase tables, e.g. the shard's
+    checksum contribution; info["extras"] holds every rank's, in rank order.
     Returns (stream bytes as a uint8 numpy array on rank 0 / None elsewhere, info dict)."""
     rank, world = dist.get_rank(), dist.get_world_size()
+    extra = np.zeros(0, dtype=np.int64) if extra is None else np.ascontiguousarray(extra, dtype=np.int64)
 
     if world == 1:
         end_bit, _ = ctx.stitch_device(final_block_local, phase=0)
         nbytes = (end_bit + 7) // 8
-        return _to_host(torch, _stream_tensor(ctx, torch, device, nbytes)), {"shard_bytes": nbytes, "start_phase": 0, "sent_bytes": 0}
+        return _to_host(torch, _stream_tensor(ctx, torch, device, nbytes)), {"shard_bytes": nbytes, "start_phase": 0, "sent_bytes": 0, "extras": [extra]}
 
     # (1) phase tables of every rank -> start phase and byte offset of every shard
-    mine = torch.from_numpy(phase_table(lib, ctx, max_block)).to(device)
+    mine = torch.from_numpy(np.concatenate([phase_table(lib, ctx, max_block).reshape(-1), extra])).to(device)
     tabs = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(tabs, mine)
     tabs = [t.cpu().numpy() for t in tabs]
+    extras = [t[16:] for t in tabs]
+    tabs = [t[:16].reshape(8, 2) for t in tabs]
     phase, off = 0, 0            # off = index of the byte that holds the pending bits (or the next free byte at phase 0)
     starts = []
     for r in range(world):
@@ -132,7 +137,7 @@ def assemble(lib, ctx, max_block, dist, torch, device, final_block_local):
         skip = 1 if (n and ph) else 0
         return o, n, skip
 
-    info = {"shard_bytes": nbytes, "start_phase": my_phase, "sent_bytes": 0}
+    info = {"shard_bytes": nbytes, "start_phase": my_phase, "sent_bytes": 0, "extras": extras}
     if rank != 0:
         o, n, skip = touched(rank)
         if n - skip > 0:
