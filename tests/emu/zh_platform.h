@@ -221,6 +221,11 @@ inline uint32_t zh_wave_min(uint32_t v) {
    });
 }
 inline uint32_t zh_wave_min_bcast(uint32_t v) { return zh_wave_min(v); }
+inline void zh_wave_min3_lane63(uint32_t &a, uint32_t &b, uint32_t &c) {   // results in every lane here: a superset of "in lane 63"
+   a = zh_wave_min(a);
+   b = zh_wave_min(b);
+   c = zh_wave_min(c);
+}
 inline uint32_t zh_wave_sum(uint32_t v) {
    using namespace zh_emu;
    return (uint32_t)collect(v, [] {

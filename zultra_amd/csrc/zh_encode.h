@@ -267,10 +267,7 @@ zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint
    if ((int)lane < ndist) ws.lens[nlit + (int)lane] = ws.dist_len[lane];
    zh_sync();
 
-   if (lane == 0) ws.tmp = zh_cl_make_runs(ws.lens, nlit + ndist, ws.runs);
-   zh_sync();
-   const int nruns = ws.tmp;
-   zh_sync();
+   const int nruns = zh_cl_make_runs_wave(ws.lens, nlit + ndist, ws.runs, ws.sc.keys);
    uint32_t mkey = 0xFFFFFFFFu;
    if (lane < 20) {
       // 20 lanes, one mask each, all walking the same run list: the loop trip counts agree, only the token choice differs

@@ -59,7 +59,95 @@ struct zh_huff_scratch_t {
    uint32_t sorted[ZH_NLIT];
    int32_t A[ZH_NLIT];
    uint32_t count;
+   uint32_t small[36];   // per code length: symbols / first index / first code (canonical code assignment)
 };
+
+// The same result as zh_mk_depths, by all 64 lanes of a wave on A[0..n) in LDS (n >= 2; `tmp` = n words of LDS scratch).
+// Phase 1 (the two-queue merge, huffencoder.c:198-223) is serial and stays on lane 0; what follows it in the reference
+// are two more serial walks over the array, each step a dependent LDS access (~75 cycles on gfx950) — they go wide:
+//   phase 2 (:227-231)  depth of every internal node = depth of its parent + 1: pointer jumping, ceil(log2(depth)) rounds;
+//   phase 3 (:235-254)  leaves per depth from the number of internal nodes per depth (a histogram), then every depth's
+//                       leaves are written by the lanes at once.
+__device__ inline void zh_mk_depths_wave(int32_t *A, int n, uint32_t *tmp) {
+   const int lane = (int)zh_lane();
+   if (lane == 0) {
+      int leaf = 0, node = 0, t;
+      for (t = 0; t < n - 1; t++) {
+         int w = 0;
+         for (int pick = 0; pick < 2; pick++) {
+            if (leaf >= n || (node < t && A[node] < A[leaf])) {
+               w += A[node];
+               A[node] = t;
+               node++;
+            }
+            else {
+               w += A[leaf];
+               leaf++;
+            }
+         }
+         A[t] = w;
+      }
+   }
+   zh_wave_sync();
+   // ---- phase 2: A[t] = parent of internal node t (t <= n-3), node n-2 is the root -> A[t] = depth of t ------------
+   const int ni = n - 1;   // internal nodes
+   const int root = n - 2;
+   int par[5], dep[5];     // ZH_NLIT <= 5 * 64
+#pragma unroll
+   for (int q = 0; q < 5; q++) {
+      const int t = lane + 64 * q;
+      par[q] = (t < root) ? A[t] : root;
+      dep[q] = (t < root) ? 1 : 0;
+   }
+   for (;;) {
+      bool moving = false;
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+         const int t = lane + 64 * q;
+         if (t < ni) {
+            A[t] = par[q];
+            tmp[t] = (uint32_t)dep[q];
+            moving = moving || par[q] != root;
+         }
+      }
+      if (!zh_ballot(moving)) break;   // (also orders the stores before the gathers below)
+      zh_wave_sync();
+      int pp[5], dd[5];
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+         const int t = lane + 64 * q;
+         pp[q] = root;
+         dd[q] = 0;
+         if (t < ni) {
+            pp[q] = A[par[q]];
+            dd[q] = (int)tmp[par[q]];
+         }
+      }
+      zh_wave_sync();
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+         dep[q] += dd[q];
+         par[q] = pp[q];
+      }
+   }
+   zh_wave_sync();
+   // ---- phase 3: internal nodes per depth -> leaves per depth; the heaviest leaves (highest indices) are the shallowest ----
+   for (int k = lane; k < n; k += 64) tmp[k] = 0;
+   zh_wave_sync();
+#pragma unroll
+   for (int q = 0; q < 5; q++)
+      if (lane + 64 * q < ni) atomicAdd(&tmp[dep[q]], 1u);
+   zh_wave_sync();
+   int avail = 1, next = n - 1;
+   for (int depth = 0; avail > 0; depth++) {
+      const int used = depth < n ? (int)tmp[depth] : 0;
+      const int nleaf = avail - used;
+      for (int k = lane; k < nleaf; k += 64) A[next - k] = depth;
+      next -= nleaf;
+      avail = used << 1;
+   }
+   zh_wave_sync();
+}
 
 // Lane-parallel rank sort of unique 32-bit keys: sorted[rank(k)] = k. All lanes call.
 __device__ inline void zh_rank_sort_wave(const uint32_t *keys, uint32_t *sorted, int n) {
@@ -106,8 +194,7 @@ __device__ inline void zh_huff_lengths_wave(const int32_t *freq, uint8_t *len, i
    zh_rank_sort_wave(sc->keys, sc->sorted, n);
    for (int e = lane; e < n; e += 64) sc->A[e] = (int32_t)(sc->sorted[e] >> 9);
    zh_wave_sync();
-   if (lane == 0) zh_mk_depths(sc->A, n);
-   zh_wave_sync();
+   zh_mk_depths_wave(sc->A, n, sc->keys);   // the keys have been sorted into sc->sorted: their array is free
    for (int e = lane; e < n; e += 64) len[sc->sorted[e] & 511u] = (uint8_t)sc->A[e];
    zh_wave_sync();
 }
@@ -158,6 +245,38 @@ __device__ inline void zh_assign_codes(const uint8_t *len, uint16_t *code, const
    }
 }
 
+// The same codes as zh_assign_codes by all lanes of a wave: along a (length, symbol)-ordered list the reference's recurrence
+// c' = (c + 1) << (next length - length) is the canonical code — first code of a length = (first code + count of the previous
+// length) << 1 — so a symbol's code is its length's first code plus its rank inside the length. Lengths <= 15.
+__device__ inline void zh_assign_codes_wave(const uint8_t *len, uint16_t *code, const uint32_t *order, int n, uint32_t *small /* 36 words */) {
+   const int lane = (int)zh_lane();
+   if (lane < 36) small[lane] = 0;
+   zh_wave_sync();
+   for (int i = lane; i < n; i += 64) atomicAdd(&small[len[order[i] & 511u]], 1u);   // [1..15]: symbols per length
+   zh_wave_sync();
+   if (lane == 0) {
+      uint32_t first_index = 0, first_code = 0, prev_count = 0;
+      bool started = false;
+      for (int l = 1; l <= 15; l++) {
+         const uint32_t cnt = small[l];
+         // lengths before the shortest one in use start the code at 0 (zh_assign_codes: c = 0 at the first symbol)
+         first_code = started ? (first_code + prev_count) << 1 : 0u;
+         started = started || cnt != 0;
+         small[16 + l] = first_index;
+         prev_count = cnt;
+         first_index += cnt;
+         small[l] = first_code;   // the count has been consumed: its slot takes the first code
+      }
+   }
+   zh_wave_sync();
+   for (int i = lane; i < n; i += 64) {
+      const int sym = (int)(order[i] & 511u);
+      const int l = len[sym];
+      code[sym] = (uint16_t)zh_bitrev16(small[l] + ((uint32_t)i - small[16 + l]), l);
+   }
+   zh_wave_sync();
+}
+
 // huffencoder.c:279-375: lengths, limit to maxbits, canonical codes. All lanes call. Returns 0 / -1 (uniform).
 __device__ inline int zh_huff_build_wave(const int32_t *freq, uint8_t *len, uint16_t *code, int nsym, int maxbits,
                                          zh_huff_scratch_t *sc) {
@@ -175,8 +294,7 @@ __device__ inline int zh_huff_build_wave(const int32_t *freq, uint8_t *len, uint
       n = zh_collect_keys_wave(len, nsym, sc);   // huffencoder.c:344: order again after the repair
       zh_rank_sort_wave(sc->keys, sc->sorted, n);
    }
-   if (lane == 0 && n > 0) zh_assign_codes(len, code, sc->sorted, n);
-   zh_wave_sync();
+   if (n > 0) zh_assign_codes_wave(len, code, sc->sorted, n, sc->small);
    return rc;
 }
 
@@ -186,8 +304,7 @@ __device__ inline void zh_huff_static_codes_wave(const uint8_t *len, uint16_t *c
    for (int s = lane; s < nsym; s += 64) sc->keys[s] = ((uint32_t)len[s] << 9) | (uint32_t)s;
    zh_wave_sync();
    zh_rank_sort_wave(sc->keys, sc->sorted, nsym);
-   if (lane == 0) zh_assign_codes(len, code, sc->sorted, nsym);
-   zh_wave_sync();
+   zh_assign_codes_wave(len, code, sc->sorted, nsym, sc->small);
 }
 
 // huffencoder.c:532-538
@@ -396,6 +513,27 @@ __device__ inline int zh_cl_make_runs(const uint8_t *lens, int n, uint16_t *runs
    return nruns;
 }
 
+// The run list by all lanes of a wave (same entries as zh_cl_make_runs); returns the number of runs (uniform).
+// `starts` = n words of LDS scratch.
+__device__ inline int zh_cl_make_runs_wave(const uint8_t *lens, int n, uint16_t *runs, uint32_t *starts) {
+   const int lane = (int)zh_lane();
+   int nruns = 0;
+   for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const bool head = i < n && (i == 0 || lens[i] != lens[i - 1]);
+      const uint64_t m = zh_ballot(head);
+      if (head) starts[nruns + zh_popc64(m & ((1ull << lane) - 1))] = (uint32_t)i;
+      nruns += zh_popc64(m);
+   }
+   zh_wave_sync();
+   for (int q = lane; q < nruns; q += 64) {
+      const int i0 = (int)starts[q], i1 = q + 1 < nruns ? (int)starts[q + 1] : n;
+      runs[q] = (uint16_t)(lens[i0] | ((i1 - i0) << 6));
+   }
+   zh_wave_sync();
+   return nruns;
+}
+
 struct zh_cl_count_sink {
    zh_cl_t *h;
    __device__ __forceinline__ void put(int sym, int, int) { h->freq[sym]++; }
@@ -425,6 +563,34 @@ __device__ inline int zh_table_cost_lane(const uint8_t *lens, int n, zh_cl_t *h,
    zh_cl_size_sink ss{h, 0};
    zh_cl_tokenize_runs(runs, nruns, 31, ss);
    return 5 + 5 + 4 + 3 * zh_cl_raw_table_size(h) + ss.bits;
+}
+
+// The same value by all lanes of a wave: the tokens of a run depend on nothing but the run, so the two tokenizer passes go
+// one run per lane — symbol counts through LDS atomics, bits through a wave sum; only the 19-symbol length build between
+// them stays on one lane. `scratch` = n words of LDS. Returns the same value in every lane.
+struct zh_cl_atomic_count_sink {
+   zh_cl_t *h;
+   __device__ __forceinline__ void put(int sym, int, int) { atomicAdd(&h->freq[sym], 1); }
+};
+__device__ inline int zh_table_cost_wave(const uint8_t *lens, int n, zh_cl_t *h, uint32_t *scratch) {
+   const int lane = (int)zh_lane();
+   uint16_t *runs = (uint16_t *)scratch;                 // n entries of 2 bytes in the first half
+   const int nruns = zh_cl_make_runs_wave(lens, n, runs, scratch + (n + 1) / 2);
+   if (lane == 0) zh_cl_reset(h);
+   zh_wave_sync();
+   {
+      zh_cl_atomic_count_sink cs{h};
+      for (int q = lane; q < nruns; q += 64) zh_cl_tokenize_runs(runs + q, 1, 7, cs);
+   }
+   zh_wave_sync();
+   if (lane == 0) zh_cl_lengths_lane(h);
+   zh_wave_sync();
+   zh_cl_size_sink ss{h, 0};
+   for (int q = lane; q < nruns; q += 64) zh_cl_tokenize_runs(runs + q, 1, 31, ss);
+   const int bits = (int)zh_wave_sum((uint32_t)ss.bits);
+   const int r = 5 + 5 + 4 + 3 * zh_cl_raw_table_size(h) + bits;
+   zh_wave_sync();
+   return r;
 }
 
 // ---------------------------------------------------------------------------------------------------------

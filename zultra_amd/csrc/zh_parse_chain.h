@@ -42,6 +42,7 @@ struct zh_chain_ws_t {
          uint32_t ring[ZH_CHAIN_RING];                    // entry i: (cost << 9) - (i << 23) of the position p with p % 512 == i
          uint32_t desc[2][ZH_CHAIN_TILE][65];             // [tile parity][position, top first][consumer lane]; the odd row stride spreads
                                                           // the producers' stores (16 positions per store instruction) over the LDS banks
+         uint32_t lit[2][ZH_CHAIN_TILE];                  // literal price << 9 (0 for positions below the range)
          uint32_t bt[2][ZH_CHAIN_TILE];                   // winning key per position; low 9 bits zero = literal
       } p;
       uint32_t hist[ZH_NSYM];                             // after the parse: histogram of the range
@@ -130,7 +131,7 @@ __device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, 
          // a slot that does not exist gathers the cost of the tile's top (dumped a tile ago, within 32 positions of p+1): harmless
          dl[s] = s < nlong ? v : (((thi & (ZH_CHAIN_RING - 1u)) << 23) | ZH_CHAIN_NOPRICE);
       }
-      ws.p.desc[buf][j][63] = ok ? (uint32_t)ws.litprice[f.byte & 0xffu] << 9 : 0u;   // lane 63: the literal
+      ws.p.lit[buf][j] = ok ? (uint32_t)ws.litprice[f.byte & 0xffu] << 9 : 0u;
    }
 }
 
@@ -161,9 +162,11 @@ __device__ __forceinline__ void zh_chain_flush(zh_chain_ws_t &ws, uint32_t buf, 
 
 // consumer: the recurrence over one tile, one position per step, always ZH_CHAIN_TILE steps (positions below the range's start
 // are staged as "literal of price 0, no candidates": their costs are computed and never looked at). State:
-//   cv  lane j: cost9[p + 3 + j] for the position p priced next        c1, c2 (every lane): cost9[p + 1], cost9[p + 2]
-// Lane 63 prices the literal: its descriptor is the literal's price, its cost operand c1, its tie bits zero — below every
-// match's, so "literal first; a match must be strictly cheaper" (:292,:307) is the same minimum, and the step needs no compare.
+//   cv  lane j: cost9[p + 3 + j] for the position p priced next        c1, c2 (wave-uniform): cost9[p + 1], cost9[p + 2]
+// The best match of a position depends on costs from cost[p+3] on, i.e. on what was known three steps earlier: its wave-wide
+// minimum (six dependent DPP steps) runs in the shadow of the two steps before it. What carries from one step to the next is
+// the literal alone: cost[p] = min(cost[p+1] + literal, best match) — an add, a min, a mask. A match's key has tie bits >= 1 in
+// its low 9 bits, the literal's are 0: "literal first; a match must be strictly cheaper" (:292,:307) is that same minimum.
 struct zh_chain_state_t {
    uint32_t cv, c1, c2;
 };
@@ -171,28 +174,54 @@ struct zh_chain_state_t {
 __device__ __forceinline__ void zh_chain_consume(zh_chain_ws_t &ws, uint32_t buf, uint32_t thi, zh_chain_state_t &st) {
    const uint32_t lane = zh_lane();
    const bool is_long = lane >= ZH_CHAIN_LONG0 && lane < ZH_CHAIN_LONG0 + ZH_NMATCH;
-   const bool is_lit = lane == 63;
    const uint32_t *dp = &ws.p.desc[buf][0][lane];
    const uint8_t *ring8 = (const uint8_t *)ws.p.ring;
+   const uint32_t litv = ws.p.lit[buf][lane & (ZH_CHAIN_TILE - 1u)];
    uint32_t wv = 0;
    uint32_t cv = st.cv, c1 = st.c1, c2 = st.c2;
-   // two-stage read-ahead: the descriptor of step t+2 and the gather of step t+1 are issued in step t
-   uint32_t d = dp[0], dn = dp[65];
-   uint32_t g = *(const uint32_t *)(ring8 + (d >> 21));
+   // Positions go in groups of three: the three wave-wide minima of a group only need costs from before the group (position
+   // p-2 looks no nearer than cost[p+1]), so their DPP steps are interleaved; then the three literal decisions chain.
+   uint32_t d[3], g[3];
 #pragma unroll
-   for (uint32_t t = 0; t < ZH_CHAIN_TILE; t++) {
-      const uint32_t dnn = dp[65u * min(t + 2u, ZH_CHAIN_TILE - 1u)];
-      const uint32_t gn = *(const uint32_t *)(ring8 + (dn >> 21));
-      const uint32_t x = is_lit ? c1 : (is_long ? g : cv);
-      const uint32_t M = zh_wave_min_bcast(x + d);
-      const uint32_t c0 = M & ~511u;
-      wv = zh_wave_shr1(wv, M);   // the winning keys travel up the lanes like the costs: lane i = step 31 - i
-      cv = zh_wave_shr1(cv, c2);
-      c2 = c1;
-      c1 = c0;
-      d = dn;
-      dn = dnn;
-      g = gn;
+   for (uint32_t q = 0; q < 3; q++) {
+      d[q] = dp[65u * q];
+      g[q] = *(const uint32_t *)(ring8 + (d[q] >> 21));
+   }
+#pragma unroll
+   for (uint32_t t = 0; t < ZH_CHAIN_TILE; t += 3) {
+      // (the tile has 32 positions: the last group is a pair; its third member prices a copy of the tile's last row and is dropped)
+      uint32_t dn[3], gn[3];
+#pragma unroll
+      for (uint32_t q = 0; q < 3; q++) {
+         dn[q] = dp[65u * min(t + 3u + q, ZH_CHAIN_TILE - 1u)];
+         gn[q] = *(const uint32_t *)(ring8 + (dn[q] >> 21));
+      }
+      const uint32_t cva = cv, cvb = zh_wave_shr1(cva, c2), cvc = zh_wave_shr1(cvb, c1);
+      uint32_t ka = (is_long ? g[0] : cva) + d[0], kb = (is_long ? g[1] : cvb) + d[1], kc = (is_long ? g[2] : cvc) + d[2];
+      zh_wave_min3_lane63(ka, kb, kc);
+      const uint32_t ma = min(c1 + zh_readlane(litv, (int)t), zh_readlane(ka, 63));
+      const uint32_t ca = ma & ~511u;
+      const uint32_t mb = min(ca + zh_readlane(litv, (int)min(t + 1u, ZH_CHAIN_TILE - 1u)), zh_readlane(kb, 63));
+      const uint32_t cb = mb & ~511u;
+      wv = zh_wave_shr1(zh_wave_shr1(wv, ma), mb);   // the winning keys travel up the lanes like the costs: lane i = step 31 - i
+      if (t + 2 < ZH_CHAIN_TILE) {
+         const uint32_t mc = min(cb + zh_readlane(litv, (int)min(t + 2u, ZH_CHAIN_TILE - 1u)), zh_readlane(kc, 63));
+         const uint32_t cc = mc & ~511u;
+         wv = zh_wave_shr1(wv, mc);
+         cv = zh_wave_shr1(cvc, ca);
+         c2 = cb;
+         c1 = cc;
+      }
+      else {
+         cv = cvc;
+         c2 = ca;
+         c1 = cb;
+      }
+#pragma unroll
+      for (uint32_t q = 0; q < 3; q++) {
+         d[q] = dn[q];
+         g[q] = gn[q];
+      }
    }
    // the tile's winners for the flusher, its costs for the long slots of later tiles: cost9[thi - 32 + i] is c1, c2, then cv from lane 0 on
    if (lane < ZH_CHAIN_TILE) ws.p.bt[buf][ZH_CHAIN_TILE - 1u - lane] = wv;
@@ -238,9 +267,8 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
       for (uint32_t k = lane; k < ZH_CHAIN_RING; k += 64) ws.p.ring[k] = 0u - (k << 23);
    }
    else {
-      // consumer lanes 48..62 price nothing (lane 63 is the literal)
-      for (uint32_t k = lane; k < 2u * ZH_CHAIN_TILE * 16u; k += 64)
-         if ((k & 15u) != 15u) ws.p.desc[k / (ZH_CHAIN_TILE * 16u)][(k / 16u) % ZH_CHAIN_TILE][48u + (k & 15u)] = ZH_CHAIN_NOPRICE;
+      // consumer lanes 48..63 price nothing
+      for (uint32_t k = lane; k < 2u * ZH_CHAIN_TILE * 16u; k += 64) ws.p.desc[k / (ZH_CHAIN_TILE * 16u)][(k / 16u) % ZH_CHAIN_TILE][48u + (k & 15u)] = ZH_CHAIN_NOPRICE;
    }
    __syncthreads();
 

@@ -93,6 +93,20 @@ __device__ __forceinline__ uint32_t zh_wave_min_bcast(uint32_t v) {
    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, 0x143, 0xC, 0xF, false));   // rows 2, 3 <- lane 31
    return zh_readlane(v, 63);
 }
+// the same for three values at once, the steps interleaved: a DPP instruction needs its source two cycles old, and three
+// independent chains fill each other's gaps. The minima arrive in lane 63 of a, b, c.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t zh_dpp_min_rows(uint32_t v) {
+   return min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, CTRL, ROWS, 0xF, false));
+}
+__device__ __forceinline__ void zh_wave_min3_lane63(uint32_t &a, uint32_t &b, uint32_t &c) {
+   a = zh_dpp_min<ZH_DPP_QUAD_XOR1>(a); b = zh_dpp_min<ZH_DPP_QUAD_XOR1>(b); c = zh_dpp_min<ZH_DPP_QUAD_XOR1>(c);
+   a = zh_dpp_min<ZH_DPP_QUAD_XOR2>(a); b = zh_dpp_min<ZH_DPP_QUAD_XOR2>(b); c = zh_dpp_min<ZH_DPP_QUAD_XOR2>(c);
+   a = zh_dpp_min<ZH_DPP_ROW_HALF_MIRROR>(a); b = zh_dpp_min<ZH_DPP_ROW_HALF_MIRROR>(b); c = zh_dpp_min<ZH_DPP_ROW_HALF_MIRROR>(c);
+   a = zh_dpp_min<ZH_DPP_ROW_MIRROR>(a); b = zh_dpp_min<ZH_DPP_ROW_MIRROR>(b); c = zh_dpp_min<ZH_DPP_ROW_MIRROR>(c);
+   a = zh_dpp_min_rows<0x142, 0xA>(a); b = zh_dpp_min_rows<0x142, 0xA>(b); c = zh_dpp_min_rows<0x142, 0xA>(c);
+   a = zh_dpp_min_rows<0x143, 0xC>(a); b = zh_dpp_min_rows<0x143, 0xC>(b); c = zh_dpp_min_rows<0x143, 0xC>(c);
+}
 __device__ __forceinline__ uint32_t zh_wave_sum(uint32_t v) {
    v = zh_row_sum(v);
    return zh_readlane(v, 0) + zh_readlane(v, 16) + zh_readlane(v, 32) + zh_readlane(v, 48);

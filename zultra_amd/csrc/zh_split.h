@@ -295,10 +295,7 @@ __device__ inline int zh_dynamic_cost_wave(const int32_t *lit, const int32_t *di
    for (int s = lane; s < nlit; s += 64) lens[s] = lit_len[s];
    if (lane < ndist) lens[nlit + lane] = dist_len[lane];
    zh_wave_sync();
-   if (lane == 0) *tmp = zh_table_cost_lane(lens, nlit + ndist, cl, (uint16_t *)sc->keys);   // the sort scratch is free here
-   zh_wave_sync();
-   int r = (int)body + *tmp + 3;
-   zh_wave_sync();
+   const int r = (int)body + zh_table_cost_wave(lens, nlit + ndist, cl, sc->keys) + 3;   // the sort scratch (keys, sorted: 576 words) is free here
    return r;
 }
 
