@@ -64,6 +64,13 @@ typedef struct zh_match_s {
    uint16_t offset;
 } zh_match_t;
 
+// Match rows in HBM (per max-block, match_stride = 8 x max-block size entries): two planes of 16 bytes per position —
+// slots 0..3 at [position], slots 4..7 at [max-block size + position]. Rows are longest first and zero padded, and only about
+// one position in twenty has four or more matches: the matchfinder writes the second plane only then, and every reader
+// fetches it only when slot 3 holds a match. (One 32-byte row per position cost every reader a second 16-byte fetch of
+// zeros per position and pass.)
+#define ZH_ROW_HI_OFF(match_stride) ((match_stride) / ZH_NMATCH)   /* second plane, in 16-byte units from the block's first row */
+
 #if defined(__HIPCC__) || defined(ZH_EMU)
 #define ZH_HD __host__ __device__ __forceinline__
 #else

@@ -59,6 +59,7 @@ struct zultra_hip_ctx_s {
    std::vector<zh_seg_t> segs;
    std::vector<uint32_t> seg_base;
    zh_match_t *d_match;
+   uint32_t *d_longest;         // per block position: slot 0 of its match row (tok_stride per max-block)
    uint32_t *d_tok_pos;
    uint16_t *d_tok_info;
    uint32_t *d_ntok, *d_split_tok, *d_split_cnt, *d_sub_base;
@@ -299,6 +300,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_segs);
    (void)hipFree(c->d_chunk_ctr);
    (void)hipFree(c->d_match);
+   (void)hipFree(c->d_longest);
    (void)hipFree(c->d_tok_pos);
    (void)hipFree(c->d_tok_info);
    (void)hipFree(c->d_ntok);
@@ -400,7 +402,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
        zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, 32) || zh_alloc(c, &c->d_hugelist, c->max_tasks) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
-       zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) ||
+       zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) || zh_alloc(c, &c->d_longest, B * c->tok_stride) ||
        zh_alloc(c, &c->d_tok_pos, B * c->tok_stride) || zh_alloc(c, &c->d_tok_info, B * c->tok_stride) ||
        zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_chunkmax, B * c->chunks_per_block) || zh_alloc(c, &c->d_spanstart, B * c->chunks_per_block) ||
        zh_alloc(c, &c->d_spancnt, B * c->chunks_per_block) || zh_alloc(c, &c->d_split_tok, B * (ZH_MAX_SPLITS + 1)) || zh_alloc(c, &c->d_split_cnt, B) ||
@@ -536,14 +538,14 @@ static int zh_build_segments(zultra_hip_ctx_t *c, const zultra_hip_block_t *bloc
 // barrier bitmap and greedy token chain of `nb` max-blocks starting at batch block b0, in chunks (zh_split.h)
 static int zh_enqueue_tokenize(zultra_hip_ctx_t *c, hipStream_t st, const zh_block_t *blk, uint32_t b0, uint32_t nb) {
    const uint32_t cpb = c->chunks_per_block;
-   const zh_match_t *match = c->d_match + (uint64_t)b0 * c->match_stride;
+   const uint32_t *match = c->d_longest + (uint64_t)b0 * c->tok_stride;
    uint64_t *bars = c->d_bars + (uint64_t)b0 * c->bar_stride;
    uint32_t *tp = c->d_tok_pos + (uint64_t)b0 * c->tok_stride;
    uint16_t *ti = c->d_tok_info + (uint64_t)b0 * c->tok_stride;
    uint32_t *cmax = c->d_chunkmax + (uint64_t)b0 * cpb, *sstart = c->d_spanstart + (uint64_t)b0 * cpb, *scnt = c->d_spancnt + (uint64_t)b0 * cpb;
-   ZH_LAUNCH(zh_barriers, nb * cpb, 64, st, blk, match, c->match_stride, bars, c->bar_stride, cmax, cpb);
+   ZH_LAUNCH(zh_barriers, nb * cpb, 64, st, blk, match, c->tok_stride, bars, c->bar_stride, cmax, cpb);
    if (cpb > 1) ZH_LAUNCH(zh_barriers_fix, (nb + 63) / 64, 64, st, blk, nb, bars, c->bar_stride, (const uint32_t *)cmax, cpb);
-   ZH_LAUNCH(zh_tokenize_spans, nb * cpb, 64, st, c->cur_data, blk, match, c->match_stride, tp, ti, c->tok_stride, (const uint64_t *)bars, c->bar_stride, sstart, scnt,
+   ZH_LAUNCH(zh_tokenize_spans, nb * cpb, 64, st, c->cur_data, blk, match, c->tok_stride, tp, ti, c->tok_stride, (const uint64_t *)bars, c->bar_stride, sstart, scnt,
              cpb);
    ZH_LAUNCH(zh_tokens_compact, nb, ZH_COMPACT_THREADS, st, blk, tp, ti, c->tok_stride, (const uint32_t *)sstart, (const uint32_t *)scnt, cpb, c->d_ntok + b0);
    return 0;
@@ -568,7 +570,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)c->d_segs, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride,
              c->run_stride, 0, nb, c->d_chunk_ctr + (size_t)nb * 2 + 1);
    ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, (const zh_seg_t *)c->d_segs, (const uint32_t *)c->d_sort_a,
-             (const uint2 *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
+             (const uint2 *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
    if (zh_enqueue_tokenize(c, st, blk, 0, nb) != 0) return -1;
    ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
    ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 32 * sizeof(uint32_t), st));
@@ -729,7 +731,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
       // (segment descriptors carry batch-wide block indices: the rows go to d_match + block * match_stride)
       ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint2 *)p3, (const uint32_t *)rn,
-                c->sort_stride, c->run_stride, c->d_match, c->match_stride, ctr, nsg, 1u);
+                c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, ctr, nsg, 1u);
       ZH_CHECK(c, hipEventRecord(ev[3], st));
       if (zh_enqueue_tokenize(c, st, blk, b0, nb) != 0) return -1;
       if (c->max_block > 131072) {
@@ -1018,8 +1020,20 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
 extern "C" int zultra_hip_get_matches(zultra_hip_ctx_t *c, uint32_t block, uint16_t *out) {
    if (!c || block >= c->nblocks) return -1;
    ZH_CHECK(c, hipSetDevice(c->device));
-   ZH_CHECK(c, hipMemcpy(out, c->d_match + (uint64_t)block * c->match_stride, (size_t)c->blocks[block].n * ZH_NMATCH * sizeof(zh_match_t),
-                         hipMemcpyDeviceToHost));
+   // rows live in two planes of four slots (zh_common.h); the second one is only written behind a full first one
+   const size_t n = c->blocks[block].n;
+   std::vector<uint32_t> lo(n * 4), hi(n * 4);
+   const uint32_t *base = (const uint32_t *)(c->d_match + (uint64_t)block * c->match_stride);
+   ZH_CHECK(c, hipMemcpy(lo.data(), base, n * 16, hipMemcpyDeviceToHost));
+   ZH_CHECK(c, hipMemcpy(hi.data(), base + 4 * ZH_ROW_HI_OFF(c->match_stride), n * 16, hipMemcpyDeviceToHost));
+   uint32_t *o = (uint32_t *)out;
+   for (size_t i = 0; i < n; i++) {
+      const bool more = (lo[4 * i + 3] & 0xffffu) >= ZH_MIN_MATCH;
+      for (int k = 0; k < 4; k++) {
+         o[8 * i + k] = lo[4 * i + k];
+         o[8 * i + 4 + k] = more ? hi[4 * i + k] : 0u;
+      }
+   }
    return 0;
 }
 

@@ -439,8 +439,8 @@ template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
 zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs,
                const uint32_t *__restrict__ sorted, const uint2 *__restrict__ prev_all, const uint32_t *__restrict__ runs_all,
-               uint64_t sort_stride, uint64_t run_stride, zh_match_t *match, uint64_t match_stride, uint32_t *chunk_ctr,
-               uint32_t nsegs, uint32_t steal) {
+               uint64_t sort_stride, uint64_t run_stride, zh_match_t *match, uint64_t match_stride, uint32_t *longest_all, uint64_t longest_stride,
+               uint32_t *chunk_ctr, uint32_t nsegs, uint32_t steal) {
    // Persistent workgroups (one per CU, see zh_mf_group) take segments from a ticket counter, then help: on real data a
    // few segments carry several times the average scan work (measured: 7x on source code), and a workgroup that only did
    // its own would leave the chip waiting for them. Every segment hands out its 64-entry chunks from a counter in HBM, so
@@ -499,7 +499,11 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
    const uint32_t *S = sorted + (uint64_t)seg_id * sort_stride;
    const uint2 *prevs = prev_all + (uint64_t)seg_id * sort_stride;   // x: previous trigram occurrence, y: distances of prev4 | prev5
    const uint32_t *runs = runs_all + (uint64_t)seg_id * run_stride;
-   zh_match_t *rows = match + (uint64_t)blk.block * match_stride + blk.row_off * ZH_NMATCH;   // row r = segment position prev + r
+   // row r = segment position prev + r: slots 0..3 in rows_lo[r], slots 4..7 in rows_hi[r] (zh_common.h); its longest match again in
+   // longest[r], for the kernels that only follow the greedy chain (zh_split.h)
+   uint4 *rows_lo = (uint4 *)(match + (uint64_t)blk.block * match_stride) + blk.row_off;
+   uint4 *rows_hi = rows_lo + ZH_ROW_HI_OFF(match_stride);
+   uint32_t *longest = longest_all + (uint64_t)blk.block * longest_stride + blk.row_off;
    const uint8_t *win = gwin;
 
    if (LDS_WIN) {
@@ -530,15 +534,13 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
                }
             }
          }
-         uint4 *r = (uint4 *)(rows + (uint64_t)(i - prev) * ZH_NMATCH);
-         uint4 a, z;
+         uint4 a;
          a.x = n > 0 ? m[n - 1] : 0u;   // rows are longest first
          a.y = n > 1 ? m[n - 2] : 0u;
          a.z = n > 2 ? m[n - 3] : 0u;
          a.w = 0;
-         z.x = 0; z.y = 0; z.z = 0; z.w = 0;
-         r[0] = a;
-         r[1] = z;
+         rows_lo[i - prev] = a;
+         longest[i - prev] = a.x;
       }
    }
 
@@ -793,12 +795,12 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
          uint32_t m[8];
 #pragma unroll
          for (uint32_t k = 0; k < 8; k++) m[k] = (k < nm) ? myring[((nm - 1 - k) & 7u) * ZH_MF_THREADS] : 0u;
-         uint4 *r = (uint4 *)(rows + (uint64_t)(i - prev) * ZH_NMATCH);
          uint4 a, b2;
          a.x = m[0]; a.y = m[1]; a.z = m[2]; a.w = m[3];
          b2.x = m[4]; b2.y = m[5]; b2.z = m[6]; b2.w = m[7];
-         r[0] = a;
-         r[1] = b2;
+         rows_lo[i - prev] = a;
+         if (nm >= 4) rows_hi[i - prev] = b2;   // readers fetch it whenever slot 3 holds a match
+         longest[i - prev] = a.x;
       }
    }
 

@@ -231,10 +231,11 @@ __device__ __forceinline__ uint32_t zh_lane_key(zh_parse_ws_t &ws, const uint16_
 
 // decode the winning (slot, length) of a staged position into the parse entry; `row8` = the position's match row (8 x
 // len | offset << 16), which the same lane loaded one tile earlier (an L2 hit)
-__device__ __forceinline__ uint32_t zh_decode_pick(zh_parse_ws_t &ws, uint32_t trow, uint32_t tslot, uint32_t kk, uint32_t room, const uint32_t *row8) {
+__device__ __forceinline__ uint32_t zh_decode_pick(zh_parse_ws_t &ws, uint32_t trow, uint32_t tslot, uint32_t kk, uint32_t room, const uint32_t *row_lo,
+                                                   const uint32_t *row_hi) {
    if (kk == 0xFFFFFFFFu) return 0;
    const uint32_t m = (kk >> 6) & 7u;
-   const uint32_t e = row8[m];
+   const uint32_t e = m < 4 ? row_lo[m] : row_hi[m - 4];
    const uint32_t nlong = ZH_REC_NLONG(ws.rec[trow][tslot].w);
    const uint32_t len = (m < nlong) ? min(e & 0xffffu, room) : (39u - (kk & 63u));
    return len | (e & 0xffff0000u);
@@ -257,7 +258,8 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
    const zh_block_t blk = blocks[wk.block];
    const uint8_t *win = data + blk.win_off;
    const uint32_t prev = blk.prev;
-   const uint4 *rows = (const uint4 *)(match + (uint64_t)wk.block * match_stride);   // row r = pos - prev: 2 x uint4
+   const uint4 *rows = (const uint4 *)(match + (uint64_t)wk.block * match_stride);   // row r = pos - prev: slots 0..3 (zh_common.h)
+   const uint4 *rows_hi = rows + ZH_ROW_HI_OFF(match_stride);                        // ... and 4..7, present when slot 3 holds a match
    const uint64_t *bar = bars + (uint64_t)wk.block * bar_stride;
    uint32_t *best = best_all + (uint64_t)wk.block * best_stride;
    const uint32_t lane = zh_lane(), row = lane >> 4, s = lane & 15;
@@ -321,9 +323,11 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       {                                                                                                        \
          const bool ok_ = s < n_cnt;                                                                           \
          const uint32_t pos_ = ok_ ? n_lo + s : wk.start;   /* clamped: the loads are always legal */          \
-         const uint4 a_ = rows[(uint64_t)(pos_ - prev) * 2], b_ = rows[(uint64_t)(pos_ - prev) * 2 + 1];       \
-         const uint32_t y_ = win[pos_];                                                                        \
          const uint4 z_ = {0, 0, 0, 0};                                                                        \
+         const uint4 a_ = rows[pos_ - prev];                                                                   \
+         uint4 b_ = z_;                                                                                        \
+         if (ok_ && (a_.w & 0xffffu) >= ZH_MIN_MATCH) b_ = rows_hi[pos_ - prev];                               \
+         const uint32_t y_ = win[pos_];                                                                        \
          regs.a = ok_ ? a_ : z_;                                                                               \
          regs.b = ok_ ? b_ : z_;                                                                               \
          regs.byte = y_;                                                                                       \
@@ -374,7 +378,8 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       zh_sync();
       // ---- flush: decode the winning (slot, length) of each position and store the parse --------------------------
       if (s < c_cnt)
-         best[(c_lo + s) - prev] = zh_decode_pick(ws, row, s, ws.rec[row][s].x, sb_end - (c_lo + s), (const uint32_t *)(rows + (uint64_t)(c_lo + s - prev) * 2));
+         best[(c_lo + s) - prev] = zh_decode_pick(ws, row, s, ws.rec[row][s].x, sb_end - (c_lo + s), (const uint32_t *)(rows + (c_lo + s - prev)),
+                                                  (const uint32_t *)(rows_hi + (c_lo + s - prev)));
       zh_sync();
    }
 #undef ZH_NEXT_TILE

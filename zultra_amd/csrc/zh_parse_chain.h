@@ -59,11 +59,13 @@ struct zh_chain_fetch_t {
 };
 
 // producer thread pl = 4 j + part: position thi-1-j of the tile [thi - cnt, thi)
-__device__ __forceinline__ void zh_chain_fetch(zh_chain_fetch_t &f, const uint4 *rows, const uint8_t *win, uint32_t prev, uint32_t thi, uint32_t cnt, uint32_t pl) {
+__device__ __forceinline__ void zh_chain_fetch(zh_chain_fetch_t &f, const uint4 *rows, const uint4 *rows_hi, const uint8_t *win, uint32_t prev, uint32_t thi,
+                                               uint32_t cnt, uint32_t pl) {
    const uint32_t j = pl >> 2;
    const uint32_t pos = j < cnt ? thi - 1 - j : thi - 1;   // clamped: the loads are always legal
-   f.a = rows[(uint64_t)(pos - prev) * 2];
-   f.b = rows[(uint64_t)(pos - prev) * 2 + 1];
+   f.a = rows[pos - prev];
+   f.b.x = f.b.y = f.b.z = f.b.w = 0;
+   if ((f.a.w & 0xffffu) >= ZH_MIN_MATCH) f.b = rows_hi[pos - prev];   // slots 4..7 exist only behind a full first plane (zh_common.h)
    f.byte = win[pos];
 }
 
@@ -137,14 +139,17 @@ __device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, 
 
 // flusher: the winning keys of a priced tile -> parse entries (zh_decode_pick). Thread i = position thi-1-i; the position's match
 // row is read again (an L2 hit: the producers loaded it two tile periods ago).
-__device__ __forceinline__ void zh_chain_flush(zh_chain_ws_t &ws, uint32_t buf, const uint4 *rows, uint32_t prev, uint32_t thi, uint32_t cnt, uint32_t sb_end, uint32_t i,
-                                               uint32_t *best) {
+__device__ __forceinline__ void zh_chain_flush(zh_chain_ws_t &ws, uint32_t buf, const uint4 *rows, const uint4 *rows_hi, uint32_t prev, uint32_t thi, uint32_t cnt,
+                                               uint32_t sb_end, uint32_t i, uint32_t *best) {
    if (i >= cnt) return;
    const uint32_t pos = thi - 1 - i;
    const uint32_t kk = ws.p.bt[buf][i];
    uint32_t pick = 0;
    if (kk & 511u) {   // low 9 bits: 0 = literal, else (slot << 6 | 39 - length) + 1
-      const uint4 a = rows[(uint64_t)(pos - prev) * 2], b = rows[(uint64_t)(pos - prev) * 2 + 1];
+      const uint4 a = rows[pos - prev];
+      uint4 b;
+      b.x = b.y = b.z = b.w = 0;
+      if ((a.w & 0xffffu) >= ZH_MIN_MATCH) b = rows_hi[pos - prev];
       const uint32_t raw[ZH_NMATCH] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
       uint32_t nlong = 0;
 #pragma unroll
@@ -247,8 +252,8 @@ __device__ __forceinline__ void zh_chain_rebase(zh_chain_ws_t &ws, zh_chain_stat
 
 // Parse [t0, t1) of a sub-block as one chain, t1 a barrier or the sub-block end (cost[t1] = 0). All ZH_CHAIN_THREADS threads call.
 // ws.litprice / lencost / distcost hold the prices of the pass.
-__device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, const uint8_t *win, uint32_t prev, uint32_t t0, uint32_t t1, uint32_t sb_end,
-                                      uint32_t *best) {
+__device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, const uint4 *rows_hi, const uint8_t *win, uint32_t prev, uint32_t t0, uint32_t t1,
+                                      uint32_t sb_end, uint32_t *best) {
    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
    const uint32_t ntiles = t1 > t0 ? (t1 - t0 + ZH_CHAIN_TILE - 1) / ZH_CHAIN_TILE : 0u;
    if (!ntiles) return;
@@ -258,8 +263,8 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
    fnext.a.x = fnext.a.y = fnext.a.z = fnext.a.w = fnext.b.x = fnext.b.y = fnext.b.z = fnext.b.w = fnext.byte = 0;
    if (stager) {
       zh_chain_fetch_t f0;
-      zh_chain_fetch(f0, rows, win, prev, t1, min(ZH_CHAIN_TILE, t1 - t0), pl);
-      if (ntiles > 1) zh_chain_fetch(fnext, rows, win, prev, t1 - ZH_CHAIN_TILE, min(ZH_CHAIN_TILE, t1 - ZH_CHAIN_TILE - t0), pl);
+      zh_chain_fetch(f0, rows, rows_hi, win, prev, t1, min(ZH_CHAIN_TILE, t1 - t0), pl);
+      if (ntiles > 1) zh_chain_fetch(fnext, rows, rows_hi, win, prev, t1 - ZH_CHAIN_TILE, min(ZH_CHAIN_TILE, t1 - ZH_CHAIN_TILE - t0), pl);
       zh_chain_stage(ws, 0, f0, t1, min(ZH_CHAIN_TILE, t1 - t0), sb_end, pl);
    }
    else if (wave == 0) {
@@ -288,18 +293,18 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
          if (k + 1 < ntiles) {
             const uint32_t nhi = thi - ZH_CHAIN_TILE;
             const zh_chain_fetch_t f = fnext;
-            if (k + 2 < ntiles) zh_chain_fetch(fnext, rows, win, prev, nhi - ZH_CHAIN_TILE, min(ZH_CHAIN_TILE, nhi - ZH_CHAIN_TILE - t0), pl);
+            if (k + 2 < ntiles) zh_chain_fetch(fnext, rows, rows_hi, win, prev, nhi - ZH_CHAIN_TILE, min(ZH_CHAIN_TILE, nhi - ZH_CHAIN_TILE - t0), pl);
             zh_chain_stage(ws, buf ^ 1u, f, nhi, min(ZH_CHAIN_TILE, nhi - t0), sb_end, pl);
          }
       }
       else if (k)
-         zh_chain_flush(ws, buf ^ 1u, rows, prev, thi + ZH_CHAIN_TILE, ZH_CHAIN_TILE, sb_end, lane, best);
+         zh_chain_flush(ws, buf ^ 1u, rows, rows_hi, prev, thi + ZH_CHAIN_TILE, ZH_CHAIN_TILE, sb_end, lane, best);
       __syncthreads();
    }
    if (wave == 3) {
       const uint32_t k = ntiles - 1;
       const uint32_t thi = t1 - k * ZH_CHAIN_TILE;
-      zh_chain_flush(ws, k & 1u, rows, prev, thi, thi - t0, sb_end, lane, best);
+      zh_chain_flush(ws, k & 1u, rows, rows_hi, prev, thi, thi - t0, sb_end, lane, best);
    }
 }
 
@@ -354,6 +359,7 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       const uint8_t *win = data + blk.win_off;
       const uint32_t prev = blk.prev;
       const uint4 *rows = (const uint4 *)(match + (uint64_t)wk.block * match_stride);
+      const uint4 *rows_hi = rows + ZH_ROW_HI_OFF(match_stride);
       const uint64_t *bar = bars + (uint64_t)wk.block * bar_stride;
       uint32_t *best = best_all + (uint64_t)wk.block * best_stride;
       const uint32_t sb_end = wk.start + wk.size;
@@ -375,7 +381,7 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y, wk.ntasks);
       const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
       __syncthreads();
-      zh_chain_parse(ws, rows, win, prev, t0, t1, sb_end, best);
+      zh_chain_parse(ws, rows, rows_hi, win, prev, t0, t1, sb_end, best);
 
       // ---- histogram of the task's parse; the per-sub-block sum is taken by zh_sb_build -------------------------------
       if (st->is_dynamic) {

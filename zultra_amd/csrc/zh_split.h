@@ -77,14 +77,14 @@ __device__ inline uint32_t zh_first_barrier(const uint64_t *bar, uint32_t r, uin
 #endif
 
 __global__ void __launch_bounds__(64)
-zh_barriers(const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride, uint64_t *bars, uint64_t bar_stride,
+zh_barriers(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ longest, uint64_t longest_stride, uint64_t *bars, uint64_t bar_stride,
             uint32_t *chunkmax, uint32_t cpb) {
    const uint32_t b = blockIdx.x / cpb, c = blockIdx.x - b * cpb;
    const zh_block_t blk = blocks[b];
    const uint32_t n = blk.n, lo = c * ZH_TOK_CHUNK;
    if (lo >= n) return;
    const uint32_t hi = min(n, lo + ZH_TOK_CHUNK);
-   const uint32_t *rows = (const uint32_t *)(match + (uint64_t)b * match_stride);
+   const uint32_t *rows = longest + (uint64_t)b * longest_stride;   // per position: its longest match (slot 0 of its row, matchfinder.c:221)
    uint64_t *bar = bars + (uint64_t)b * bar_stride;
    const uint32_t lane = zh_lane();
    uint32_t reach_before = 0;   // running maximum over the chunk's earlier tiles
@@ -92,7 +92,7 @@ zh_barriers(const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict_
 #pragma unroll
    for (uint32_t u = 0; u < 4; u++) {
       const uint32_t r = lo + u * 64 + lane;
-      pm[u] = r < hi ? rows[(uint64_t)r * ZH_NMATCH] : 0u;   // slot 0 = longest match (matchfinder.c:221)
+      pm[u] = r < hi ? rows[r] : 0u;
    }
    for (uint32_t base4 = lo; base4 < hi; base4 += 256) {
 #pragma unroll
@@ -101,7 +101,7 @@ zh_barriers(const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict_
          if (base >= hi) break;
          const uint32_t r = base + lane;
          const uint32_t len = pm[u] & 0xffffu;
-         pm[u] = r + 256 < hi ? rows[(uint64_t)(r + 256) * ZH_NMATCH] : 0u;
+         pm[u] = r + 256 < hi ? rows[r + 256] : 0u;
          const uint32_t incl = zh_wave_incl_max(r < hi ? r + max(len, 1u) : 0u);
          const uint32_t up = zh_shfl(incl, (int)((lane - 1) & 63));
          const uint32_t excl = lane ? max(reach_before, up) : reach_before;
@@ -131,7 +131,7 @@ __global__ void zh_barriers_fix(const zh_block_t *__restrict__ blocks, uint32_t 
 }
 
 __global__ void __launch_bounds__(64)
-zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
+zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ longest, uint64_t longest_stride,
                   uint32_t *tok_pos, uint16_t *tok_info, uint64_t tok_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride, uint32_t *spanstart,
                   uint32_t *spancnt, uint32_t cpb) {
    const uint32_t b = blockIdx.x / cpb, c = blockIdx.x - b * cpb;
@@ -150,7 +150,7 @@ zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict
       return;
    }
    const uint8_t *win = data + blk.win_off;
-   const uint32_t *rows = (const uint32_t *)(match + (uint64_t)b * match_stride);
+   const uint32_t *rows = longest + (uint64_t)b * longest_stride;
    uint32_t *tp = tok_pos + (uint64_t)b * tok_stride + s0;    // staged at the span's position offset (tokens <= positions)
    uint16_t *ti = tok_info + (uint64_t)b * tok_stride + s0;
    uint32_t ntok = 0, carry = 0;
@@ -161,7 +161,7 @@ zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict
       pm[u] = 0;
       pb[u] = 0;
       if (r < s1) {
-         pm[u] = rows[(uint64_t)r * ZH_NMATCH];
+         pm[u] = rows[r];
          pb[u] = win[blk.prev + r];
       }
    }
@@ -176,7 +176,7 @@ zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict
          pm[u] = 0;
          pb[u] = 0;
          if (r + 256 < s1) {
-            pm[u] = rows[(uint64_t)(r + 256) * ZH_NMATCH];
+            pm[u] = rows[r + 256];
             pb[u] = win[blk.prev + r + 256];
          }
          const uint32_t len = m0 & 0xffffu;
