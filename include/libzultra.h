@@ -115,6 +115,12 @@ size_t zultra_memory_compress_dict(const unsigned char *pInputData, size_t nInpu
                                    const void *pDictionaryData, int nDictionaryDataSize);
 /* Device the library runs on (default 0, or env ZULTRA_HIP_DEVICE); call before the first stream is created. */
 void zultra_set_device(int nDevice);
+/* zultra_stream_end frees everything the stream owns through zfree, like the reference (libzultra.c:521-565) — except that the
+ * device context (device memory and pinned staging) of a finished stream is kept for the next stream of the same geometry:
+ * creating one takes ~45 device allocations. zultra_release_cached_contexts() destroys the contexts kept that way (at most
+ * two); with the environment variable ZULTRA_HIP_CACHE=0 none is ever kept and zultra_stream_end releases the device memory
+ * itself. Returns the number of contexts destroyed. */
+int zultra_release_cached_contexts(void);
 
 #ifdef __cplusplus
 }

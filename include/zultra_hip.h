@@ -82,6 +82,12 @@ zultra_hip_ctx_t *zultra_hip_create(int device, uint32_t max_block_size, uint32_
 void zultra_hip_destroy(zultra_hip_ctx_t *ctx);
 const char *zultra_hip_last_error(const zultra_hip_ctx_t *ctx);
 
+/* What a context was created with, and the device memory it holds (any pointer may be NULL). */
+void zultra_hip_ctx_info(const zultra_hip_ctx_t *ctx, int *device, uint32_t *max_block_size, uint32_t *max_blocks, size_t *device_bytes);
+/* Device bytes zultra_hip_create(device, max_block_size, max_blocks) will allocate, computed from the same layout without
+ * allocating: callers size their batches against the memory they want to spend. */
+size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max_blocks);
+
 /* Pinned host staging owned by the context (which: 0 = input side, 1 = output side), at least `size` bytes, valid until
  * the context is destroyed or a larger size is requested. The streaming API stages caller data through these: copies
  * from pageable memory run at a fraction of the PCIe rate. Returns NULL on failure. */

@@ -378,3 +378,29 @@ def test_bench_config1_known_answer():
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert line["known_answer_ok"] and line["compressed_bytes"] == 10523 and line["gzip_bytes"] == 10541
     assert "roofline" in line and "cpu_baseline" in line
+
+
+def test_cached_contexts_are_released_on_request(gpu):
+    """zultra_stream_end keeps the device context of a finished stream for the next one; zultra_release_cached_contexts()
+    frees what is kept (the reference frees everything in zultra_stream_end, libzultra.c:521-565)."""
+    import ctypes as C
+    f = gpu.L.zultra_release_cached_contexts
+    f.restype = C.c_int
+    f()
+    d = corpus.text_like(200000, 3)
+    assert gpu.memory_compress(d, 2, 65536) is not None
+    assert f() == 1          # the stream's context was cached ...
+    assert f() == 0          # ... and is gone now
+    g = gpu.L.zultra_hip_context_bytes
+    g.argtypes = [C.c_uint32, C.c_uint32]
+    g.restype = C.c_size_t
+    ctx = gpu.context(65536, 64)
+    try:
+        info = (C.c_int(), C.c_uint32(), C.c_uint32(), C.c_size_t())
+        gpu.L.zultra_hip_ctx_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
+        gpu.L.zultra_hip_ctx_info(ctx.h, *[C.byref(x) for x in info])
+        assert (info[1].value, info[2].value) == (65536, 64)
+        est = g(65536, 64)
+        assert 0.95 * info[3].value <= est <= 1.10 * info[3].value, (est, info[3].value)   # the estimate follows the real layout
+    finally:
+        ctx.close()

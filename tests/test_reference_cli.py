@@ -50,3 +50,24 @@ def test_reference_cli_compress_verify_and_guard_byte_bench(tmp_path, oracle):
     # -cbench: five timed runs with guard bytes either side of the output buffer (tool/zultra.c:705-753)
     r = subprocess.run([CLI, "-cbench", str(src), str(dst)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+OWN_CLI = os.path.join(ROOT, "zultra_amd", "zultra_amd_cli")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,flags,bs,chunk_kib", [("gzip", 2, 65536, 1024), ("zlib", 1, 32768, 16), ("raw", 0, 0, 8192)])
+def test_own_cli_block_size_option(tmp_path, oracle, fmt, flags, bs, chunk_kib):
+    """The build's own tool (zultra_amd/csrc/zultra_cli.c): -b selects the max-block size the reference's tool cannot, input is
+    fed in `chunk_kib` KiB pieces (16 KiB = the reference tool's chunking: blocks are then collected into device batches by the
+    stream layer). The file equals the CPU path's bytes for the same flags and block size."""
+    if not os.path.exists(OWN_CLI):
+        pytest.skip("zultra_amd_cli not built")
+    d = np.concatenate([corpus.text_like(900000, 13), corpus.noise(80000, 6), corpus.mixed(300000, 8)])
+    src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
+    src.write_bytes(d.tobytes())
+    args = [OWN_CLI, "-f", fmt, "-k", str(chunk_kib), "-v"] + (["-b", str(bs)] if bs else []) + [str(src), str(dst)]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert dst.read_bytes() == oracle.memory_compress(d, flags, bs)
+    assert "MB/s" in r.stdout

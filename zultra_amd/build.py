@@ -13,6 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzultra_amd.so")
+CLI = os.path.join(HERE, "zultra_amd_cli")
 SOURCES = ["zh_device.hip", "libzultra.cpp"]
 HEADERS = ["zh_platform.h", "zh_common.h", "zh_matchfinder.h", "zh_huffman.h", "zh_split.h", "zh_parse.h", "zh_parse_chain.h", "zh_encode.h", "zh_stitch.h"]
 
@@ -25,10 +26,10 @@ def hipcc_path():
 
 
 def needs_build():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(CLI):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + ["zultra_cli.c"]]
     deps += [os.path.join(HERE, "..", "include", f) for f in ("libzultra.h", "zultra_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -42,6 +43,11 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    # the command-line tool (csrc/zultra_cli.c): plain C against include/libzultra.h, linked against the library just built
+    cli = [shutil.which("gcc") or "gcc", "-O2", "-Wall", "-o", CLI, os.path.join(CSRC, "zultra_cli.c"), "-L", HERE, "-lzultra_amd", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cli), flush=True)
+    subprocess.run(cli, check=True)
     return OUT
 
 

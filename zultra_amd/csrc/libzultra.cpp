@@ -427,9 +427,6 @@ static uint32_t clamp_block(uint32_t n) {
    return n;
 }
 
-// device bytes one max-block of a batch costs (see the layout comment in zh_device.hip)
-static uint64_t per_block_device_bytes(uint32_t bs) { return (uint64_t)bs * 64 + 900000; }
-
 static zultra_hip_ctx_t *ctx_acquire(uint32_t bs, uint32_t want_blocks) {
    const int dev = zh_pick_device();
    std::lock_guard<std::mutex> lk(g_ctx_mutex);
@@ -452,14 +449,32 @@ static zultra_hip_ctx_t *ctx_acquire(uint32_t bs, uint32_t want_blocks) {
    return zultra_hip_create(dev, bs, want_blocks);
 }
 
-static void ctx_release(zultra_hip_ctx_t *c, uint32_t bs, uint32_t blocks) {
+// A finished stream's context goes back under what the CONTEXT says it is (device, block size, capacity) — not under what the
+// stream asked for or what zultra_set_device says now.
+static void ctx_release(zultra_hip_ctx_t *c) {
    if (!c) return;
+   const char *e = getenv("ZULTRA_HIP_CACHE");
+   if (e && atoi(e) == 0) {
+      zultra_hip_destroy(c);
+      return;
+   }
+   CachedCtx cc;
+   cc.ctx = c;
+   zultra_hip_ctx_info(c, &cc.device, &cc.max_block, &cc.max_blocks, NULL);
    std::lock_guard<std::mutex> lk(g_ctx_mutex);
    if (g_ctx_pool.size() >= 2) {
       zultra_hip_destroy(g_ctx_pool[0].ctx);
       g_ctx_pool.erase(g_ctx_pool.begin());
    }
-   g_ctx_pool.push_back(CachedCtx{c, zh_pick_device(), bs, blocks});
+   g_ctx_pool.push_back(cc);
+}
+
+extern "C" int zultra_release_cached_contexts(void) {
+   std::lock_guard<std::mutex> lk(g_ctx_mutex);
+   const int n = (int)g_ctx_pool.size();
+   for (size_t i = 0; i < g_ctx_pool.size(); i++) zultra_hip_destroy(g_ctx_pool[i].ctx);
+   g_ctx_pool.clear();
+   return n;
 }
 
 struct _zultra_compressor_s {
@@ -525,9 +540,9 @@ static zultra_status_t stream_init_sized(zultra_stream_t *s, unsigned flags, uns
       batch_blocks = e ? (uint32_t)atoi(e) : (uint32_t)((64u << 20) / bs);
       if (batch_blocks < 2) batch_blocks = 2;
    }
-   const uint64_t budget = 24ull << 30;   // device bytes per context; MI355X has 288 GB
-   if ((uint64_t)batch_blocks * per_block_device_bytes(bs) > budget) batch_blocks = (uint32_t)(budget / per_block_device_bytes(bs));
-   if (batch_blocks < 1) batch_blocks = 1;
+   // device bytes per context (MI355X has 288 GB): sized from the layout the context will really allocate
+   const uint64_t budget = 24ull << 30;
+   while (batch_blocks > 1 && (uint64_t)zultra_hip_context_bytes(bs, batch_blocks) > budget) batch_blocks = batch_blocks - (batch_blocks + 7) / 8;
    c->batch_blocks = batch_blocks;
 
    c->hip = ctx_acquire(bs, batch_blocks);
@@ -566,7 +581,7 @@ extern "C" zultra_status_t zultra_stream_set_dictionary(zultra_stream_t *s, cons
 extern "C" void zultra_stream_end(zultra_stream_t *s) {
    if (s->state && s->zfree) {
       zultra_compressor_t *c = s->state;
-      ctx_release(c->hip, c->max_block, c->batch_blocks);
+      ctx_release(c->hip);
       /* c->in / c->out belong to the device context */
       c->~zultra_compressor_t();
       s->zfree(s->opaque, c);
@@ -730,7 +745,11 @@ extern "C" zultra_status_t zultra_stream_compress(zultra_stream_t *s, const int 
             final_last = (s->avail_in == 0);
          }
          else if (full) {
-            count = (rem || s->avail_in) ? full : full - 1;
+            // A full max-block may be compressed once input beyond it has been seen (libzultra.c:269). Nothing obliges us to do it
+            // at once: blocks are kept until the staging area is full, so that a caller feeding small chunks (the reference's
+            // CLI reads 16 KiB at a time) still gets device batches of many max-blocks instead of one launch sequence per block.
+            const uint32_t ready = (rem || s->avail_in) ? full : full - 1;
+            if (c->in_bytes >= cap || (ready >= c->batch_blocks)) count = ready;
          }
          if (count) err = compress_staged(s, c, count, last_n, final_last && count > 0);
       }

@@ -43,6 +43,7 @@ struct zultra_hip_ctx_s {
    uint32_t max_block, max_blocks;
    uint64_t W, sort_stride, match_stride, tok_stride, best_stride, slot_stride;
    size_t data_cap;
+   size_t device_bytes;         // sum of the context's device allocations (zultra_hip_ctx_info)
    hipStream_t stream;
    hipEvent_t ev[8];
 
@@ -285,6 +286,7 @@ extern "C" int zultra_hip_device_count(void) {
 template <typename T>
 static int zh_alloc(zultra_hip_ctx_t *c, T **p, size_t count) {
    ZH_CHECK(c, hipMalloc((void **)p, count * sizeof(T)));
+   c->device_bytes += count * sizeof(T);
    return 0;
 }
 
@@ -498,6 +500,36 @@ extern "C" void *zultra_hip_staging(zultra_hip_ctx_t *c, int which, size_t size)
 }
 
 extern "C" const char *zultra_hip_last_error(const zultra_hip_ctx_t *c) { return c ? c->err : "no context"; }
+extern "C" void zultra_hip_ctx_info(const zultra_hip_ctx_t *c, int *device, uint32_t *max_block_size, uint32_t *max_blocks, size_t *device_bytes) {
+   if (!c) return;
+   if (device) *device = c->device;
+   if (max_block_size) *max_block_size = c->max_block;
+   if (max_blocks) *max_blocks = c->max_blocks;
+   if (device_bytes) *device_bytes = c->device_bytes;
+}
+
+// Device bytes a context for batches of `max_blocks` max-blocks of `max_block_size` bytes allocates: the same strides and the
+// same list of arrays as zh_create / zh_create_buffers (the layout comment at the top of this file), without allocating.
+extern "C" size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max_blocks) {
+   const uint64_t N = zh_clamp_block(max_block_size), B = max_blocks;
+   const uint64_t W = N + ZH_HISTORY;
+   const uint64_t seg_W = W <= ZH_SEG_WINDOW ? W : (uint64_t)ZH_SEG_WINDOW;
+   const uint64_t S = W <= ZH_SEG_WINDOW ? 1 : (N + ZH_SEG_POSITIONS - 1) / ZH_SEG_POSITIONS;
+   const uint64_t sort_stride = (seg_W + 63) & ~63ull, run_stride = sort_stride + 576, tok_stride = (N + 63) & ~63ull;
+   const uint64_t slot_stride = ((N + 64 * ZH_MAX_SPLITS + 64) + 63) & ~63ull, cpb = (N + ZH_TOK_CHUNK - 1) / ZH_TOK_CHUNK;
+   const uint64_t tasks = B * (N / ZH_TASK + ZH_MAX_SPLITS), subs = B * ZH_MAX_SPLITS;
+   uint64_t bytes = 0;
+   bytes += W + (B - 1) * N + 64;                                    // d_data
+   bytes += B * S * sort_stride * (4 + 4 + 8) + B * S * run_stride * 4;   // sort ping-pong, prev records, run tables
+   bytes += B * N * ZH_NMATCH * sizeof(zh_match_t) + B * tok_stride * (4 + 4 + 2 + 4);   // rows, longest, token chain, parse
+   bytes += B * (tok_stride / 64) * 8;                               // barrier bitmap
+   bytes += B * slot_stride;                                         // payload slots
+   bytes += (B * (N + 5 * (N / 65535 + 1) + 8) + 80);                // stitched stream
+   bytes += subs * (sizeof(zh_sbstate_t) + sizeof(zh_work_t) + 2 * sizeof(zh_subblock_t) + sizeof(zh_stitch_item_t));
+   bytes += tasks * (sizeof(uint2) + 4 + 4 + ZH_NSYM * 4);           // task map, chain list, bit counts, histograms
+   bytes += B * (S * (sizeof(zh_seg_t) + 8) + sizeof(zh_block_t) + cpb * 12 + (ZH_MAX_SPLITS + 1) * 4 + 6 * 4) + 8192;
+   return (size_t)bytes;
+}
 extern "C" size_t zultra_hip_data_capacity(const zultra_hip_ctx_t *c) { return c ? c->data_cap : 0; }
 
 // Cuts the max-blocks of a batch into matchfinder segments (zh_common.h) and uploads the list.
