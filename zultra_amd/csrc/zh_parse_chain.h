@@ -6,12 +6,13 @@
 // on the costs is done by other waves of the workgroup.
 //
 // Workgroup = 4 waves, one chain at a time:
-//   producers (waves 1, 2)  digest the match rows of the NEXT tile of 32 positions (loads issued a tile period earlier) and write
+//   producers (waves 1, 2)  digest the match rows of the NEXT tile of 32 positions (loads issued three tile periods earlier) and write
 //                           one 32-bit descriptor per (position, candidate): price of the candidate in the bits the costs are
 //                           kept in, below it the (slot, length) bits that break ties the way the reference's evaluation order
 //                           does, and — for the slots stored with length >= 40, tried at full length only
 //                           (blockdeflate.c:286-297) — above it the cost-ring entry that holds cost[p + length];
-//   flusher   (wave 3)      turns the winning keys of the PREVIOUS tile into parse entries and stores them;
+//   flusher   (wave 3)      turns the winning keys of the PREVIOUS tile into parse entries and stores them (the rows it needs for
+//                           that were left in LDS by the producers);
 //   consumer  (wave 0)      one position per step, candidate = lane: lane j < 37 prices length 3+j, lanes 40..47 the long slots.
 //                           The costs live in REGISTERS across the lanes: lane j holds cost[p+3+j], and moving to p-1 is one DPP
 //                           wave shift with cost[p+2] — known two steps earlier — entering at lane 0. So a step is: one LDS read
@@ -44,6 +45,8 @@ struct zh_chain_ws_t {
                                                           // the producers' stores (16 positions per store instruction) over the LDS banks
          uint32_t lit[2][ZH_CHAIN_TILE];                  // literal price << 9 (0 for positions below the range)
          uint32_t bt[2][ZH_CHAIN_TILE];                   // winning key per position; low 9 bits zero = literal
+         uint32_t raw[4][ZH_CHAIN_TILE][9];               // [tile % 4]: the positions' match rows as staged (8 slots; the odd stride spreads
+                                                          // the banks), for the flusher two tile periods later
       } p;
       uint32_t hist[ZH_NSYM];                             // after the parse: histogram of the range
    };
@@ -71,7 +74,8 @@ __device__ __forceinline__ void zh_chain_fetch(zh_chain_fetch_t &f, const uint4 
 
 // producer: stage tile [thi - cnt, thi) into parity `buf`. Thread pl = 4 j + part writes the 16 descriptors of consumer lanes
 // 16 part .. 16 part + 15 of position thi-1-j (part 0: lengths 3..18, 1: 19..34, 2: 35..39, 3: the slots stored with length >= 40).
-__device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, const zh_chain_fetch_t &f, uint32_t thi, uint32_t cnt, uint32_t sb_end, uint32_t pl) {
+__device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, uint32_t rbuf, const zh_chain_fetch_t &f, uint32_t thi, uint32_t cnt, uint32_t sb_end,
+                                               uint32_t pl) {
    const uint32_t j = pl >> 2, part = pl & 3u;
    uint32_t *d = &ws.p.desc[buf][j][16u * part];
    const bool ok = j < cnt;
@@ -97,6 +101,10 @@ __device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, 
       nshort += is_short ? 1u : 0u;
    }
    kmax = min(kmax, room);                                  // end clamp (blockdeflate.c:283-284)
+   if (part == 0) {
+#pragma unroll
+      for (uint32_t m = 0; m < ZH_NMATCH; m++) ws.p.raw[rbuf][j][m] = raw[m];
+   }
    if (part < 3) {
       // lengths k = 3 + 16 part + s (part 2: lanes 32..39, of which lengths 35..39 exist): the last short slot reaching k has
       // the cheapest distance among those that can provide it
@@ -138,27 +146,21 @@ __device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, 
 }
 
 // flusher: the winning keys of a priced tile -> parse entries (zh_decode_pick). Thread i = position thi-1-i; the position's match
-// row is read again (an L2 hit: the producers loaded it two tile periods ago).
-__device__ __forceinline__ void zh_chain_flush(zh_chain_ws_t &ws, uint32_t buf, const uint4 *rows, const uint4 *rows_hi, uint32_t prev, uint32_t thi, uint32_t cnt,
-                                               uint32_t sb_end, uint32_t i, uint32_t *best) {
+// row comes from LDS, where the stager left it (a global load here would put HBM latency into every tile period).
+__device__ __forceinline__ void zh_chain_flush(zh_chain_ws_t &ws, uint32_t buf, uint32_t rbuf, uint32_t prev, uint32_t thi, uint32_t cnt, uint32_t sb_end, uint32_t i,
+                                               uint32_t *best) {
    if (i >= cnt) return;
    const uint32_t pos = thi - 1 - i;
    const uint32_t kk = ws.p.bt[buf][i];
    uint32_t pick = 0;
    if (kk & 511u) {   // low 9 bits: 0 = literal, else (slot << 6 | 39 - length) + 1
-      const uint4 a = rows[pos - prev];
-      uint4 b;
-      b.x = b.y = b.z = b.w = 0;
-      if ((a.w & 0xffffu) >= ZH_MIN_MATCH) b = rows_hi[pos - prev];
-      const uint32_t raw[ZH_NMATCH] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      const uint32_t *raw = ws.p.raw[rbuf][i];
       uint32_t nlong = 0;
 #pragma unroll
       for (uint32_t q = 0; q < ZH_NMATCH; q++) nlong += (raw[q] & 0xffffu) >= ZH_LEAVE_ALONE ? 1u : 0u;
       const uint32_t tb = (kk & 511u) - 1u;
       const uint32_t m = tb >> 6;
-      uint32_t e = raw[0];
-#pragma unroll
-      for (uint32_t q = 1; q < ZH_NMATCH; q++) e = (m == q) ? raw[q] : e;
+      const uint32_t e = raw[m];
       const uint32_t len = (m < nlong) ? min(e & 0xffffu, sb_end - pos) : (39u - (tb & 63u));
       pick = len | (e & 0xffff0000u);
    }
@@ -259,13 +261,20 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
    if (!ntiles) return;
    const bool stager = wave == 1 || wave == 2;
    const uint32_t pl = tid - 64;   // stagers: 0..127
-   zh_chain_fetch_t fnext;
-   fnext.a.x = fnext.a.y = fnext.a.z = fnext.a.w = fnext.b.x = fnext.b.y = fnext.b.z = fnext.b.w = fnext.byte = 0;
+   // the consumer takes a tile in about a microsecond; the stagers' row loads are therefore issued three tile periods ahead
+   // (HBM latency under load is two of them)
+   zh_chain_fetch_t fq[3];
+#pragma unroll
+   for (uint32_t q = 0; q < 3; q++) fq[q].a.x = fq[q].a.y = fq[q].a.z = fq[q].a.w = fq[q].b.x = fq[q].b.y = fq[q].b.z = fq[q].b.w = fq[q].byte = 0;
+#define ZH_CHAIN_TILE_HI(k_) (t1 - (k_) * ZH_CHAIN_TILE)
+#define ZH_CHAIN_TILE_CNT(k_) min(ZH_CHAIN_TILE, ZH_CHAIN_TILE_HI(k_) - t0)
    if (stager) {
       zh_chain_fetch_t f0;
-      zh_chain_fetch(f0, rows, rows_hi, win, prev, t1, min(ZH_CHAIN_TILE, t1 - t0), pl);
-      if (ntiles > 1) zh_chain_fetch(fnext, rows, rows_hi, win, prev, t1 - ZH_CHAIN_TILE, min(ZH_CHAIN_TILE, t1 - ZH_CHAIN_TILE - t0), pl);
-      zh_chain_stage(ws, 0, f0, t1, min(ZH_CHAIN_TILE, t1 - t0), sb_end, pl);
+      zh_chain_fetch(f0, rows, rows_hi, win, prev, t1, ZH_CHAIN_TILE_CNT(0u), pl);
+#pragma unroll
+      for (uint32_t q = 0; q < 3; q++)
+         if (q + 1 < ntiles) zh_chain_fetch(fq[q], rows, rows_hi, win, prev, ZH_CHAIN_TILE_HI(q + 1), ZH_CHAIN_TILE_CNT(q + 1), pl);
+      zh_chain_stage(ws, 0, 0, f0, t1, ZH_CHAIN_TILE_CNT(0u), sb_end, pl);
    }
    else if (wave == 0) {
       // cost[t1] = 0; entries above it are never asked for (t1 is a barrier or the end: no candidate reaches past it)
@@ -282,8 +291,7 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
    st.c1 = 0;   // cost9[t1]
    st.c2 = 0;
    for (uint32_t k = 0; k < ntiles; k++) {
-      const uint32_t thi = t1 - k * ZH_CHAIN_TILE;
-      const uint32_t cnt = min(ZH_CHAIN_TILE, thi - t0);
+      const uint32_t thi = ZH_CHAIN_TILE_HI(k);
       const uint32_t buf = k & 1u;
       if (wave == 0) {
          if (st.c1 >= ZH_CHAIN_REBASE) zh_chain_rebase(ws, st);
@@ -291,21 +299,23 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
       }
       else if (stager) {
          if (k + 1 < ntiles) {
-            const uint32_t nhi = thi - ZH_CHAIN_TILE;
-            const zh_chain_fetch_t f = fnext;
-            if (k + 2 < ntiles) zh_chain_fetch(fnext, rows, rows_hi, win, prev, nhi - ZH_CHAIN_TILE, min(ZH_CHAIN_TILE, nhi - ZH_CHAIN_TILE - t0), pl);
-            zh_chain_stage(ws, buf ^ 1u, f, nhi, min(ZH_CHAIN_TILE, nhi - t0), sb_end, pl);
+            const zh_chain_fetch_t f = fq[0];
+            fq[0] = fq[1];
+            fq[1] = fq[2];
+            if (k + 4 < ntiles) zh_chain_fetch(fq[2], rows, rows_hi, win, prev, ZH_CHAIN_TILE_HI(k + 4), ZH_CHAIN_TILE_CNT(k + 4), pl);
+            zh_chain_stage(ws, buf ^ 1u, (k + 1) & 3u, f, ZH_CHAIN_TILE_HI(k + 1), ZH_CHAIN_TILE_CNT(k + 1), sb_end, pl);
          }
       }
       else if (k)
-         zh_chain_flush(ws, buf ^ 1u, rows, rows_hi, prev, thi + ZH_CHAIN_TILE, ZH_CHAIN_TILE, sb_end, lane, best);
+         zh_chain_flush(ws, buf ^ 1u, (k - 1) & 3u, prev, thi + ZH_CHAIN_TILE, ZH_CHAIN_TILE, sb_end, lane, best);
       __syncthreads();
    }
    if (wave == 3) {
       const uint32_t k = ntiles - 1;
-      const uint32_t thi = t1 - k * ZH_CHAIN_TILE;
-      zh_chain_flush(ws, k & 1u, rows, rows_hi, prev, thi, thi - t0, sb_end, lane, best);
+      zh_chain_flush(ws, k & 1u, k & 3u, prev, ZH_CHAIN_TILE_HI(k), ZH_CHAIN_TILE_CNT(k), sb_end, lane, best);
    }
+#undef ZH_CHAIN_TILE_HI
+#undef ZH_CHAIN_TILE_CNT
 }
 
 // the tasks zh_parse_tasks leaves alone: one wave per task, the same piece computation
@@ -333,7 +343,7 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
 
 // Persistent workgroups take the listed tasks from a ticket: the grid is small and fixed (ZH_CHAIN_GRID), so it is dispatched at
 // once — next to zh_parse_tasks' tens of thousands of waves — and every chain starts at the beginning of the pass.
-#define ZH_CHAIN_GRID 1024
+#define ZH_CHAIN_GRID 1536
 __global__ void __launch_bounds__(ZH_CHAIN_THREADS)
 zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
