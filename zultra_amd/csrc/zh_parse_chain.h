@@ -37,6 +37,10 @@
 #define ZH_CHAIN_LONG0 40u           // consumer lane of long slot 0
 #define ZH_CHAIN_REBASE (1u << 30)
 
+#ifdef ZH_CHAIN_PROFILE
+__device__ uint64_t zh_chain_profile[4];   // probe builds only (tools/probes/chain2_probe.hip): busy cycles per role of the last chain
+#endif
+
 struct zh_chain_ws_t {
    union {
       struct {
@@ -66,33 +70,46 @@ __device__ __forceinline__ void zh_chain_fetch(zh_chain_fetch_t &f, const uint4 
                                                uint32_t cnt, uint32_t pl) {
    const uint32_t j = pl >> 2;
    const uint32_t pos = j < cnt ? thi - 1 - j : thi - 1;   // clamped: the loads are always legal
+   // both planes unconditionally (a load that waited for the first plane would put a memory round trip into the tile period);
+   // the second one holds stale bytes unless slot 3 is a match: zh_chain_stage masks it
    f.a = rows[pos - prev];
-   f.b.x = f.b.y = f.b.z = f.b.w = 0;
-   if ((f.a.w & 0xffffu) >= ZH_MIN_MATCH) f.b = rows_hi[pos - prev];   // slots 4..7 exist only behind a full first plane (zh_common.h)
+   f.b = rows_hi[pos - prev];
    f.byte = win[pos];
 }
 
-// producer: stage tile [thi - cnt, thi) into parity `buf`. Thread pl = 4 j + part writes the 16 descriptors of consumer lanes
-// 16 part .. 16 part + 15 of position thi-1-j (part 0: lengths 3..18, 1: 19..34, 2: 35..39, 3: the slots stored with length >= 40).
+// producer: stage tile [thi - cnt, thi) into parity `buf`. Thread pl = 4 j + part serves position thi-1-j:
+//   part 0: consumer lanes 0..15 (lengths 3..18)      part 1: lanes 16..31 (lengths 19..34)
+//   part 2: lanes 32..39 (lengths 35..39, three unused) and 40..47 (the slots stored with length >= 40)
+//   part 3: the literal's price and the raw row for the flusher
+// lcw = the 16 length prices of the thread's part (lencost[16 part ..], four per word), loaded once per chain: a byte read
+// from LDS per descriptor, each waited for, was most of this function's time.
 __device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, uint32_t rbuf, const zh_chain_fetch_t &f, uint32_t thi, uint32_t cnt, uint32_t sb_end,
-                                               uint32_t pl) {
+                                               uint32_t pl, const uint32_t (&lcw)[4]) {
    const uint32_t j = pl >> 2, part = pl & 3u;
    uint32_t *d = &ws.p.desc[buf][j][16u * part];
    const bool ok = j < cnt;
    const uint32_t pos = ok ? thi - 1 - j : thi - 1;
    const uint32_t room = sb_end - pos;
-   const uint32_t raw[ZH_NMATCH] = {ok ? f.a.x : 0u, ok ? f.a.y : 0u, ok ? f.a.z : 0u, ok ? f.a.w : 0u, ok ? f.b.x : 0u, ok ? f.b.y : 0u, ok ? f.b.z : 0u, ok ? f.b.w : 0u};
+   const bool more = ok && (f.a.w & 0xffffu) >= ZH_MIN_MATCH;   // slots 4..7 exist only behind a full first plane (zh_common.h)
+   const uint32_t raw[ZH_NMATCH] = {ok ? f.a.x : 0u, ok ? f.a.y : 0u, ok ? f.a.z : 0u, ok ? f.a.w : 0u, more ? f.b.x : 0u, more ? f.b.y : 0u, more ? f.b.z : 0u, more ? f.b.w : 0u};
+   if (part == 3) {
+#pragma unroll
+      for (uint32_t m = 0; m < ZH_NMATCH; m++) ws.p.raw[rbuf][j][m] = raw[m];
+      ws.p.lit[buf][j] = ok ? (uint32_t)ws.litprice[f.byte & 0xffu] << 9 : 0u;
+      return;
+   }
    // the same digest as zh_stage_position: bitmap of short slot lengths, running minima of (distance price, slot)
    uint32_t nlong = 0, nshort = 0, kmax = 0, run = 0xFFu;
    uint64_t pm = 0, lmask = 0;
    uint32_t oc[ZH_NMATCH];
 #pragma unroll
+   for (uint32_t m = 0; m < ZH_NMATCH; m++) oc[m] = (uint32_t)ws.distcost[zh_dist_sym((raw[m] & 0xffffu) >= ZH_MIN_MATCH ? raw[m] >> 16 : 1u)];
+#pragma unroll
    for (uint32_t m = 0; m < ZH_NMATCH; m++) {
-      const uint32_t len = raw[m] & 0xffffu, off = raw[m] >> 16;
+      const uint32_t len = raw[m] & 0xffffu;
       const bool valid = len >= ZH_MIN_MATCH;
       const bool is_long = len >= ZH_LEAVE_ALONE;
       const bool is_short = valid && !is_long;
-      oc[m] = (uint32_t)ws.distcost[zh_dist_sym(valid ? off : 1u)];
       nlong += is_long ? 1u : 0u;
       kmax = max(kmax, is_short ? len : 0u);               // the first short slot is the longest
       lmask |= is_short ? (1ull << (len - ZH_MIN_MATCH)) : 0ull;
@@ -101,47 +118,37 @@ __device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, 
       nshort += is_short ? 1u : 0u;
    }
    kmax = min(kmax, room);                                  // end clamp (blockdeflate.c:283-284)
-   if (part == 0) {
+   // lengths k = 3 + 16 part + s: the last short slot reaching k has the cheapest distance among those that can provide it
+   const uint32_t e0 = 16u * part;
+   const uint32_t w = (uint32_t)(lmask >> e0);                              // lengths e0+3 .. e0+34
+   const uint32_t above = (uint32_t)__popcll(lmask >> (e0 + 16u) >> 16u);   // slots longer than that window
+   const uint32_t pm_lo = (uint32_t)pm, pm_hi = (uint32_t)(pm >> 32);
 #pragma unroll
-      for (uint32_t m = 0; m < ZH_NMATCH; m++) ws.p.raw[rbuf][j][m] = raw[m];
+   for (uint32_t s = 0; s < 16; s++) {
+      if (part == 2 && s >= 8) break;   // (uniform per thread; lanes 40..47 follow)
+      const uint32_t k = ZH_MIN_MATCH + e0 + s;
+      const uint32_t sel = (uint32_t)__popc(w >> s) + above - 1u;
+      const uint32_t bb = ((sel < 4 ? pm_lo : pm_hi) >> ((sel & 3u) * 8u)) & 0xffu;
+      const uint32_t price = ((lcw[s >> 2] >> (8u * (s & 3u))) & 0xffu) + (bb >> 3);
+      const uint32_t v = (price << 9) | (((bb & 7u) << 6) + (40u - k));   // tie bits: (slot, 39 - k) + 1, the literal's are 0
+      d[s] = (k <= kmax && k < ZH_LEAVE_ALONE) ? v : ZH_CHAIN_NOPRICE;
    }
-   if (part < 3) {
-      // lengths k = 3 + 16 part + s (part 2: lanes 32..39, of which lengths 35..39 exist): the last short slot reaching k has
-      // the cheapest distance among those that can provide it
-      const uint32_t e0 = 16u * part;
-      const uint32_t w = (uint32_t)(lmask >> e0);                              // lengths e0+3 .. e0+34
-      const uint32_t above = (uint32_t)__popcll(lmask >> (e0 + 16u) >> 16u);   // slots longer than that window
-      const uint32_t pm_lo = (uint32_t)pm, pm_hi = (uint32_t)(pm >> 32);
-      const uint32_t nl = part == 2 ? 8u : 16u;
+   if (part == 2) {
+      // the slots stored with length >= 40: tried at their full (clamped) length only (blockdeflate.c:286-297)
+      uint32_t lc[ZH_NMATCH];
 #pragma unroll
-      for (uint32_t i = 0; i < 16; i++) {
-         if (i >= nl) break;
-         const uint32_t s = i;
-         const uint32_t k = ZH_MIN_MATCH + e0 + s;
-         const uint32_t sel = (uint32_t)__popc(w >> s) + above - 1u;
-         const uint32_t bb = ((sel < 4 ? pm_lo : pm_hi) >> ((sel & 3u) * 8u)) & 0xffu;
-         const uint32_t price = (uint32_t)ws.lencost[(e0 + s) & 255u] + (bb >> 3);
-         const uint32_t v = (price << 9) | (((bb & 7u) << 6) + (40u - k));   // tie bits: (slot, 39 - k) + 1, the literal's are 0
-         d[s] = (k <= kmax && k < ZH_LEAVE_ALONE) ? v : ZH_CHAIN_NOPRICE;
-      }
-   }
-   else {
-      // consumer lanes 40..47: the slots stored with length >= 40, tried at their full (clamped) length only; lanes 48..63 are
-      // unused (set once per chain)
-      uint32_t *dl = &ws.p.desc[buf][j][ZH_CHAIN_LONG0];
-#pragma unroll
-      for (uint32_t i = 0; i < ZH_NMATCH; i++) {
-         const uint32_t s = i;
-         const uint32_t rs = raw[s], os = oc[s];
-         const uint32_t mlen = min(rs & 0xffffu, room);
-         uint32_t enc = mlen - ZH_MIN_MATCH;                 // wraps below 3, then saturates (:289, :216-219)
+      for (uint32_t s = 0; s < ZH_NMATCH; s++) {
+         uint32_t enc = min(raw[s] & 0xffffu, room) - ZH_MIN_MATCH;   // wraps below 3, then saturates (:289, :216-219)
          if (enc > 255) enc = 255;
-         const uint32_t price = (uint32_t)ws.lencost[enc] + os;
-         const uint32_t v = (((pos + mlen) & (ZH_CHAIN_RING - 1u)) << 23) | (price << 9) | ((s << 6) + 1u);
-         // a slot that does not exist gathers the cost of the tile's top (dumped a tile ago, within 32 positions of p+1): harmless
-         dl[s] = s < nlong ? v : (((thi & (ZH_CHAIN_RING - 1u)) << 23) | ZH_CHAIN_NOPRICE);
+         lc[s] = ws.lencost[enc];
       }
-      ws.p.lit[buf][j] = ok ? (uint32_t)ws.litprice[f.byte & 0xffu] << 9 : 0u;
+#pragma unroll
+      for (uint32_t s = 0; s < ZH_NMATCH; s++) {
+         const uint32_t mlen = min(raw[s] & 0xffffu, room);
+         const uint32_t v = (((pos + mlen) & (ZH_CHAIN_RING - 1u)) << 23) | ((lc[s] + oc[s]) << 9) | ((s << 6) + 1u);
+         // a slot that does not exist gathers the cost of the tile's top (dumped a tile ago, within 32 positions of p+1): harmless
+         d[8u + s] = s < nlong ? v : (((thi & (ZH_CHAIN_RING - 1u)) << 23) | ZH_CHAIN_NOPRICE);
+      }
    }
 }
 
@@ -263,6 +270,11 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
    const uint32_t pl = tid - 64;   // stagers: 0..127
    // the consumer takes a tile in about a microsecond; the stagers' row loads are therefore issued three tile periods ahead
    // (HBM latency under load is two of them)
+   uint32_t lcw[4] = {0, 0, 0, 0};
+   if (stager) {
+#pragma unroll
+      for (uint32_t q = 0; q < 4; q++) lcw[q] = *(const uint32_t *)&ws.lencost[16u * (pl & 3u) + 4u * q];
+   }
    zh_chain_fetch_t fq[3];
 #pragma unroll
    for (uint32_t q = 0; q < 3; q++) fq[q].a.x = fq[q].a.y = fq[q].a.z = fq[q].a.w = fq[q].b.x = fq[q].b.y = fq[q].b.z = fq[q].b.w = fq[q].byte = 0;
@@ -274,7 +286,7 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
 #pragma unroll
       for (uint32_t q = 0; q < 3; q++)
          if (q + 1 < ntiles) zh_chain_fetch(fq[q], rows, rows_hi, win, prev, ZH_CHAIN_TILE_HI(q + 1), ZH_CHAIN_TILE_CNT(q + 1), pl);
-      zh_chain_stage(ws, 0, 0, f0, t1, ZH_CHAIN_TILE_CNT(0u), sb_end, pl);
+      zh_chain_stage(ws, 0, 0, f0, t1, ZH_CHAIN_TILE_CNT(0u), sb_end, pl, lcw);
    }
    else if (wave == 0) {
       // cost[t1] = 0; entries above it are never asked for (t1 is a barrier or the end: no candidate reaches past it)
@@ -290,9 +302,15 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
    st.cv = 0;   // lane j: cost9[t1 + 2 + j]: beyond the end; lane 0 receives cost9[t1] = 0 when position t1-2 is priced
    st.c1 = 0;   // cost9[t1]
    st.c2 = 0;
+#ifdef ZH_CHAIN_PROFILE
+   uint64_t busy = 0;
+#endif
    for (uint32_t k = 0; k < ntiles; k++) {
       const uint32_t thi = ZH_CHAIN_TILE_HI(k);
       const uint32_t buf = k & 1u;
+#ifdef ZH_CHAIN_PROFILE
+      const uint64_t tp0 = zh_clock();
+#endif
       if (wave == 0) {
          if (st.c1 >= ZH_CHAIN_REBASE) zh_chain_rebase(ws, st);
          zh_chain_consume(ws, buf, thi, st);
@@ -303,13 +321,19 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
             fq[0] = fq[1];
             fq[1] = fq[2];
             if (k + 4 < ntiles) zh_chain_fetch(fq[2], rows, rows_hi, win, prev, ZH_CHAIN_TILE_HI(k + 4), ZH_CHAIN_TILE_CNT(k + 4), pl);
-            zh_chain_stage(ws, buf ^ 1u, (k + 1) & 3u, f, ZH_CHAIN_TILE_HI(k + 1), ZH_CHAIN_TILE_CNT(k + 1), sb_end, pl);
+            zh_chain_stage(ws, buf ^ 1u, (k + 1) & 3u, f, ZH_CHAIN_TILE_HI(k + 1), ZH_CHAIN_TILE_CNT(k + 1), sb_end, pl, lcw);
          }
       }
       else if (k)
          zh_chain_flush(ws, buf ^ 1u, (k - 1) & 3u, prev, thi + ZH_CHAIN_TILE, ZH_CHAIN_TILE, sb_end, lane, best);
+#ifdef ZH_CHAIN_PROFILE
+      busy += zh_clock() - tp0;
+#endif
       __syncthreads();
    }
+#ifdef ZH_CHAIN_PROFILE
+   if (lane == 0) zh_chain_profile[wave] = busy;
+#endif
    if (wave == 3) {
       const uint32_t k = ntiles - 1;
       zh_chain_flush(ws, k & 1u, k & 3u, prev, ZH_CHAIN_TILE_HI(k), ZH_CHAIN_TILE_CNT(k), sb_end, lane, best);
