@@ -264,6 +264,9 @@ inline uint32_t atomicOr(uint32_t *p, uint32_t v) {
    return o;
 }
 inline uint64_t zh_clock() { return 0; }
+inline void zh_set_wave_priority_high() {}
+inline void zh_set_wave_priority_mid() {}
+inline void zh_set_wave_priority_normal() {}
 inline void __threadfence_block() {}
 inline void __threadfence() {}
 struct uint2 {

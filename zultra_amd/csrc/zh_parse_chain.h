@@ -297,6 +297,12 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
       for (uint32_t k = lane; k < 2u * ZH_CHAIN_TILE * 16u; k += 64) ws.p.desc[k / (ZH_CHAIN_TILE * 16u)][(k / 16u) % ZH_CHAIN_TILE][48u + (k & 15u)] = ZH_CHAIN_NOPRICE;
    }
    __syncthreads();
+   // the recurrence is the critical path of the whole batch: its wave outranks the throughput waves it shares a SIMD with
+   // (zh_parse_tasks of the same pass, the other run's kernels); the producers must keep up with it
+   if (wave == 0)
+      zh_set_wave_priority_high();
+   else
+      zh_set_wave_priority_mid();
 
    zh_chain_state_t st;
    st.cv = 0;   // lane j: cost9[t1 + 2 + j]: beyond the end; lane 0 receives cost9[t1] = 0 when position t1-2 is priced
@@ -338,6 +344,7 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
       const uint32_t k = ntiles - 1;
       zh_chain_flush(ws, k & 1u, k & 3u, prev, ZH_CHAIN_TILE_HI(k), ZH_CHAIN_TILE_CNT(k), sb_end, lane, best);
    }
+   zh_set_wave_priority_normal();
 #undef ZH_CHAIN_TILE_HI
 #undef ZH_CHAIN_TILE_CNT
 }

@@ -122,6 +122,13 @@ __device__ __forceinline__ uint32_t zh_wave_excl_sum(uint32_t v) {
    return x - v;
 }
 
+// issue priority of the calling wave (0..3): the SIMD's arbiter serves the highest priority first, then the oldest wave. A wave that
+// carries a serial dependency chain next to throughput waves of other kernels needs it: at equal priority it gets one issue
+// slot in as many as there are ready waves on its SIMD.
+__device__ __forceinline__ void zh_set_wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
+__device__ __forceinline__ void zh_set_wave_priority_mid() { __builtin_amdgcn_s_setprio(2); }
+__device__ __forceinline__ void zh_set_wave_priority_normal() { __builtin_amdgcn_s_setprio(0); }
+
 // shader-clock stamp for the optional in-kernel phase profile (diagnostics only)
 __device__ __forceinline__ uint64_t zh_clock() { return (uint64_t)clock64(); }
 
