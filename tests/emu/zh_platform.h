@@ -152,6 +152,20 @@ inline uint64_t collect(uint64_t mine, F combine) {
 
 inline void __syncthreads() { zh_emu::park(2); }
 inline void zh_sync() { zh_emu::park(2); }
+inline void zh_sync_lds() { zh_emu::park(2); }
+// caller-tracked global loads (zh_platform.h of the product): here simply loads
+struct uint4;
+struct zh_u32x4_t {
+   uint32_t x, y, z, w;
+};
+struct zh_async_row_t {
+   zh_u32x4_t a, b;
+   uint32_t byte;
+};
+#define ZH_ASYNC_ROW_LOADS 3
+template <int N>
+inline void zh_async_wait() {}
+inline void zh_async_landed(zh_async_row_t &) {}
 inline void zh_wave_sync() {
    zh_emu::collect(0, [] { return (uint64_t)0; });
 }
@@ -275,6 +289,11 @@ struct uint2 {
 struct uint4 {
    uint32_t x, y, z, w;
 };
+inline void zh_async_load_row(zh_async_row_t &r, const uint4 *lo, const uint4 *hi, const uint8_t *byte) {
+   r.a = {lo->x, lo->y, lo->z, lo->w};
+   r.b = {hi->x, hi->y, hi->z, hi->w};
+   r.byte = *byte;
+}
 inline uint32_t zh_load_relaxed(const uint32_t *p) { return *(const volatile uint32_t *)p; }
 inline uint32_t zh_atomic_add_lds(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 inline uint32_t zh_atomic_add_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }

@@ -50,6 +50,20 @@ __global__ void __launch_bounds__(256) k_chain(const uint4 *rows, const uint8_t 
    }
 }
 
+// background load: single-wave workgroups doing what zh_parse_tasks does most (LDS reads, VALU, DPP), 5.7 KB of LDS each
+__global__ void __launch_bounds__(64) k_noise(uint32_t *out, int iters) {
+   __shared__ uint32_t lds[1428];
+   uint32_t v = threadIdx.x + blockIdx.x;
+   for (uint32_t k = threadIdx.x; k < 1428; k += 64) lds[k] = k * 2654435761u;
+   __syncthreads();
+   for (int i = 0; i < iters; i++) {
+      v += lds[(v + i) % 1428u];
+      v = min(v * 3u + 1u, (uint32_t)__builtin_amdgcn_update_dpp(0xffffffff, v, 0xB1, 0xf, 0xf, false));
+      v ^= lds[(v >> 7) % 1428u];
+   }
+   out[blockIdx.x * 64 + threadIdx.x] = v;
+}
+
 int main() {
    uint64_t *d_out;
    hipMalloc(&d_out, 8192 * 16);
@@ -60,7 +74,16 @@ int main() {
    }
    printf("consumer alone: %.1f cycles per position\n", (double)h[0] / (2000.0 * 32));
    const uint32_t n = 65536;
-   for (int wgs : {1, 1024}) {
+   uint32_t *d_noise;
+   hipMalloc(&d_noise, 60000 * 64 * 4);
+   hipStream_t s_noise, s_chain;
+   hipStreamCreateWithFlags(&s_noise, hipStreamNonBlocking);
+   int lo_p = 0, hi_p = 0;
+   hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+   hipStreamCreateWithPriority(&s_chain, hipStreamNonBlocking, hi_p);
+   for (int wgs : {1, -1, 1024}) {
+      const bool noisy = wgs < 0;
+      if (noisy) wgs = 1;
       const size_t tot = (size_t)wgs * n;
       std::vector<uint4> rows(2 * tot);
       std::vector<uint8_t> win(tot);
@@ -91,24 +114,30 @@ int main() {
       hipEventCreate(&e0);
       hipEventCreate(&e1);
       for (int rep = 0; rep < 2; rep++) {
-         hipEventRecord(e0, 0);
-         hipLaunchKernelGGL(k_chain, dim3(wgs), dim3(256), 0, 0, (const uint4 *)d_rows, (const uint8_t *)d_win, n, d_best, d_out);
-         hipEventRecord(e1, 0);
+         hipDeviceSynchronize();
+         if (noisy) hipLaunchKernelGGL(k_noise, dim3(48000), dim3(64), 0, s_noise, d_noise, 20000);
+         hipEventRecord(e0, s_chain);
+         hipLaunchKernelGGL(k_chain, dim3(wgs), dim3(256), 0, s_chain, (const uint4 *)d_rows, (const uint8_t *)d_win, n, d_best, d_out);
+         hipEventRecord(e1, s_chain);
          hipEventSynchronize(e1);
+         hipDeviceSynchronize();
       }
       float ms = 0;
       hipEventElapsedTime(&ms, e0, e1);
       hipMemcpy(o.data(), d_out, o.size() * 8, hipMemcpyDeviceToHost);
-      double sum = 0, mx = 0;
+      double sum = 0, mx = 0, rt = 0;
       for (int w = 0; w < wgs; w++) {
          sum += (double)o[2 * w];
+         rt += (double)o[2 * w + 1];
          mx = mx > (double)o[2 * w] ? mx : (double)o[2 * w];
       }
+      printf("   shader clock while the chains ran: %.2f GHz; a workgroup was inside its chain for %.3f ms on average\n", sum / rt * 0.1, rt / wgs * 1e-5);
       if (wgs == 1) {
          uint64_t prof[4];
          hipMemcpyFromSymbol(prof, HIP_SYMBOL(zh_chain_profile), sizeof(prof));
          printf("   busy cycles per position: consumer %.1f, stagers %.1f / %.1f, flusher %.1f\n", (double)prof[0] / n, (double)prof[1] / n, (double)prof[2] / n, (double)prof[3] / n);
       }
+      if (noisy) printf("   (next line: one chain next to 48000 single-wave workgroups of LDS + VALU work on another stream)\n");
       printf("%4d chain workgroups x %u positions: kernel %.3f ms, %.1f cycles per position (mean), %.1f (slowest), %.3f us per position wall\n", wgs, n, ms,
              sum / wgs / n, mx / n, ms * 1e3 / n);
       hipFree(d_rows);

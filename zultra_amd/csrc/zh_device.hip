@@ -40,6 +40,7 @@ static_assert(sizeof(zultra_hip_subblock_t) == sizeof(zh_subblock_t), "ABI");
 struct zultra_hip_ctx_s {
    int device;
    uint32_t num_cus;            // persistent kernels launch one workgroup per CU
+   uint32_t task_waves;         // persistent zh_parse_tasks waves per CU next to chains (ZULTRA_HIP_TASK_WAVES)
    uint32_t max_block, max_blocks;
    uint64_t W, sort_stride, match_stride, tok_stride, best_stride, slot_stride;
    size_t data_cap;
@@ -74,7 +75,8 @@ struct zultra_hip_ctx_s {
    uint64_t bar_stride, max_tasks;
    zh_sbstate_t *d_states;
    uint2 *d_taskmap;
-   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: per run [0..3] tasks, [4..7] tasks listed for zh_parse_chain, [8..11] their positions, [16 + 4 run + pass] its tickets
+   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: per run [0..3] tasks, [4..7] / [12..15] long / other tasks listed for zh_parse_chain, [8..11] their positions,
+                                                     // [16 + 4 run + pass] its tickets, [32 + 4 run + pass] tickets of a persistent zh_parse_tasks
    uint32_t *h_ntasks;          // pinned mirror, read after the batch (zultra_hip_last_stats)
    uint32_t *d_hugelist;
    hipEvent_t ev2[16];
@@ -372,6 +374,10 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->ev[i]));
    for (int i = 0; i < 16; i++) ZH_CHECK(c, hipEventCreate(&c->ev2[i]));
    {
+      const char *tw = getenv("ZULTRA_HIP_TASK_WAVES");
+      c->task_waves = tw ? (uint32_t)atoi(tw) : 10u;
+      if (c->task_waves < 1) c->task_waves = 1;
+      if (c->task_waves > 32) c->task_waves = 32;
       const char *e = getenv("ZULTRA_HIP_STREAMS");
       c->nlanes = e ? atoi(e) : 2;
       if (c->nlanes < 1) c->nlanes = 1;
@@ -392,8 +398,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_split_cnt, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_sub_base, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_crc, B * sizeof(uint32_t), 0));
-      ZH_CHECK(c, hipHostMalloc((void **)&c->h_ntasks, 16 * sizeof(uint32_t), 0));
-      memset(c->h_ntasks, 0, 16 * sizeof(uint32_t));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_ntasks, 64 * sizeof(uint32_t), 0));
+      memset(c->h_ntasks, 0, 64 * sizeof(uint32_t));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_adler, 2 * B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_results, B * c->max_subs * sizeof(zh_subblock_t), 0));
    }
@@ -401,7 +407,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
-       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, 32) || zh_alloc(c, &c->d_hugelist, c->max_tasks) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, 64) || zh_alloc(c, &c->d_hugelist, c->max_tasks) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) || zh_alloc(c, &c->d_longest, B * c->tok_stride) ||
@@ -605,7 +611,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
              (const uint2 *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
    if (zh_enqueue_tokenize(c, st, blk, 0, nb) != 0) return -1;
    ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 32 * sizeof(uint32_t), st));
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 64 * sizeof(uint32_t), st));
    ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, (size_t)nb * c->slot_stride, st));
    ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)c->d_tok_pos, c->tok_stride, (const uint32_t *)c->d_ntok,
              (const uint32_t *)c->d_split_tok, (const uint32_t *)c->d_split_cnt, (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work, c->d_taskmap,
@@ -613,20 +619,20 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    ZH_LAUNCH(zh_sb_init, nb, 64, st, (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_states);
    const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap,
-             (const uint32_t *)c->d_ntasks, c->d_hugelist, c->d_ntasks + 4, c->d_ntasks + 8);
+             (const uint32_t *)c->d_ntasks, c->d_hugelist, task_grid, c->d_ntasks + 4, c->d_ntasks + 12, c->d_ntasks + 8);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       hipStream_t side = c->side_stream[0];
       ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass], st));
       ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[0][2 * pass], 0));
       ZH_LAUNCH(zh_parse_chain, min(nb, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride,
-                (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_hugelist,
-                (const uint32_t *)(c->d_ntasks + 4), (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride, c->d_hist_part, pass,
-                c->d_ntasks + 16 + pass);
+                (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_hugelist, task_grid,
+                (const uint32_t *)(c->d_ntasks + 4), (const uint32_t *)(c->d_ntasks + 12), (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride,
+                c->d_hist_part, pass, c->d_ntasks + 16 + pass);
       ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass + 1], side));
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride,
                 (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
-                c->best_stride, c->d_hist_part, pass);
+                c->best_stride, c->d_hist_part, pass, (uint32_t *)NULL);
       ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[0][2 * pass + 1], 0));
       ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)c->d_work, c->d_states, (const uint32_t *)c->d_hist_part, c->d_payload, pass);
    }
@@ -787,7 +793,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    // ---- stage 3 of every run: the sub-block coder, one kernel per step over the run (zh_encode.h) -------------------
    uint32_t nsubs = 0;
    uint32_t lane_sub0[4], lane_nsubs[4];
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 32 * sizeof(uint32_t), st0));
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 64 * sizeof(uint32_t), st0));
    ZH_CHECK(c, hipEventRecord(c->ev2[0], st0));
    for (int k = 0; k < lanes; k++) {
       hipStream_t st = c->lane_stream[k];
@@ -830,20 +836,34 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
       ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
       ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)ntasks, hugelist,
-                ntasks + 4, ntasks + 8);
+                task_grid, ntasks + 4, ntasks + 12, ntasks + 8);
+      // Does this run have chains at all? With none (text without long repeats) zh_parse_tasks gets the whole chip; with chains it
+      // runs as a bounded number of persistent waves per CU, so that the chain workgroups find room the moment they are launched.
+      ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks + 48 + 2 * k, ntasks + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks + 49 + 2 * k, ntasks + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipEventRecord(ev[5], st));
+      ZH_CHECK(c, hipEventSynchronize(ev[5]));
+      const uint32_t nchains = c->h_ntasks[48 + 2 * k] + c->h_ntasks[49 + 2 * k];
+      const uint32_t chain_grid = min(nchains, (uint32_t)ZH_CHAIN_GRID);
+      const uint32_t persistent_grid = min(task_grid, c->num_cus * c->task_waves);
       for (int pass = 0; pass <= 3; pass++) {
          // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
          hipStream_t side = c->side_stream[k];
-         ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
-         ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
-         ZH_LAUNCH(zh_parse_chain, ZH_CHAIN_GRID, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                   (const uint2 *)taskmap, (const uint32_t *)hugelist, (const uint32_t *)(ntasks + 4), (const zh_sbstate_t *)states, best, c->best_stride,
-                   hist_part, pass, c->d_ntasks + 16 + 4 * k + pass);
-         ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
-         ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                   (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass);
-         ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
+         if (nchains) {
+            ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
+            ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
+            ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+                      (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, (const uint32_t *)(ntasks + 4), (const uint32_t *)(ntasks + 12),
+                      (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, c->d_ntasks + 16 + 4 * k + pass);
+            ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
+            ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+                      (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
+                      c->d_ntasks + 32 + 4 * k + pass);
+            ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
+         }
+         else
+            ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+                      (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
          ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));
          ZH_LAUNCH(zh_sb_build, ns, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass);
          ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));
@@ -1043,7 +1063,7 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
    out->subblocks = c->nsubs;
    for (int k = 0; k < 4; k++) {
       out->tasks += c->h_ntasks[k];
-      out->huge_tasks += c->h_ntasks[4 + k];
+      out->huge_tasks += c->h_ntasks[4 + k] + c->h_ntasks[12 + k];
       out->huge_positions += c->h_ntasks[8 + k];
    }
    for (uint32_t b = 0; b < c->nblocks; b++) out->positions += c->blocks[b].n;

@@ -241,14 +241,11 @@ __device__ __forceinline__ uint32_t zh_decode_pick(zh_parse_ws_t &ws, uint32_t t
    return len | (e & 0xffff0000u);
 }
 
-__global__ void __launch_bounds__(64)
-zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match,
-               uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
-               const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total, const zh_sbstate_t *__restrict__ states,
-               uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass) {
-   __shared__ zh_parse_ws_t ws;
-   const uint32_t gt = blockIdx.x;
-   if (gt >= *ntasks_total) return;
+// one task, by one wave (the calling workgroup); ws = its LDS workspace
+__device__ inline void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
+                                         const zh_match_t *__restrict__ match, uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride,
+                                         const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
+                                         uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass) {
    const uint2 tm = taskmap[gt];
    const zh_work_t wk = work[tm.x];
    const zh_sbstate_t *st = states + tm.x;
@@ -393,5 +390,31 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       zh_walk_histogram_wave(ws.hist, win, prev, t0, t1, best);
       uint32_t *hp = hist_part + (uint64_t)gt * ZH_NSYM;
       for (uint32_t k = lane; k < ZH_NSYM; k += 64) hp[k] = ws.hist[k];
+   }
+}
+
+// ticket == NULL: one workgroup (= one wave) per task, the grid covers the task list. Otherwise the workgroups are persistent and
+// take tasks from *ticket: the host launches a BOUNDED number of them per CU when the pass also has chains (zh_parse_chain.h) —
+// a grid of tens of thousands of single-wave workgroups keeps every wave slot, register and LDS granule of the chip taken, and
+// the four-wave workgroup that carries the longest chain of the batch would wait for room until the grid has drained
+// (measured, tools/probes/chain2_probe.hip: a 3.6 ms chain next to such a grid ended after 25 ms).
+__global__ void __launch_bounds__(64)
+zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match,
+               uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
+               const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total, const zh_sbstate_t *__restrict__ states,
+               uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket) {
+   __shared__ zh_parse_ws_t ws;
+   const uint32_t ntasks = *ntasks_total;
+   if (!ticket) {
+      if (blockIdx.x < ntasks) zh_parse_one_task(ws, blockIdx.x, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass);
+      return;
+   }
+   for (;;) {
+      uint32_t gt = 0;
+      if (zh_lane() == 0) gt = atomicAdd(ticket, 1u);
+      gt = zh_readfirstlane(gt);
+      if (gt >= ntasks) return;
+      zh_sync();   // the previous task is done with the workspace
+      zh_parse_one_task(ws, gt, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass);
    }
 }

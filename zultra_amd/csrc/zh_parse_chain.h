@@ -36,6 +36,7 @@
 #define ZH_CHAIN_NOPRICE (4095u << 9)
 #define ZH_CHAIN_LONG0 40u           // consumer lane of long slot 0
 #define ZH_CHAIN_REBASE (1u << 30)
+#define ZH_CHAIN_LONG_TASK 8192u   // positions: a listed task longer than this gets one of the first tickets
 
 #ifdef ZH_CHAIN_PROFILE
 __device__ uint64_t zh_chain_profile[4];   // probe builds only (tools/probes/chain2_probe.hip): busy cycles per role of the last chain
@@ -59,22 +60,14 @@ struct zh_chain_ws_t {
    uint8_t distcost[ZH_NDIST];
 };
 
-// what a producer thread loads from HBM for one position (issued a whole tile period before it is digested)
-struct zh_chain_fetch_t {
-   uint4 a, b;
-   uint32_t byte;
-};
-
-// producer thread pl = 4 j + part: position thi-1-j of the tile [thi - cnt, thi)
-__device__ __forceinline__ void zh_chain_fetch(zh_chain_fetch_t &f, const uint4 *rows, const uint4 *rows_hi, const uint8_t *win, uint32_t prev, uint32_t thi,
+// producer thread pl = 4 j + part: requests the row of position thi-1-j of the tile [thi - cnt, thi) — both planes
+// unconditionally (the second one holds stale bytes unless slot 3 is a match: zh_chain_stage masks it) and the byte at the
+// position. The loads stay in flight for three tile periods (zh_async_load_row: completion tracked by the caller).
+__device__ __forceinline__ void zh_chain_fetch(zh_async_row_t &f, const uint4 *rows, const uint4 *rows_hi, const uint8_t *win, uint32_t prev, uint32_t thi,
                                                uint32_t cnt, uint32_t pl) {
    const uint32_t j = pl >> 2;
    const uint32_t pos = j < cnt ? thi - 1 - j : thi - 1;   // clamped: the loads are always legal
-   // both planes unconditionally (a load that waited for the first plane would put a memory round trip into the tile period);
-   // the second one holds stale bytes unless slot 3 is a match: zh_chain_stage masks it
-   f.a = rows[pos - prev];
-   f.b = rows_hi[pos - prev];
-   f.byte = win[pos];
+   zh_async_load_row(f, rows + (pos - prev), rows_hi + (pos - prev), win + pos);
 }
 
 // producer: stage tile [thi - cnt, thi) into parity `buf`. Thread pl = 4 j + part serves position thi-1-j:
@@ -83,7 +76,7 @@ __device__ __forceinline__ void zh_chain_fetch(zh_chain_fetch_t &f, const uint4 
 //   part 3: the literal's price and the raw row for the flusher
 // lcw = the 16 length prices of the thread's part (lencost[16 part ..], four per word), loaded once per chain: a byte read
 // from LDS per descriptor, each waited for, was most of this function's time.
-__device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, uint32_t rbuf, const zh_chain_fetch_t &f, uint32_t thi, uint32_t cnt, uint32_t sb_end,
+__device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, uint32_t rbuf, const zh_async_row_t &f, uint32_t thi, uint32_t cnt, uint32_t sb_end,
                                                uint32_t pl, const uint32_t (&lcw)[4]) {
    const uint32_t j = pl >> 2, part = pl & 3u;
    uint32_t *d = &ws.p.desc[buf][j][16u * part];
@@ -275,18 +268,29 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
 #pragma unroll
       for (uint32_t q = 0; q < 4; q++) lcw[q] = *(const uint32_t *)&ws.lencost[16u * (pl & 3u) + 4u * q];
    }
-   zh_chain_fetch_t fq[3];
-#pragma unroll
-   for (uint32_t q = 0; q < 3; q++) fq[q].a.x = fq[q].a.y = fq[q].a.z = fq[q].a.w = fq[q].b.x = fq[q].b.y = fq[q].b.z = fq[q].b.w = fq[q].byte = 0;
+   zh_async_row_t fr[3];   // slot t % 3: the rows of tile t
+   // wait until at most y_ row requests (of ZH_ASYNC_ROW_LOADS loads each) are still in flight
+#define ZH_CHAIN_AWAIT(y_)                                                \
+   do {                                                                   \
+      const uint32_t y__ = (y_);                                          \
+      if (y__ >= 3u)                                                      \
+         zh_async_wait<3 * ZH_ASYNC_ROW_LOADS>();                         \
+      else if (y__ == 2u)                                                 \
+         zh_async_wait<2 * ZH_ASYNC_ROW_LOADS>();                         \
+      else if (y__ == 1u)                                                 \
+         zh_async_wait<1 * ZH_ASYNC_ROW_LOADS>();                         \
+      else                                                                \
+         zh_async_wait<0>();                                              \
+   } while (0)
 #define ZH_CHAIN_TILE_HI(k_) (t1 - (k_) * ZH_CHAIN_TILE)
 #define ZH_CHAIN_TILE_CNT(k_) min(ZH_CHAIN_TILE, ZH_CHAIN_TILE_HI(k_) - t0)
    if (stager) {
-      zh_chain_fetch_t f0;
-      zh_chain_fetch(f0, rows, rows_hi, win, prev, t1, ZH_CHAIN_TILE_CNT(0u), pl);
 #pragma unroll
       for (uint32_t q = 0; q < 3; q++)
-         if (q + 1 < ntiles) zh_chain_fetch(fq[q], rows, rows_hi, win, prev, ZH_CHAIN_TILE_HI(q + 1), ZH_CHAIN_TILE_CNT(q + 1), pl);
-      zh_chain_stage(ws, 0, 0, f0, t1, ZH_CHAIN_TILE_CNT(0u), sb_end, pl, lcw);
+         if (q < ntiles) zh_chain_fetch(fr[q], rows, rows_hi, win, prev, ZH_CHAIN_TILE_HI(q), ZH_CHAIN_TILE_CNT(q), pl);
+      ZH_CHAIN_AWAIT(min(ntiles, 3u) - 1u);   // tile 0 has landed; up to two younger requests stay in flight
+      zh_async_landed(fr[0]);
+      zh_chain_stage(ws, 0, 0, fr[0], t1, ZH_CHAIN_TILE_CNT(0u), sb_end, pl, lcw);
    }
    else if (wave == 0) {
       // cost[t1] = 0; entries above it are never asked for (t1 is a barrier or the end: no candidate reaches past it)
@@ -304,47 +308,67 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
    else
       zh_set_wave_priority_mid();
 
-   zh_chain_state_t st;
-   st.cv = 0;   // lane j: cost9[t1 + 2 + j]: beyond the end; lane 0 receives cost9[t1] = 0 when position t1-2 is priced
-   st.c1 = 0;   // cost9[t1]
-   st.c2 = 0;
 #ifdef ZH_CHAIN_PROFILE
-   uint64_t busy = 0;
+   uint64_t busy = 0, tic = 0;
+#define ZH_CHAIN_TIC() tic = zh_clock()
+#define ZH_CHAIN_TOC() busy += zh_clock() - tic
+#else
+#define ZH_CHAIN_TIC()
+#define ZH_CHAIN_TOC()
 #endif
-   for (uint32_t k = 0; k < ntiles; k++) {
-      const uint32_t thi = ZH_CHAIN_TILE_HI(k);
-      const uint32_t buf = k & 1u;
-#ifdef ZH_CHAIN_PROFILE
-      const uint64_t tp0 = zh_clock();
-#endif
-      if (wave == 0) {
+   // One loop per role, one workgroup barrier per tile period in each (every wave meets the same number of barriers).
+   if (wave == 0) {
+      zh_chain_state_t st;
+      st.cv = 0;   // lane j: cost9[t1 + 2 + j]: beyond the end; lane 0 receives cost9[t1] = 0 when position t1-2 is priced
+      st.c1 = 0;   // cost9[t1]
+      st.c2 = 0;
+      for (uint32_t k = 0; k < ntiles; k++) {
+         ZH_CHAIN_TIC();
          if (st.c1 >= ZH_CHAIN_REBASE) zh_chain_rebase(ws, st);
-         zh_chain_consume(ws, buf, thi, st);
+         zh_chain_consume(ws, k & 1u, ZH_CHAIN_TILE_HI(k), st);
+         ZH_CHAIN_TOC();
+         zh_sync_lds();
       }
-      else if (stager) {
-         if (k + 1 < ntiles) {
-            const zh_chain_fetch_t f = fq[0];
-            fq[0] = fq[1];
-            fq[1] = fq[2];
-            if (k + 4 < ntiles) zh_chain_fetch(fq[2], rows, rows_hi, win, prev, ZH_CHAIN_TILE_HI(k + 4), ZH_CHAIN_TILE_CNT(k + 4), pl);
-            zh_chain_stage(ws, buf ^ 1u, (k + 1) & 3u, f, ZH_CHAIN_TILE_HI(k + 1), ZH_CHAIN_TILE_CNT(k + 1), sb_end, pl, lcw);
+   }
+   else if (stager) {
+      // period k: the rows of tile k+3 are requested into the slot tile k occupied, then tile k+1 (requested two periods ago)
+      // is staged. The slots are addressed statically (three periods per loop iteration): rotating them through register copies
+      // would make every period wait for ALL outstanding loads, the youngest included.
+      for (uint32_t k3 = 0; k3 < ntiles; k3 += 3) {
+#pragma unroll
+         for (uint32_t q = 0; q < 3; q++) {
+            const uint32_t k = k3 + q;
+            if (k < ntiles) {
+               ZH_CHAIN_TIC();
+               if (k + 3 < ntiles) zh_chain_fetch(fr[q], rows, rows_hi, win, prev, ZH_CHAIN_TILE_HI(k + 3), ZH_CHAIN_TILE_CNT(k + 3), pl);
+               if (k + 1 < ntiles) {
+                  ZH_CHAIN_AWAIT(min(ntiles - 1u, k + 3u) - (k + 1u));   // requests younger than tile k+1's: tiles k+2 .. min(k+3, last)
+                  zh_async_landed(fr[(q + 1) % 3u]);
+                  zh_chain_stage(ws, (k + 1) & 1u, (k + 1) & 3u, fr[(q + 1) % 3u], ZH_CHAIN_TILE_HI(k + 1), ZH_CHAIN_TILE_CNT(k + 1), sb_end, pl, lcw);
+               }
+               ZH_CHAIN_TOC();
+               zh_sync_lds();
+            }
          }
       }
-      else if (k)
-         zh_chain_flush(ws, buf ^ 1u, (k - 1) & 3u, prev, thi + ZH_CHAIN_TILE, ZH_CHAIN_TILE, sb_end, lane, best);
-#ifdef ZH_CHAIN_PROFILE
-      busy += zh_clock() - tp0;
-#endif
-      __syncthreads();
+   }
+   else {
+      for (uint32_t k = 0; k < ntiles; k++) {
+         ZH_CHAIN_TIC();
+         if (k) zh_chain_flush(ws, (k - 1) & 1u, (k - 1) & 3u, prev, ZH_CHAIN_TILE_HI(k - 1), ZH_CHAIN_TILE, sb_end, lane, best);
+         ZH_CHAIN_TOC();
+         zh_sync_lds();
+      }
+      const uint32_t k = ntiles - 1;
+      zh_chain_flush(ws, k & 1u, k & 3u, prev, ZH_CHAIN_TILE_HI(k), ZH_CHAIN_TILE_CNT(k), sb_end, lane, best);
    }
 #ifdef ZH_CHAIN_PROFILE
    if (lane == 0) zh_chain_profile[wave] = busy;
 #endif
-   if (wave == 3) {
-      const uint32_t k = ntiles - 1;
-      zh_chain_flush(ws, k & 1u, k & 3u, prev, ZH_CHAIN_TILE_HI(k), ZH_CHAIN_TILE_CNT(k), sb_end, lane, best);
-   }
+#undef ZH_CHAIN_TIC
+#undef ZH_CHAIN_TOC
    zh_set_wave_priority_normal();
+#undef ZH_CHAIN_AWAIT
 #undef ZH_CHAIN_TILE_HI
 #undef ZH_CHAIN_TILE_CNT
 }
@@ -352,7 +376,7 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
 // the tasks zh_parse_tasks leaves alone: one wave per task, the same piece computation
 __global__ void __launch_bounds__(64)
 zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
-             const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total, uint32_t *hugelist, uint32_t *nhuge,
+             const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total, uint32_t *hugelist, uint32_t cap, uint32_t *nlong, uint32_t *nshort,
              uint32_t *huge_positions) {
    __shared__ uint32_t bnd[ZH_MAXPIECES + 1];
    const uint32_t gt = blockIdx.x;
@@ -367,7 +391,12 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
    const uint32_t np = zh_task_pieces(bnd, bar, prev, t0, t1, lane);
    zh_sync();
    if (zh_task_is_huge(bnd, np, lane) && lane == 0) {
-      hugelist[atomicAdd(nhuge, 1u)] = gt;
+      // the list is filled from both ends: the long chains — what the pass will wait for — from the front, so that they get
+      // the first tickets of zh_parse_chain
+      if (t1 - t0 > ZH_CHAIN_LONG_TASK)
+         hugelist[atomicAdd(nlong, 1u)] = gt;
+      else
+         hugelist[cap - 1u - atomicAdd(nshort, 1u)] = gt;
       atomicAdd(huge_positions, t1 - t0);   // statistics only (zultra_hip_last_stats)
    }
 }
@@ -378,19 +407,19 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
 __global__ void __launch_bounds__(ZH_CHAIN_THREADS)
 zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
-               const uint32_t *__restrict__ hugelist, const uint32_t *__restrict__ nhuge, const zh_sbstate_t *__restrict__ states, uint32_t *best_all,
-               uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket) {
+               const uint32_t *__restrict__ hugelist, uint32_t cap, const uint32_t *__restrict__ nlong_p, const uint32_t *__restrict__ nshort_p,
+               const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket) {
    __shared__ zh_chain_ws_t ws;
    __shared__ uint32_t s_item;
    const uint32_t tid = threadIdx.x, wave = tid >> 6;
-   const uint32_t count = *nhuge;
+   const uint32_t nlong = *nlong_p, count = nlong + *nshort_p;
    for (;;) {
       __syncthreads();   // the previous task's histogram has left LDS, s_item has been read
       if (tid == 0) s_item = atomicAdd(ticket, 1u);
       __syncthreads();
       const uint32_t item = s_item;
       if (item >= count) return;
-      const uint32_t gt = hugelist[item];
+      const uint32_t gt = item < nlong ? hugelist[item] : hugelist[cap - 1u - (item - nlong)];
       const uint2 tm = taskmap[gt];
       const zh_work_t wk = work[tm.x];
       const zh_sbstate_t *st = states + tm.x;

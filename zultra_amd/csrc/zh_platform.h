@@ -134,6 +134,31 @@ __device__ __forceinline__ uint64_t zh_clock() { return (uint64_t)clock64(); }
 
 // LDS visibility between the lanes of a workgroup (a single wave for the 64-thread kernels)
 __device__ __forceinline__ void zh_sync() { __syncthreads(); }
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also drains the wave's outstanding GLOBAL loads
+// (s_waitcnt vmcnt(0) before s_barrier): a wave that keeps row loads in flight across several barriers — the producers of
+// zh_parse_chain.h — would pay a full memory round trip at every one of them.
+__device__ __forceinline__ void zh_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Global loads whose completion the CALLER tracks: issue now, use after zh_async_wait<N>() — N = how many loads issued later
+// may still be in flight (vector-memory operations of a wave complete in order). The compiler's own bookkeeping gives up
+// on loads kept in flight around a loop (it waits for all of them, the youngest included, at the first use of any), which
+// turns a three-tile read-ahead into none. The values must not be touched before the wait.
+typedef uint32_t zh_u32x4_t __attribute__((ext_vector_type(4)));
+struct zh_async_row_t {
+   zh_u32x4_t a, b;   // the two planes of a match row (zh_common.h)
+   uint32_t byte;
+};
+__device__ __forceinline__ void zh_async_load_row(zh_async_row_t &r, const uint4 *lo, const uint4 *hi, const uint8_t *byte) {
+   asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\tglobal_load_ubyte %2, %5, off"
+                : "=&v"(r.a), "=&v"(r.b), "=&v"(r.byte)
+                : "v"(lo), "v"(hi), "v"(byte)
+                : "memory");
+}
+#define ZH_ASYNC_ROW_LOADS 3   // vector-memory operations per zh_async_load_row
+template <int N>
+__device__ __forceinline__ void zh_async_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// after the wait: the registers now hold the loaded values (keeps the compiler from having moved their use above the wait)
+__device__ __forceinline__ void zh_async_landed(zh_async_row_t &r) { asm volatile("" : "+v"(r.a), "+v"(r.b), "+v"(r.byte)::"memory"); }
+
 // LDS visibility between the lanes of ONE wave (wave-private data inside a multi-wave workgroup): LDS operations of a
 // wave execute in order, so draining them and stopping the compiler from moving accesses across is all it takes.
 __device__ __forceinline__ void zh_wave_sync() {
