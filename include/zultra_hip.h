@@ -115,6 +115,11 @@ typedef struct zultra_hip_stats_s {
 } zultra_hip_stats_t;
 void zultra_hip_last_stats(const zultra_hip_ctx_t *ctx, zultra_hip_stats_t *out);
 
+/* Diagnostics: with ZULTRA_HIP_CHAIN_TRACE=1 in the environment when the context is created, the chain kernels record per work
+ * ticket {positions, start, end} on the device's 100 MHz clock; out = uint64[4 runs][4 passes][*slots][3]. Returns 0, or -1 when
+ * tracing is off. */
+int zultra_hip_chain_trace(zultra_hip_ctx_t *ctx, uint64_t *out, uint32_t *slots);
+
 /* Stage outputs of the last batch, for parity tests (copied device -> host on request).
  *   matches: n*8 entries {u16 length, u16 offset} of max-block `block`          (match[], private.h:59-62,97)
  *   splits : absolute window offsets of the sub-block ends, last = prev+n; returns the count (nSplitOffset, libzultra.c:299)

@@ -278,6 +278,7 @@ inline uint32_t atomicOr(uint32_t *p, uint32_t v) {
    return o;
 }
 inline uint64_t zh_clock() { return 0; }
+inline uint64_t zh_wall_clock() { return 0; }
 inline void zh_set_wave_priority_high() {}
 inline void zh_set_wave_priority_mid() {}
 inline void zh_set_wave_priority_normal() {}

@@ -34,6 +34,8 @@
 #include "zh_split.h"
 #include "zh_stitch.h"
 
+#define ZH_TRACE_SLOTS 4096u
+
 static_assert(sizeof(zultra_hip_block_t) == sizeof(zh_block_t), "ABI");
 static_assert(sizeof(zultra_hip_subblock_t) == sizeof(zh_subblock_t), "ABI");
 
@@ -79,6 +81,7 @@ struct zultra_hip_ctx_s {
                                                      // [16 + 4 run + pass] its tickets, [32 + 4 run + pass] tickets of a persistent zh_parse_tasks
    uint32_t *h_ntasks;          // pinned mirror, read after the batch (zultra_hip_last_stats)
    uint32_t *d_hugelist;
+   uint64_t *d_chain_trace;     // diagnostics (ZULTRA_HIP_CHAIN_TRACE=1): [run][pass][ticket] {positions, start, end}
    hipEvent_t ev2[16];
    // sub-batch pipelining: a batch runs as up to ZH_MAX_LANES contiguous runs of max-blocks, each on its own stream
    // "files" mode (zultra_hip_create_files): every max-block is a whole small input (< 8192 bytes, so the splitter can
@@ -323,6 +326,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_taskmap);
    (void)hipFree(c->d_ntasks);
    (void)hipFree(c->d_hugelist);
+   (void)hipFree(c->d_chain_trace);
    (void)hipFree(c->d_hist_part);
    (void)hipFree(c->d_task_bits);
    for (int i = 0; i < 16; i++)
@@ -374,6 +378,10 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->ev[i]));
    for (int i = 0; i < 16; i++) ZH_CHECK(c, hipEventCreate(&c->ev2[i]));
    {
+      if (getenv("ZULTRA_HIP_CHAIN_TRACE") && atoi(getenv("ZULTRA_HIP_CHAIN_TRACE"))) {
+         if (zh_alloc(c, &c->d_chain_trace, (size_t)3 * ZH_TRACE_SLOTS * 16)) return -1;
+         ZH_CHECK(c, hipMemset(c->d_chain_trace, 0, (size_t)3 * ZH_TRACE_SLOTS * 16 * sizeof(uint64_t)));
+      }
       const char *tw = getenv("ZULTRA_HIP_TASK_WAVES");
       c->task_waves = tw ? (uint32_t)atoi(tw) : 10u;
       if (c->task_waves < 1) c->task_waves = 1;
@@ -628,7 +636,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
       ZH_LAUNCH(zh_parse_chain, min(nb, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride,
                 (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_hugelist, task_grid,
                 (const uint32_t *)(c->d_ntasks + 4), (const uint32_t *)(c->d_ntasks + 12), (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride,
-                c->d_hist_part, pass, c->d_ntasks + 16 + pass);
+                c->d_hist_part, pass, c->d_ntasks + 16 + pass, (uint64_t *)NULL);
       ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass + 1], side));
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride,
                 (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
@@ -854,7 +862,8 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
             ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
             ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                       (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, (const uint32_t *)(ntasks + 4), (const uint32_t *)(ntasks + 12),
-                      (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, c->d_ntasks + 16 + 4 * k + pass);
+                      (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, c->d_ntasks + 16 + 4 * k + pass,
+                      c->d_chain_trace ? c->d_chain_trace + 3 * (uint64_t)ZH_TRACE_SLOTS * (4 * k + pass) : (uint64_t *)NULL);
             ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
             ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                       (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
@@ -1054,6 +1063,14 @@ extern "C" int zultra_hip_stream_read(zultra_hip_ctx_t *c, void *out, size_t off
 }
 extern "C" void zultra_hip_last_timing(const zultra_hip_ctx_t *c, zultra_hip_timing_t *t) {
    if (c && t) *t = c->timing;
+}
+
+// diagnostics: the chain kernels' per-ticket records of the last batch (ZULTRA_HIP_CHAIN_TRACE=1), [run 0..3][pass 0..3][ZH_TRACE_SLOTS][3]
+extern "C" int zultra_hip_chain_trace(zultra_hip_ctx_t *c, uint64_t *out, uint32_t *slots) {
+   if (!c || !c->d_chain_trace) return -1;
+   if (slots) *slots = ZH_TRACE_SLOTS;
+   if (out) ZH_CHECK(c, hipMemcpy(out, c->d_chain_trace, (size_t)3 * ZH_TRACE_SLOTS * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+   return 0;
 }
 
 extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stats_t *out) {

@@ -408,7 +408,8 @@ __global__ void __launch_bounds__(ZH_CHAIN_THREADS)
 zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
                const uint32_t *__restrict__ hugelist, uint32_t cap, const uint32_t *__restrict__ nlong_p, const uint32_t *__restrict__ nshort_p,
-               const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket) {
+               const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket,
+               uint64_t *trace /* diagnostics (ZULTRA_HIP_CHAIN_TRACE): per ticket {positions, start, end} on the 100 MHz clock, or NULL */) {
    __shared__ zh_chain_ws_t ws;
    __shared__ uint32_t s_item;
    const uint32_t tid = threadIdx.x, wave = tid >> 6;
@@ -451,7 +452,13 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y, wk.ntasks);
       const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
       __syncthreads();
+      const uint64_t trace_t0 = trace ? zh_wall_clock() : 0;
       zh_chain_parse(ws, rows, rows_hi, win, prev, t0, t1, sb_end, best);
+      if (trace && tid == 0) {
+         trace[3 * (uint64_t)item] = t1 - t0;
+         trace[3 * (uint64_t)item + 1] = trace_t0;
+         trace[3 * (uint64_t)item + 2] = zh_wall_clock();
+      }
 
       // ---- histogram of the task's parse; the per-sub-block sum is taken by zh_sb_build -------------------------------
       if (st->is_dynamic) {

@@ -131,6 +131,8 @@ __device__ __forceinline__ void zh_set_wave_priority_normal() { __builtin_amdgcn
 
 // shader-clock stamp for the optional in-kernel phase profile (diagnostics only)
 __device__ __forceinline__ uint64_t zh_clock() { return (uint64_t)clock64(); }
+// constant-rate (100 MHz) device clock, comparable between workgroups
+__device__ __forceinline__ uint64_t zh_wall_clock() { return (uint64_t)wall_clock64(); }
 
 // LDS visibility between the lanes of a workgroup (a single wave for the 64-thread kernels)
 __device__ __forceinline__ void zh_sync() { __syncthreads(); }
