@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Diagnostics: wave-cycles of zh_mf_frontier by phase, from a profiling build of the library (-DZH_MF_PROFILE, built into build/).
+usage: python tools/mf_profile.py --build            (here, no GPU needed)
+       python tools/mf_profile.py [bytes] [corpus]   (on the GPU box)"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+SO = os.path.join(ROOT, "build", "libzultra_amd_mfprof.so")
+CSRC = os.path.join(ROOT, "zultra_amd", "csrc")
+if "--build" in sys.argv:
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-DZH_MF_PROFILE=1", "-I", CSRC, "-o", SO,
+                    os.path.join(CSRC, "zh_device.hip"), os.path.join(CSRC, "libzultra.cpp")], check=True)
+    sys.exit(0)
+import numpy as np  # noqa: E402
+
+import corpus  # noqa: E402
+from zultra_amd._ffi import Lib  # noqa: E402
+
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+kind = sys.argv[2] if len(sys.argv) > 2 else "pysrc"
+L = Lib(SO)
+d = corpus.real_text(size) if kind == "pysrc" else corpus.text_like_fast(size, 1000) if kind == "text" else corpus.mixed_config4(0, size >> 20)
+size, bs = len(d), 65536
+nb = (size + bs - 1) // bs
+blocks = [(b * bs - (32768 if b else 0), 32768 if b else 0, min(bs, size - b * bs)) for b in range(nb)]
+ctx = L.context(bs, nb)
+ctx.compress_blocks(d, blocks)
+f = L.L.zultra_hip_mf_profile
+f.argtypes = [C.c_void_p, C.c_int]
+f(None, 1)
+ctx.compress_blocks(d, blocks)
+out = np.zeros(8, dtype=np.uint64)
+f(out.ctypes.data, 0)
+t = ctx.timing()
+names = ["window staging", "chunk head", "byte-run path", "class walk", "row store"]
+tot = float(out[:5].sum())
+print("%s %d bytes: frontier %.2f ms (both runs), group %.2f ms" % (kind, size, t["frontier_ms"], t["group_ms"]))
+for i, n in enumerate(names):
+    print("   %-16s %5.1f %%   %.0f wave-cycles per position" % (n, 100.0 * float(out[i]) / tot, float(out[i]) * 64 / size))
+print("   chunks %d, walk iterations per chunk %.1f, lanes alive per iteration %.1f" % (out[6], float(out[5]) / max(1, float(out[6])), float(out[7]) / max(1.0, float(out[5]))))

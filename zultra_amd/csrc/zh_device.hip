@@ -383,7 +383,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
          ZH_CHECK(c, hipMemset(c->d_chain_trace, 0, (size_t)3 * ZH_TRACE_SLOTS * 16 * sizeof(uint64_t)));
       }
       const char *tw = getenv("ZULTRA_HIP_TASK_WAVES");
-      c->task_waves = tw ? (uint32_t)atoi(tw) : 10u;
+      c->task_waves = tw ? (uint32_t)atoi(tw) : 26u;
       if (c->task_waves < 1) c->task_waves = 1;
       if (c->task_waves > 32) c->task_waves = 32;
       const char *e = getenv("ZULTRA_HIP_STREAMS");
@@ -1072,6 +1072,17 @@ extern "C" int zultra_hip_chain_trace(zultra_hip_ctx_t *c, uint64_t *out, uint32
    if (out) ZH_CHECK(c, hipMemcpy(out, c->d_chain_trace, (size_t)3 * ZH_TRACE_SLOTS * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
    return 0;
 }
+
+#ifdef ZH_MF_PROFILE
+extern "C" int zultra_hip_mf_profile(unsigned long long *out, int reset) {
+   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(zh_mf_prof), sizeof(zh_mf_prof)) != hipSuccess) return -1;
+   if (reset) {
+      unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (hipMemcpyToSymbol(HIP_SYMBOL(zh_mf_prof), z, sizeof(z)) != hipSuccess) return -1;
+   }
+   return 0;
+}
+#endif
 
 extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stats_t *out) {
    if (!c || !out) return;

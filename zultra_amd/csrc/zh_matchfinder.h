@@ -435,6 +435,56 @@ __device__ __forceinline__ void zh_load128_at(const uint32_t *w32, uint32_t x, u
 }
 
 
+// match length of the strings at byte offsets q and (the lane's own, its first 16 bytes in own16) over their first 16 bytes: 0..16
+__device__ __forceinline__ uint32_t zh_mf_match16(const uint32_t *lwin32, uint32_t q, const uint32_t (&own16)[4]) {
+   uint32_t c16[4];
+   zh_load128_at(lwin32, q, c16);
+   const uint32_t x0 = c16[0] ^ own16[0], x1 = c16[1] ^ own16[1], x2 = c16[2] ^ own16[2], x3 = c16[3] ^ own16[3];
+   if (x0) return (uint32_t)(__ffs((int)x0) - 1) >> 3;
+   if (x1) return 4u + ((uint32_t)(__ffs((int)x1) - 1) >> 3);
+   if (x2) return 8u + ((uint32_t)(__ffs((int)x2) - 1) >> 3);
+   if (x3) return 12u + ((uint32_t)(__ffs((int)x3) - 1) >> 3);
+   return 16u;
+}
+
+// Matches that run past 16 bytes are finished by the whole wave: for every lane with `need` in turn, lane k compares the four
+// bytes at offset 16 + 4k of the two strings (64 lanes cover 16..271: every length up to 258 in one step), a ballot finds the
+// first difference. A lane stepping through its own long match four bytes at a time kept the other 63 waiting for up to 60
+// rounds — on source code and other repetitive data that was most of the walk. All lanes call; returns l, or the lane's full
+// match length (not yet clamped to maxlen beyond the comparison range) where it had `need`.
+__device__ __forceinline__ uint32_t zh_mf_extend_wave(const uint32_t *lwin32, bool need, uint32_t q, uint32_t i, uint32_t maxlen, uint32_t l) {
+   uint64_t todo = zh_ballot(need);
+   const uint32_t lane = zh_lane();
+   const uint32_t off = 16u + 4u * lane;
+   while (todo) {
+      const int src = zh_ctz64(todo);
+      todo &= todo - 1;
+      const uint32_t qq = zh_readlane(q, src), ii = zh_readlane(i, src), ml = zh_readlane(maxlen, src);
+      const bool beyond = off >= ml;   // (also keeps every read inside the window)
+      uint32_t x = 0;
+      if (!beyond) x = zh_load32_at(lwin32, qq + off) ^ zh_load32_at(lwin32, ii + off);
+      const uint64_t stop = zh_ballot(beyond || x != 0);   // lane 63 compares offset 268: always beyond
+      const int fl = zh_ctz64(stop);
+      const uint32_t xf = zh_readlane(x, fl);
+      const uint32_t len = 16u + 4u * (uint32_t)fl + (xf ? ((uint32_t)(__ffs((int)xf) - 1) >> 3) : 0u);
+      if ((int)lane == src) l = min(len, ml);
+   }
+   return l;
+}
+
+#ifdef ZH_MF_PROFILE
+// probe builds only (tools/mf_profile.py): wave-cycles of zh_mf_frontier by phase — 0 window staging, 1 chunk head (entries, prev
+// records, first records), 2 byte-run path, 3 class walk, 4 row store, 5 walk iterations, 6 chunks, 7 lanes x walk iterations alive
+__device__ unsigned long long zh_mf_prof[8];
+#define ZH_MF_TIC() const uint64_t tic_ = zh_clock()
+#define ZH_MF_TOC(slot_) do { if (lane == 0) atomicAdd(&zh_mf_prof[slot_], (unsigned long long)(zh_clock() - tic_)); } while (0)
+#define ZH_MF_COUNT(slot_, n_) do { if (lane == 0) atomicAdd(&zh_mf_prof[slot_], (unsigned long long)(n_)); } while (0)
+#else
+#define ZH_MF_TIC()
+#define ZH_MF_TOC(slot_)
+#define ZH_MF_COUNT(slot_, n_)
+#endif
+
 template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
 zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs,
@@ -507,8 +557,10 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
    const uint8_t *win = gwin;
 
    if (LDS_WIN) {
+      ZH_MF_TIC();
       zh_stage_window(lwin32, gwin, W);
       win = (const uint8_t *)lwin32;
+      ZH_MF_TOC(0);
    }
    if (threadIdx.x == 0) {
       help_key = 0;
@@ -567,6 +619,13 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       const uint32_t c = ((((ticket >> 6) * 40503u + 12345u) & cmask)) << 6;
       if (c >= M) continue;
 
+      ZH_MF_COUNT(6, 1);
+      uint64_t ptic_ = zh_clock();
+#ifdef ZH_MF_PROFILE
+#define ZH_MF_LAP(slot_) do { const uint64_t now_ = zh_clock(); if (lane == 0) atomicAdd(&zh_mf_prof[slot_], (unsigned long long)(now_ - ptic_)); ptic_ = now_; } while (0)
+#else
+#define ZH_MF_LAP(slot_) (void)ptic_
+#endif
       const uint32_t t = c + lane;
       const uint32_t own = t < M ? S[t] : ZH_MF_SENTINEL;
       const uint32_t i = own & ZH_MF_POS_MASK;
@@ -627,6 +686,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
             alive = !(own & ZH_MF_HEAD);   // a class head has no earlier occurrence of its 6-gram
          }
       }
+      ZH_MF_LAP(1);
       // ---- positions with six or more bytes of a byte run ahead: the frontier comes from the run table -----------------
       if (mine && has4 && isrun) {
          alive = false;
@@ -710,6 +770,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
             }
          }
       }
+      ZH_MF_LAP(2);
       // what a candidate must match to beat `cur`: the four bytes ending at position max(cur, 3) — for cur <= 3 that is
       // a window inside the first six bytes, which every member of the class shares
       uint32_t fo = max(cur, 3u) - 3u;
@@ -720,49 +781,14 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       uint32_t vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_SENTINEL;
       int vi = 63;
 
-      // A candidate can only beat `cur` if its bytes fo..fo+3 equal ci; one LDS byte probe (the last of the four) weeds out
-      // most, the 4-byte probe nearly all of the rest, the survivors get their true match length from byte 0 (an
-      // entry of a neighbouring class met after the class head fails there). Both probes of an
-      // iteration are issued before either is used; a probe taken before `cur` grew stays a valid pre-filter.
-#define ZH_MF_VERIFY(Q, D)                                                                                        \
-      if ((LDS_WIN ? zh_load32_at(lwin32, (Q) + fo) : zh_ld32(win + (Q) + fo)) == ci) {                           \
-         uint32_t l = 0;                                                                                          \
-         if (LDS_WIN) {                                                                                           \
-            /* bytes past the window end are garbage but l is clamped to maxlen */                                 \
-            uint32_t c16_[4];                                                                                     \
-            zh_load128_at(lwin32, (Q), c16_);                                                                     \
-            const uint32_t x0_ = c16_[0] ^ own16[0], x1_ = c16_[1] ^ own16[1], x2_ = c16_[2] ^ own16[2], x3_ = c16_[3] ^ own16[3]; \
-            if (x0_) l = (uint32_t)(__ffs((int)x0_) - 1) >> 3;                                                    \
-            else if (x1_) l = 4u + ((uint32_t)(__ffs((int)x1_) - 1) >> 3);                                        \
-            else if (x2_) l = 8u + ((uint32_t)(__ffs((int)x2_) - 1) >> 3);                                        \
-            else if (x3_) l = 12u + ((uint32_t)(__ffs((int)x3_) - 1) >> 3);                                       \
-            else l = 16;                                                                                          \
-            /* beyond 16: four bytes per probe pair */                                                            \
-            while (l >= 16 && l < maxlen) {                                                                       \
-               const uint32_t x = zh_load32_at(lwin32, (Q) + l) ^ zh_load32_at(lwin32, i + l);                    \
-               if (x) {                                                                                           \
-                  l += (uint32_t)(__ffs((int)x) - 1) >> 3;                                                        \
-                  break;                                                                                          \
-               }                                                                                                  \
-               l += 4;                                                                                            \
-            }                                                                                                     \
-            l = min(l, maxlen);                                                                                   \
-         }                                                                                                        \
-         else {                                                                                                   \
-            while (l < maxlen && win[(Q) + l] == win[i + l]) l++;                                                 \
-         }                                                                                                        \
-         if (l > cur) {                                                                                           \
-            myring[(nm & 7u) * ZH_MF_THREADS] = l | ((D) << 16); /* offset 32768 needs all 16 bits */            \
-            nm++;                                                                                                 \
-            cur = l;                                                                                              \
-            if (cur < maxlen) {                                                                                   \
-               fo = cur - 3;                                                                                      \
-               ci = LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo);                               \
-            }                                                                                                     \
-         }                                                                                                        \
-      }
-
-      while (zh_ballot(alive)) {
+      // A candidate can only beat `cur` if its bytes fo..fo+3 equal ci: the 4-byte probe weeds out nearly all; the survivors get
+      // their true match length from byte 0 (an entry of a neighbouring class met after the class head fails there) — the
+      // first 16 bytes per lane against the lane's own 16 in registers, anything longer by the whole wave at once
+      // (zh_mf_extend_wave). Both probes of an iteration are issued before either is used; a probe taken before `cur` grew
+      // stays a valid pre-filter.
+      while (const uint64_t alive_mask_ = zh_ballot(alive)) {
+         ZH_MF_COUNT(5, 1);
+         ZH_MF_COUNT(7, zh_popc64(alive_mask_));
          // advance twice: entries c+l-1-2k and c+l-2-2k arrive at lane l; lane 0 takes the next entries below the chunk
          const uint32_t c1 = zh_wave_shr1(cand, zh_readlane(vec, vi));
          const uint32_t c2 = zh_wave_shr1(c1, zh_readlane(vec, vi - 1));
@@ -773,23 +799,45 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
             vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_SENTINEL;
             vi = 63;
          }
-         if (alive) {
-            const uint32_t q1 = c1 & ZH_MF_POS_MASK, q2 = c2 & ZH_MF_POS_MASK;
-            const uint32_t d1 = i - q1, d2 = i - q2;
-            const bool ok1 = d1 <= ZH_MAX_DIST, ok2 = d2 <= ZH_MAX_DIST;     // false for the sentinel too
-            // both 4-byte probes are issued before either is used (an out-of-reach candidate probes the lane's own position);
-            // nearly every candidate dies here, so the divergent verification below runs for few lanes and few iterations
-            const uint32_t a1 = (ok1 ? q1 : i) + fo, a2 = (ok2 ? q2 : i) + fo;
-            const uint32_t pb1 = LDS_WIN ? zh_load32_at(lwin32, a1) : zh_ld32(win + a1);
-            const uint32_t pb2 = LDS_WIN ? zh_load32_at(lwin32, a2) : zh_ld32(win + a2);
-            const uint32_t tgt = ci;
-            if (ok1 && pb1 == tgt) { ZH_MF_VERIFY(q1, d1) }
-            if (ok2 && pb2 == tgt && cur < maxlen) { ZH_MF_VERIFY(q2, d2) }
-            // the class ends at its head; beyond 32 KiB everything else is farther still; 258 (or the window end) cannot be beaten
-            alive = ok1 && ok2 && !((c1 | c2) & ZH_MF_HEAD) && cur < maxlen;
+         const uint32_t q1 = c1 & ZH_MF_POS_MASK, q2 = c2 & ZH_MF_POS_MASK;
+         const uint32_t d1 = i - q1, d2 = i - q2;
+         const bool ok1 = alive && d1 <= ZH_MAX_DIST, ok2 = alive && d2 <= ZH_MAX_DIST;     // false for the sentinel too
+         // both 4-byte probes are issued before either is used (an out-of-reach candidate probes the lane's own position);
+         // nearly every candidate dies here, so the verification below runs for few lanes
+         // (lanes that are done probe offset 0: their position may be the sentinel)
+         const uint32_t a1 = ok1 ? q1 + fo : (alive ? i + fo : 0u), a2 = ok2 ? q2 + fo : (alive ? i + fo : 0u);
+         const uint32_t pb1 = LDS_WIN ? zh_load32_at(lwin32, a1) : zh_ld32(win + a1);
+         const uint32_t pb2 = LDS_WIN ? zh_load32_at(lwin32, a2) : zh_ld32(win + a2);
+         const uint32_t tgt = ci;
+#pragma unroll
+         for (int which = 0; which < 2; which++) {
+            const uint32_t q = which ? q2 : q1, dist = which ? d2 : d1;
+            bool v = which ? (ok2 && pb2 == tgt && cur < maxlen) : (ok1 && pb1 == tgt);
+            // (the first record of the iteration may have moved fo: the second candidate is probed again where it counts now)
+            if (which && v) v = (LDS_WIN ? zh_load32_at(lwin32, q + fo) : zh_ld32(win + q + fo)) == ci;
+            uint32_t l = 0;
+            if (LDS_WIN) {
+               if (v) l = zh_mf_match16(lwin32, q, own16);   // bytes past the window end are garbage, but l is clamped to maxlen
+               l = zh_mf_extend_wave(lwin32, v && l == 16 && maxlen > 16, q, i, maxlen, l);
+               l = min(l, maxlen);
+            }
+            else if (v) {
+               while (l < maxlen && win[q + l] == win[i + l]) l++;
+            }
+            if (v && l > cur) {
+               myring[(nm & 7u) * ZH_MF_THREADS] = l | (dist << 16);   // offset 32768 needs all 16 bits
+               nm++;
+               cur = l;
+               if (cur < maxlen) {
+                  fo = cur - 3;
+                  ci = LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo);
+               }
+            }
          }
+         // the class ends at its head; beyond 32 KiB everything else is farther still; 258 (or the window end) cannot be beaten
+         alive = ok1 && ok2 && !((c1 | c2) & ZH_MF_HEAD) && cur < maxlen;
       }
-#undef ZH_MF_VERIFY
+      ZH_MF_LAP(3);
       if (mine) {
          // rows are longest first: the ring read backwards from the last accepted match
          uint32_t m[8];
@@ -802,6 +850,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
          if (nm >= 4) rows_hi[i - prev] = b2;   // readers fetch it whenever slot 3 holds a match
          longest[i - prev] = a.x;
       }
+      ZH_MF_LAP(4);
    }
 
    __syncthreads();   // every wave is done with the window in LDS
