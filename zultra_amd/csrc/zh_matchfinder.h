@@ -84,9 +84,12 @@ __device__ inline void zh_stage_window(uint32_t *lwin32, const uint8_t *gwin, ui
 // NEXT >= 0: count the digits of pass mode NEXT into hist_next the same way (M_next = number of elements this pass writes).
 __device__ __forceinline__ uint32_t zh_mf_slice(uint32_t M) { return (((M + ZH_MF_WAVES - 1) / ZH_MF_WAVES) + 63) & ~63u; }
 
+// MODE 8/9: the elements are indices into the run table (aux_rs = run starts, aux_rl = run lengths): digit = the byte that follows the
+// run (0 where the run reaches the window end) / the run's byte. MODE 8 with src == nullptr reads the identity permutation.
 template <int MODE, bool HAVE = false, int NEXT = -1>
 __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, uint32_t M, const uint32_t *src, uint32_t *dst, uint32_t *hist,
-                                       uint32_t *wave_tot, uint32_t W = 0, uint32_t *hist_next = nullptr, uint32_t M_next = 0) {
+                                       uint32_t *wave_tot, uint32_t W = 0, uint32_t *hist_next = nullptr, uint32_t M_next = 0,
+                                       const uint32_t *aux_rs = nullptr, const uint32_t *aux_rl = nullptr) {
    const uint32_t tid = threadIdx.x;
    const uint32_t lane = tid & 63, wave = tid >> 6;
    const uint32_t seg = zh_mf_slice(M);
@@ -112,6 +115,15 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
       else if (MODE == 1 || MODE == 2) {                                                            \
          e = src[idx];                                                                              \
          d = gwin[e + (MODE == 1 ? 1 : 0)];                                                         \
+      }                                                                                             \
+      else if (MODE == 8) {                                                                         \
+         e = src ? src[idx] : (idx);                                                                \
+         const uint32_t after_ = aux_rs[e] + aux_rl[e];                                             \
+         d = after_ < W ? (uint32_t)gwin[after_] : 0u;                                              \
+      }                                                                                             \
+      else if (MODE == 9) {                                                                         \
+         e = src[idx];                                                                              \
+         d = gwin[aux_rs[e]];                                                                       \
       }                                                                                             \
       else { /* MODE 5/6/7: byte 3/4/5 of the string at e; strings that end before it are dropped */ \
          e = src[idx];                                                                              \
@@ -210,7 +222,8 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
 // min(r, r_p) bytes unless r_p == r — so per earlier run only ONE position can beat the current length. The frontier
 // of such positions is therefore computed from a table of the window's runs (zh_mf_frontier), not from the class scan.
 // Table layout per max-block (u32, Q = W/4 + 1): start[Q] grouped by byte value and ascending within a byte, length[Q]
-// in the same order, then first[256] / end[256] (slice of each byte value) and the run count.
+// in the same order, then first[256] / end[256] (slice of each byte value) and the run count; then the same runs in a second
+// order (zh_mf_build_runs): start | following byte << 24 [Q], length [Q]. 4 Q + 513 words <= the window size + 576.
 #define ZH_RUN_MIN 4
 __device__ __forceinline__ uint32_t zh_runs_q(uint32_t W) { return W / 4 + 1; }
 
@@ -264,6 +277,24 @@ __device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin,
       if (idx + 1 == total || gwin[RS[idx + 1]] != c) end[c] = idx + 1;
    }
    if (tid == 0) *count = total;
+   // The same runs once more, ordered by (byte, byte that follows the run, position): a position with r run bytes left can only
+   // find a match longer than r at the one position of an earlier run that has exactly r bytes left too, and only if that run is
+   // followed by the same byte — the walk over "earlier runs of this byte" then skips every run that ends differently
+   // (indentation in source code: a thousand runs of spaces within reach, a few dozen of them followed by the same letter).
+   // Entry j of this order: RS2[j] = start | following byte << 24, RL2[j] = length.
+   uint32_t *RS2 = count + 1, *RL2 = RS2 + Q;
+   uint32_t *Pa = T + Q, *Pb = T + 2 * Q;
+   __threadfence_block();
+   __syncthreads();
+   zh_mf_sort_pass<8>(win, gwin, total, nullptr, Pa, hist, wave_tot, W, nullptr, 0, RS, RL);
+   zh_mf_sort_pass<9>(win, gwin, total, Pa, Pb, hist, wave_tot, W, nullptr, 0, RS, RL);
+   for (uint32_t idx = tid; idx < total; idx += ZH_MF_THREADS) {
+      const uint32_t e = Pb[idx];
+      const uint32_t st = RS[e], ln = RL[e];
+      const uint32_t x = st + ln < W ? (uint32_t)gwin[st + ln] : 0u;
+      RS2[idx] = st | (x << 24);
+      RL2[idx] = ln;
+   }
 }
 
 // X = the K-gram order (MK entries, K = 4 or 5): prev[pos].y half K-4 = distance - 1 to the nearest earlier position
@@ -714,8 +745,9 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
             }
             // (2) earlier runs of the same byte, nearest first; inside a run the nearer positions have fewer bytes left.
             //     Four table entries are fetched per round trip.
+            //     Only until the record reaches r: from then on the second order takes over (below).
             uint32_t j = a > g0 ? a - 1 : g0;
-            while (j > g0 && cur < maxlen) {
+            while (j > g0 && cur < r) {
                const uint32_t nf = min(4u, j - g0);
                uint32_t es[4], ls[4];
 #pragma unroll
@@ -763,6 +795,67 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
                            myring[(nm & 7u) * ZH_MF_THREADS] = l | ((i - p) << 16);
                            nm++;
                            cur = l;
+                        }
+                     }
+                  }
+               }
+            }
+            // (3) a match longer than r: only the position with exactly r run bytes left of an earlier run (of at least r bytes)
+            //     that is followed by the same byte as this run. Those runs are contiguous in the second order of the table.
+            if (cur >= r && cur < maxlen && a > g0) {
+               const uint32_t *RS2 = runs + 2 * Q + 513, *RL2 = RS2 + Q;
+               const uint32_t X = win[i + r];                              // cur < maxlen: i + r is inside the window
+               const uint32_t key = (X << 24) | RS[a - 1];                 // this position's own run
+               uint32_t lo = g0, hi = g1;
+               while (lo < hi) {
+                  const uint32_t mid = (lo + hi) >> 1;
+                  if (RS2[mid] < key)
+                     lo = mid + 1;
+                  else
+                     hi = mid;
+               }
+               uint32_t j2 = lo;                                           // entries below j2: runs that start earlier (or end in a smaller byte)
+               while (j2 > g0 && cur < maxlen) {
+                  const uint32_t nf = min(4u, j2 - g0);
+                  uint32_t ss[4], ls[4];
+#pragma unroll
+                  for (uint32_t u = 0; u < 4; u++) {
+                     const uint32_t jj = j2 - 1 - min(u, nf - 1);
+                     ss[u] = RS2[jj];
+                     ls[u] = RL2[jj];
+                  }
+                  j2 -= nf;
+#pragma unroll
+                  for (uint32_t u = 0; u < 4; u++) {
+                     if (u >= nf || cur >= maxlen) break;
+                     const uint32_t len = ls[u], e = (ss[u] & 0xffffffu) + len;
+                     if ((ss[u] >> 24) != X || i - (e - ZH_RUN_MIN) > ZH_MAX_DIST) {   // the runs ending in X are used up, or out of reach
+                        j2 = g0;
+                        break;
+                     }
+                     if (len >= r) {
+                        const uint32_t p = e - r;
+                        if (i - p <= ZH_MAX_DIST && win[p + cur] == win[i + cur]) {   // cheap reject: it must agree at byte `cur`
+                           uint32_t l = r;
+                           if (LDS_WIN) {
+                              while (l < maxlen) {
+                                 const uint32_t x = zh_load32_at(lwin32, p + l) ^ zh_load32_at(lwin32, i + l);
+                                 if (x) {
+                                    l += (uint32_t)(__ffs((int)x) - 1) >> 3;
+                                    break;
+                                 }
+                                 l += 4;
+                              }
+                              l = min(l, maxlen);
+                           }
+                           else {
+                              while (l < maxlen && win[p + l] == win[i + l]) l++;
+                           }
+                           if (l > cur) {
+                              myring[(nm & 7u) * ZH_MF_THREADS] = l | ((i - p) << 16);
+                              nm++;
+                              cur = l;
+                           }
                         }
                      }
                   }
