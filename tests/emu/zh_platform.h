@@ -361,6 +361,10 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) {
    *s = nullptr;
    return 0;
 }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *) {
+   *s = nullptr;
+   return 0;
+}
 inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) {
    *lo = 0;
    *hi = 0;

@@ -42,6 +42,7 @@ static_assert(sizeof(zultra_hip_subblock_t) == sizeof(zh_subblock_t), "ABI");
 struct zultra_hip_ctx_s {
    int device;
    uint32_t num_cus;            // persistent kernels launch one workgroup per CU
+   uint32_t total_cus, chain_cus;   // CUs of the device / kept free of the main streams' kernels (ZULTRA_HIP_CHAIN_CUS)
    uint32_t task_waves;         // persistent zh_parse_tasks waves per CU next to chains (ZULTRA_HIP_TASK_WAVES)
    uint32_t max_block, max_blocks;
    uint64_t W, sort_stride, match_stride, tok_stride, best_stride, slot_stride;
@@ -77,7 +78,7 @@ struct zultra_hip_ctx_s {
    uint64_t bar_stride, max_tasks;
    zh_sbstate_t *d_states;
    uint2 *d_taskmap;
-   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: per run [0..3] tasks, [4..7] / [12..15] long / other tasks listed for zh_parse_chain, [8..11] their positions,
+   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: per run [0..3] tasks, [40..43] / [4..7] / [12..15] very long / long / other tasks listed for zh_parse_chain, [8..11] their positions,
                                                      // [16 + 4 run + pass] its tickets, [32 + 4 run + pass] tickets of a persistent zh_parse_tasks
    uint32_t *h_ntasks;          // pinned mirror, read after the batch (zultra_hip_last_stats)
    uint32_t *d_hugelist;
@@ -369,7 +370,11 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    {
       int n = 0;
       if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || n <= 0) n = 256;
-      c->num_cus = (uint32_t)n;
+      c->total_cus = (uint32_t)n;
+      const char *cc = getenv("ZULTRA_HIP_CHAIN_CUS");
+      c->chain_cus = cc ? (uint32_t)atoi(cc) : 16u;
+      if (c->chain_cus * 4 > c->total_cus) c->chain_cus = c->total_cus / 4;   // (a small device: never more than a quarter)
+      c->num_cus = c->total_cus - c->chain_cus;   // what the main streams' persistent kernels may fill
       // the matchfinder kernels take all their LDS dynamically (zh_matchfinder.h): more than the 64 KiB default limit
       ZH_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&zh_mf_group<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ZH_MF_GROUP_LDS));
       ZH_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&zh_mf_frontier<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ZH_MF_FRONTIER_LDS));
@@ -391,7 +396,19 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       if (c->nlanes < 1) c->nlanes = 1;
       if (c->nlanes > 4) c->nlanes = 4;
       for (int k = 0; k < c->nlanes; k++) {
-         ZH_CHECK(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
+         // The run's main stream keeps off the last `chain_cus` CUs: whatever it launches — the matchfinder's one-workgroup-per-CU
+         // kernels, tens of thousands of single-wave task workgroups — those CUs stay free for the kernels of the other streams,
+         // i.e. for the first workgroups of zh_parse_chain (which take the longest chains): a four-wave workgroup otherwise waits
+         // for room until the flood has drained, and the whole pass waits for it.
+         if (c->chain_cus) {
+            uint32_t mask[32];
+            const uint32_t words = (c->total_cus + 31) / 32;
+            for (uint32_t w2 = 0; w2 < words && w2 < 32; w2++) mask[w2] = 0xffffffffu;
+            for (uint32_t b = c->total_cus - c->chain_cus; b < c->total_cus && b < 1024; b++) mask[b / 32] &= ~(1u << (b % 32));
+            ZH_CHECK(c, hipExtStreamCreateWithCUMask(&c->lane_stream[k], words, mask));
+         }
+         else
+            ZH_CHECK(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
          for (int i = 0; i < 24; i++) ZH_CHECK(c, hipEventCreate(&c->lane_ev[k][i]));
          {
             // zh_parse_chain is a few workgroups following long chains: it should never queue behind the wide kernels
@@ -627,7 +644,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    ZH_LAUNCH(zh_sb_init, nb, 64, st, (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_states);
    const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap,
-             (const uint32_t *)c->d_ntasks, c->d_hugelist, task_grid, c->d_ntasks + 4, c->d_ntasks + 12, c->d_ntasks + 8);
+             (const uint32_t *)c->d_ntasks, c->d_hugelist, task_grid, c->d_ntasks + 4, c->d_ntasks + 12, c->d_ntasks + 40, c->d_ntasks + 8);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       hipStream_t side = c->side_stream[0];
@@ -635,7 +652,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
       ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[0][2 * pass], 0));
       ZH_LAUNCH(zh_parse_chain, min(nb, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride,
                 (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_hugelist, task_grid,
-                (const uint32_t *)(c->d_ntasks + 4), (const uint32_t *)(c->d_ntasks + 12), (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride,
+                (const uint32_t *)(c->d_ntasks + 4), (const uint32_t *)(c->d_ntasks + 12), (const uint32_t *)(c->d_ntasks + 40), (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride,
                 c->d_hist_part, pass, c->d_ntasks + 16 + pass, (uint64_t *)NULL);
       ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass + 1], side));
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride,
@@ -653,7 +670,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    ZH_CHECK(c, hipMemcpyAsync(c->h_adler, c->d_adler, 2 * nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
    ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results, nb * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
    ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-   ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks, c->d_ntasks, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+   ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks, c->d_ntasks, 48 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
    return 0;
 }
 
@@ -844,14 +861,15 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
       ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
       ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)ntasks, hugelist,
-                task_grid, ntasks + 4, ntasks + 12, ntasks + 8);
+                task_grid, ntasks + 4, ntasks + 12, ntasks + 40, ntasks + 8);
       // Does this run have chains at all? With none (text without long repeats) zh_parse_tasks gets the whole chip; with chains it
       // runs as a bounded number of persistent waves per CU, so that the chain workgroups find room the moment they are launched.
       ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks + 48 + 2 * k, ntasks + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks + 49 + 2 * k, ntasks + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks + 56 + k, ntasks + 40, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipEventRecord(ev[5], st));
       ZH_CHECK(c, hipEventSynchronize(ev[5]));
-      const uint32_t nchains = c->h_ntasks[48 + 2 * k] + c->h_ntasks[49 + 2 * k];
+      const uint32_t nchains = c->h_ntasks[48 + 2 * k] + c->h_ntasks[49 + 2 * k] + c->h_ntasks[56 + k];
       const uint32_t chain_grid = min(nchains, (uint32_t)ZH_CHAIN_GRID);
       const uint32_t persistent_grid = min(task_grid, c->num_cus * c->task_waves);
       for (int pass = 0; pass <= 3; pass++) {
@@ -862,7 +880,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
             ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
             ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                       (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, (const uint32_t *)(ntasks + 4), (const uint32_t *)(ntasks + 12),
-                      (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, c->d_ntasks + 16 + 4 * k + pass,
+                      (const uint32_t *)(ntasks + 40), (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, c->d_ntasks + 16 + 4 * k + pass,
                       c->d_chain_trace ? c->d_chain_trace + 3 * (uint64_t)ZH_TRACE_SLOTS * (4 * k + pass) : (uint64_t *)NULL);
             ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
             ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
@@ -892,7 +910,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_CHECK(c, hipEventRecord(ev[16], st));
    }
    for (int k = 0; k < lanes; k++) ZH_CHECK(c, hipStreamSynchronize(c->lane_stream[k]));
-   ZH_CHECK(c, hipMemcpy(c->h_ntasks, c->d_ntasks, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+   ZH_CHECK(c, hipMemcpy(c->h_ntasks, c->d_ntasks, 48 * sizeof(uint32_t), hipMemcpyDeviceToHost));
    ZH_CHECK(c, hipGetLastError());
    // sub-block descriptors in batch coordinates
    c->results.assign(c->h_results, c->h_results + nsubs);
@@ -1091,7 +1109,7 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
    out->subblocks = c->nsubs;
    for (int k = 0; k < 4; k++) {
       out->tasks += c->h_ntasks[k];
-      out->huge_tasks += c->h_ntasks[4 + k] + c->h_ntasks[12 + k];
+      out->huge_tasks += c->h_ntasks[4 + k] + c->h_ntasks[12 + k] + c->h_ntasks[40 + k];
       out->huge_positions += c->h_ntasks[8 + k];
    }
    for (uint32_t b = 0; b < c->nblocks; b++) out->positions += c->blocks[b].n;

@@ -36,7 +36,8 @@
 #define ZH_CHAIN_NOPRICE (4095u << 9)
 #define ZH_CHAIN_LONG0 40u           // consumer lane of long slot 0
 #define ZH_CHAIN_REBASE (1u << 30)
-#define ZH_CHAIN_LONG_TASK 8192u   // positions: a listed task longer than this gets one of the first tickets
+#define ZH_CHAIN_VLONG_TASK 24576u  // positions: listed tasks longer than this get the first tickets ...
+#define ZH_CHAIN_LONG_TASK 6144u    // ... those longer than this the next ones
 
 #ifdef ZH_CHAIN_PROFILE
 __device__ uint64_t zh_chain_profile[4];   // probe builds only (tools/probes/chain2_probe.hip): busy cycles per role of the last chain
@@ -377,7 +378,7 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
 __global__ void __launch_bounds__(64)
 zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
              const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total, uint32_t *hugelist, uint32_t cap, uint32_t *nlong, uint32_t *nshort,
-             uint32_t *huge_positions) {
+             uint32_t *nvlong, uint32_t *huge_positions) {
    __shared__ uint32_t bnd[ZH_MAXPIECES + 1];
    const uint32_t gt = blockIdx.x;
    if (gt >= *ntasks_total) return;
@@ -391,10 +392,13 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
    const uint32_t np = zh_task_pieces(bnd, bar, prev, t0, t1, lane);
    zh_sync();
    if (zh_task_is_huge(bnd, np, lane) && lane == 0) {
-      // the list is filled from both ends: the long chains — what the pass will wait for — from the front, so that they get
-      // the first tickets of zh_parse_chain
-      if (t1 - t0 > ZH_CHAIN_LONG_TASK)
-         hugelist[atomicAdd(nlong, 1u)] = gt;
+      // three classes by length, handed out longest class first (zh_chain_ticket): what the pass will wait for are its longest
+      // chains, so they get the first tickets of zh_parse_chain. The very long ones fill the list from the front, the long ones
+      // from its middle, the rest from the back.
+      if (t1 - t0 > ZH_CHAIN_VLONG_TASK)
+         hugelist[atomicAdd(nvlong, 1u)] = gt;
+      else if (t1 - t0 > ZH_CHAIN_LONG_TASK)
+         hugelist[cap / 2u + atomicAdd(nlong, 1u)] = gt;
       else
          hugelist[cap - 1u - atomicAdd(nshort, 1u)] = gt;
       atomicAdd(huge_positions, t1 - t0);   // statistics only (zultra_hip_last_stats)
@@ -408,19 +412,19 @@ __global__ void __launch_bounds__(ZH_CHAIN_THREADS)
 zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
                const uint32_t *__restrict__ hugelist, uint32_t cap, const uint32_t *__restrict__ nlong_p, const uint32_t *__restrict__ nshort_p,
-               const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket,
+               const uint32_t *__restrict__ nvlong_p, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket,
                uint64_t *trace /* diagnostics (ZULTRA_HIP_CHAIN_TRACE): per ticket {positions, start, end} on the 100 MHz clock, or NULL */) {
    __shared__ zh_chain_ws_t ws;
    __shared__ uint32_t s_item;
    const uint32_t tid = threadIdx.x, wave = tid >> 6;
-   const uint32_t nlong = *nlong_p, count = nlong + *nshort_p;
+   const uint32_t nvlong = *nvlong_p, nlong = *nlong_p, count = nvlong + nlong + *nshort_p;
    for (;;) {
       __syncthreads();   // the previous task's histogram has left LDS, s_item has been read
       if (tid == 0) s_item = atomicAdd(ticket, 1u);
       __syncthreads();
       const uint32_t item = s_item;
       if (item >= count) return;
-      const uint32_t gt = item < nlong ? hugelist[item] : hugelist[cap - 1u - (item - nlong)];
+      const uint32_t gt = item < nvlong ? hugelist[item] : (item < nvlong + nlong ? hugelist[cap / 2u + (item - nvlong)] : hugelist[cap - 1u - (item - nvlong - nlong)]);
       const uint2 tm = taskmap[gt];
       const zh_work_t wk = work[tm.x];
       const zh_sbstate_t *st = states + tm.x;
