@@ -242,7 +242,7 @@ __device__ __forceinline__ uint32_t zh_decode_pick(zh_parse_ws_t &ws, uint32_t t
 }
 
 // one task, by one wave (the calling workgroup); ws = its LDS workspace
-__device__ inline void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
+__device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
                                          const zh_match_t *__restrict__ match, uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride,
                                          const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
                                          uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass) {
@@ -405,16 +405,15 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
                uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket) {
    __shared__ zh_parse_ws_t ws;
    const uint32_t ntasks = *ntasks_total;
-   if (!ticket) {
-      if (blockIdx.x < ntasks) zh_parse_one_task(ws, blockIdx.x, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass);
-      return;
-   }
    for (;;) {
-      uint32_t gt = 0;
-      if (zh_lane() == 0) gt = atomicAdd(ticket, 1u);
-      gt = zh_readfirstlane(gt);
+      uint32_t gt = blockIdx.x;
+      if (ticket) {
+         if (zh_lane() == 0) gt = atomicAdd(ticket, 1u);
+         gt = zh_readfirstlane(gt);
+      }
       if (gt >= ntasks) return;
-      zh_sync();   // the previous task is done with the workspace
+      zh_sync();   // (persistent form) the previous task is done with the workspace
       zh_parse_one_task(ws, gt, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass);
+      if (!ticket) return;
    }
 }
