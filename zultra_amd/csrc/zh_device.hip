@@ -788,6 +788,8 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       uint32_t *ctr = c->d_chunk_ctr + (size_t)sg0 * 2 + 2 * (size_t)k;   // this run's counters: 2 per segment + the two tickets
       const uint32_t mf_grid = min(nsg, c->num_cus);                      // persistent workgroups, one per CU (zh_matchfinder.h)
       ZH_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nsg * 2 + 2) * sizeof(uint32_t), st));
+      // token bits are ORed into the payload slots: cleared here, long before stage 3 needs them (the fill runs next to the matchfinder)
+      ZH_CHECK(c, hipMemsetAsync(c->d_payload + (uint64_t)b0 * c->slot_stride, 0, (size_t)nb * c->slot_stride, st));
       ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, rn, c->sort_stride, c->run_stride, mf_stop, nsg,
                 ctr + (size_t)nsg * 2 + 1);
       ZH_CHECK(c, hipEventRecord(ev[2], st));
@@ -855,7 +857,6 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
 
       if (k) ZH_CHECK(c, hipStreamWaitEvent(st, c->ev2[0], 0));         // task counters cleared
       ZH_CHECK(c, hipMemcpyAsync(c->d_sub_base + b0, c->h_sub_base + b0, nb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-      ZH_CHECK(c, hipMemsetAsync(payload, 0, (size_t)nb * c->slot_stride, st));   // token bits are ORed into the slots
       ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), c->tok_stride,
                 (const uint32_t *)(c->d_ntok + b0), (const uint32_t *)(c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1)),
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
