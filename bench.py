@@ -267,7 +267,7 @@ def inflate_check(flags, framed, first_shard, total_in):
     return bool(ok and d.eof and got == total_in)
 
 
-def committed_traffic(kernel):
+def committed_traffic(kernel, config):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json, written by
     tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command), or None."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
@@ -275,6 +275,8 @@ def committed_traffic(kernel):
         return None, None
     with open(files[-1]) as f:
         t = json.load(f)
+    if t.get("config") != config:   # the counters were collected on another workload: no figure for this one
+        return None, None
     k = t.get("kernels", {}).get(kernel) or t.get("kernels", {}).get(kernel.split("+")[0])   # a timed group is priced by its main kernel
     if not k:
         return None, os.path.basename(files[-1])
@@ -375,7 +377,7 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
         avg = {k: float(np.mean([t[k] for t in timings])) for k in timings[0]}
         kernels = {"zh_mf_group": avg["group_ms"], "zh_mf_frontier": avg["frontier_ms"],
                    "zh_barriers+zh_tokenize_spans+zh_split": avg["tokenize_split_ms"], "zh_plan_subblocks+zh_sb_init": avg["init_ms"],
-                   "zh_parse_tasks+zh_parse_huge": avg["parse_ms"], "zh_sb_build": avg["build_ms"], "zh_post_tasks": avg["post_ms"],
+                   "zh_parse_tasks+zh_parse_chain": avg["parse_ms"], "zh_sb_build": avg["build_ms"], "zh_post_tasks": avg["post_ms"],
                    "zh_emit_tasks": avg["emit_ms"], "zh_stitch": avg["stitch_ms"]}
         # the library runs a batch as `runs` staggered runs of max-blocks on separate streams (ZULTRA_HIP_STREAMS, default 2):
         # every kernel is launched once per run (the parse / code-rebuild pair once per pass and run) over 1/runs of the batch
@@ -383,7 +385,7 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
         if nblocks < 4 * runs or n < (runs << 22):
             runs = 1
         launches = {k: runs for k in kernels}
-        launches["zh_parse_tasks+zh_parse_huge"] = launches["zh_sb_build"] = 4 * runs
+        launches["zh_parse_tasks+zh_parse_chain"] = launches["zh_sb_build"] = 4 * runs
         launches["zh_stitch"] = 1
         dom = max(kernels, key=lambda k: kernels[k])
         out_bytes = len(body) / world
@@ -391,7 +393,7 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
         alg_bytes = (n + out_bytes) / (runs if dom != "zh_stitch" else 1)
         launch_ms = kernels[dom] / launches[dom]
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_src = committed_traffic(dom)
+        traffic, traffic_src = committed_traffic(dom, env.get("config"))
         st = res["stats"]
         res.update({
             "body": body, "checksum": chk, "total_in": total_in, "ms_per_step": dt / steps * 1e3,
@@ -401,6 +403,7 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
             "sub_blocks_per_block": round(st["subblocks"] / max(1, st["blocks"]), 3),
             "parse_huge_share_of_positions": round(st["huge_positions"] / max(1, st["positions"]), 4),
             "parse_tasks": st["tasks"], "parse_huge_tasks": st["huge_tasks"],
+            "chain_cut": {"tasks": st["cut_tasks"], "segments": st["cut_segments"], "redone_over_4_passes": st["cut_redone"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(launch_ms, 3),
@@ -411,7 +414,7 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
 
 def summarize_leg(r):
     return {k: r[k] for k in ("ms_per_step", "kernel_ms", "device_pipeline_ms", "d2h_ms", "kernel_only_MBps", "sub_blocks_per_block",
-                              "parse_huge_share_of_positions", "parse_tasks", "parse_huge_tasks")}
+                              "parse_huge_share_of_positions", "parse_tasks", "parse_huge_tasks", "chain_cut")}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -498,7 +501,7 @@ def run_stream_config(args, env, prep):
         if cfg == 2 and not args.no_synthetic:
             # round 1's headline corpus, for continuity: Zipf words without repeated phrases (never splits, never hits the chain parse)
             slead, sshard = SyntheticText().shard(0, size)
-            syn = run_stream_leg(env, slead, sshard, flags, bs, args.steps, args.warmup)
+            syn = run_stream_leg(dict(env, config=None), slead, sshard, flags, bs, args.steps, args.warmup)
             sframed = frame(L, flags, syn["body"].tobytes(), syn["checksum"], syn["total_in"])
             sok = inflate_check(flags, sframed, sshard, syn["total_in"])
             failed |= not sok
@@ -708,7 +711,7 @@ def main():
     L = zultra_amd.lib()   # raises if libzultra_amd.so is missing: there is no fallback path
     if L.device_count() < 1:
         raise RuntimeError("no HIP device")
-    env = {"L": L, "torch": torch, "dist": dist, "device": device, "rank": rank, "local_rank": local_rank, "world": world, "ranks_seen": ranks_seen}
+    env = {"L": L, "torch": torch, "dist": dist, "device": device, "rank": rank, "local_rank": local_rank, "world": world, "ranks_seen": ranks_seen, "config": args.config}
 
     line, failed = {1: run_config1, 5: run_config5}.get(args.config, run_stream_config)(args, env, prep)
     if rank == 0:

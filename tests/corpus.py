@@ -172,6 +172,24 @@ def duplicated(size, seed=1, edit_gap=400):
     return np.concatenate(out)[:size]
 
 
+def table_like(size, seed=1):
+    """Lines of a generated table — a fixed frame around a counter, a code and a few words from a small vocabulary (the codec
+    tables among the bench's Python sources look like this): medium matches overlap without a gap for thousands of positions,
+    but few of them are 258 long. These are the barrier-free runs whose costs forget their start quickly: the speculative
+    segments of the chain parse (zh_parse_chain.h) mostly verify on such data."""
+    rs = np.random.RandomState(seed)
+    words = [w.upper() for w in ("letter", "capital", "small", "with", "sign", "digit", "box", "drawings", "light", "heavy", "double", "vertical",
+                                 "horizontal", "arabic", "greek", "cyrillic", "latin", "acute", "grave", "shade", "block", "quotation", "mark")]
+    out = bytearray()
+    k = int(rs.randint(0, 4096))
+    while len(out) < size:
+        nw = int(rs.randint(2, 6))
+        name = " ".join(words[int(rs.randint(0, len(words)))] for _ in range(nw))
+        out += ("    '\\u%04x'    #  0x%02X -> %s\n" % (0x2500 + (k * 7) % 3000, k & 255, name)).encode()
+        k += 1
+    return np.frombuffer(bytes(out[:size]), dtype=np.uint8).copy()
+
+
 def fibonacci_bytes(k=19, seed=1):
     """Bytes whose counts are the Fibonacci numbers F(1)..F(k), shuffled: the unlimited Huffman tree of such a histogram is
     a chain of depth k-1 (> 15 from k = 17: the cost estimates price code lengths the format cannot even encode). Matches

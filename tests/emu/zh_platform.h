@@ -279,6 +279,7 @@ inline uint32_t atomicOr(uint32_t *p, uint32_t v) {
 }
 inline uint64_t zh_clock() { return 0; }
 inline uint64_t zh_wall_clock() { return 0; }
+inline uint32_t zh_load_agent_u32(const uint32_t *p) { return *p; }
 inline void zh_set_wave_priority_high() {}
 inline void zh_set_wave_priority_mid() {}
 inline void zh_set_wave_priority_normal() {}
@@ -290,6 +291,8 @@ struct uint2 {
 struct uint4 {
    uint32_t x, y, z, w;
 };
+inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 inline void zh_async_load_row(zh_async_row_t &r, const uint4 *lo, const uint4 *hi, const uint8_t *byte) {
    r.a = {lo->x, lo->y, lo->z, lo->w};
    r.b = {hi->x, hi->y, hi->z, hi->w};

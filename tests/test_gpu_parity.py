@@ -52,10 +52,27 @@ def test_wave_primitives_selfcheck(gpu):
     ("deep_huffman", lambda: corpus.fibonacci_bytes(22), 0, 46367, 65536),
     ("near_copies_sparse_edits", lambda: corpus.duplicated(98304, 4, 5000), 32768, 65536, 65536),
     ("near_copies_split", lambda: corpus.duplicated(60000, 5, 700), 10000, 50000, 65536),
+    ("table_cut", lambda: corpus.table_like(98304, 9), 32768, 65536, 65536),
+    ("table_cut_big", lambda: corpus.table_like(300000, 10), 32768, 267232, 1 << 20),
 ], ids=lambda c: c[0])
 def test_stages_vs_oracle(gpu, oracle, case):
     name, gen, prev, n, bs = case
     check_window(gpu, oracle, gen(), prev, n, max_block=bs, tag=name)
+
+
+def test_chain_tasks_are_cut_into_speculative_segments(gpu):
+    """zh_parse_chain.h: barrier-free runs of table-like text are parsed as segments started 1024 positions early; most
+    of the cuts must verify (test_stages_vs_oracle[table_cut*] checks the parse itself against the oracle)."""
+    ctx = gpu.context(65536, 4)
+    try:
+        data = corpus.table_like(4 * 65536, 12)
+        ctx.compress_blocks(data, [(65536 * b, 0, 65536) for b in range(4)])
+        st = ctx.stats()
+    finally:
+        ctx.close()
+    cuts = st["cut_segments"] - st["cut_tasks"]
+    assert st["cut_tasks"] >= 1 and cuts >= 8, st
+    assert st["cut_redone"] < 2 * cuts, st   # of 4 * cuts checks
 
 
 def test_large_max_block_is_cut_into_matchfinder_segments(gpu, oracle):

@@ -21,7 +21,7 @@ L = zultra_amd.lib()
 if kind == "pysrc":
     d = corpus.real_text(size)
 elif kind == "json":
-    d = corpus.json_files(0, size // 4096, 4096)
+    d = np.concatenate([corpus.json_like(1 << 20, 5 + k) for k in range((size + (1 << 20) - 1) >> 20)])[:size]
 else:
     d = corpus.mixed_config4(0, size >> 20)
 size = len(d)
@@ -36,6 +36,7 @@ L.L.zultra_hip_chain_trace(ctx.h, None, C.byref(slots))
 tr = np.zeros((4, 4, slots.value, 3), dtype=np.uint64)
 assert L.L.zultra_hip_chain_trace(ctx.h, tr.ctypes.data, C.byref(slots)) == 0
 print(ctx.timing())
+print(ctx.stats())
 for run in range(2):
     for p in range(4):
         t = tr[run, p]

@@ -46,3 +46,4 @@ print("%s %d bytes, %d max-blocks, %d sub-blocks (%d dynamic)" % (kind, size, nb
 for k, v in t.items():
     print("  %-20s %9.3f ms" % (k, v))
 print("  kernels only: %.1f MB/s" % (size / ((t["matchfinder_ms"] + t["tokenize_split_ms"] + t["encode_ms"]) * 1e-3) / 1e6))
+print("  stats:", ctx.stats())

@@ -34,7 +34,7 @@
 #include "zh_split.h"
 #include "zh_stitch.h"
 
-#define ZH_TRACE_SLOTS 4096u
+#define ZH_NCNT (4u * ZH_CNT_STRIDE)   // device counters: one block of ZH_CNT_* words per run
 
 static_assert(sizeof(zultra_hip_block_t) == sizeof(zh_block_t), "ABI");
 static_assert(sizeof(zultra_hip_subblock_t) == sizeof(zh_subblock_t), "ABI");
@@ -82,6 +82,10 @@ struct zultra_hip_ctx_s {
                                                      // [16 + 4 run + pass] its tickets, [32 + 4 run + pass] tickets of a persistent zh_parse_tasks
    uint32_t *h_ntasks;          // pinned mirror, read after the batch (zultra_hip_last_stats)
    uint32_t *d_hugelist;
+   uint4 *d_segtasks;           // tasks cut into speculative segments (zh_parse_chain.h): per max-block seg_tasks_per_block entries
+   uint2 *d_segitems;           // their segments: per max-block seg_items_per_block entries
+   int16_t *d_vecs;             // two cost vectors per segment
+   uint64_t seg_tasks_per_block, seg_items_per_block;
    uint64_t *d_chain_trace;     // diagnostics (ZULTRA_HIP_CHAIN_TRACE=1): [run][pass][ticket] {positions, start, end}
    hipEvent_t ev2[16];
    // sub-batch pipelining: a batch runs as up to ZH_MAX_LANES contiguous runs of max-blocks, each on its own stream
@@ -327,6 +331,9 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_taskmap);
    (void)hipFree(c->d_ntasks);
    (void)hipFree(c->d_hugelist);
+   (void)hipFree(c->d_segtasks);
+   (void)hipFree(c->d_segitems);
+   (void)hipFree(c->d_vecs);
    (void)hipFree(c->d_chain_trace);
    (void)hipFree(c->d_hist_part);
    (void)hipFree(c->d_task_bits);
@@ -423,16 +430,21 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_split_cnt, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_sub_base, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_crc, B * sizeof(uint32_t), 0));
-      ZH_CHECK(c, hipHostMalloc((void **)&c->h_ntasks, 64 * sizeof(uint32_t), 0));
-      memset(c->h_ntasks, 0, 64 * sizeof(uint32_t));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_ntasks, 2 * ZH_NCNT * sizeof(uint32_t), 0));   // a mirror of d_ntasks + per-run readbacks
+      memset(c->h_ntasks, 0, 2 * ZH_NCNT * sizeof(uint32_t));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_adler, 2 * B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_results, B * c->max_subs * sizeof(zh_subblock_t), 0));
    }
    c->bar_stride = c->tok_stride / 64;
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
+   // a cut task has at least ZH_CUT_MIN positions and lies inside one max-block; its segments have at least ZH_CUT_LEN each
+   c->seg_tasks_per_block = c->files_mode ? 1 : N / ZH_CUT_MIN + 1;
+   c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_LEN + 1;
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
-       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, 64) || zh_alloc(c, &c->d_hugelist, c->max_tasks) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
+       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, c->max_tasks) ||
+       zh_alloc(c, &c->d_segtasks, B * c->seg_tasks_per_block) || zh_alloc(c, &c->d_segitems, B * c->seg_items_per_block) ||
+       zh_alloc(c, &c->d_vecs, B * c->seg_items_per_block * 2 * ZH_VEC) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) || zh_alloc(c, &c->d_longest, B * c->tok_stride) ||
@@ -636,15 +648,16 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
              (const uint2 *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
    if (zh_enqueue_tokenize(c, st, blk, 0, nb) != 0) return -1;
    ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 64 * sizeof(uint32_t), st));
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, ZH_NCNT * sizeof(uint32_t), st));
    ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, (size_t)nb * c->slot_stride, st));
    ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)c->d_tok_pos, c->tok_stride, (const uint32_t *)c->d_ntok,
              (const uint32_t *)c->d_split_tok, (const uint32_t *)c->d_split_cnt, (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work, c->d_taskmap,
              c->d_ntasks);
    ZH_LAUNCH(zh_sb_init, nb, 64, st, (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_states);
    const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
+   // (inputs of a files batch are never cut into speculative segments: seg_min = all ones)
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap,
-             (const uint32_t *)c->d_ntasks, c->d_hugelist, task_grid, c->d_ntasks + 4, c->d_ntasks + 12, c->d_ntasks + 40, c->d_ntasks + 8);
+             (const uint32_t *)c->d_longest, c->tok_stride, c->d_hugelist, task_grid, c->d_segtasks, c->d_segitems, 0xFFFFFFFFu, c->d_ntasks);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       hipStream_t side = c->side_stream[0];
@@ -652,8 +665,8 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
       ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[0][2 * pass], 0));
       ZH_LAUNCH(zh_parse_chain, min(nb, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride,
                 (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_hugelist, task_grid,
-                (const uint32_t *)(c->d_ntasks + 4), (const uint32_t *)(c->d_ntasks + 12), (const uint32_t *)(c->d_ntasks + 40), (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride,
-                c->d_hist_part, pass, c->d_ntasks + 16 + pass, (uint64_t *)NULL);
+                (const uint4 *)c->d_segtasks, (const uint2 *)c->d_segitems, c->d_vecs, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
+                c->best_stride, c->d_hist_part, pass, c->d_ntasks + ZH_CNT_CHAIN_TICKET + pass, (uint64_t *)NULL);
       ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass + 1], side));
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride,
                 (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
@@ -670,7 +683,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    ZH_CHECK(c, hipMemcpyAsync(c->h_adler, c->d_adler, 2 * nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
    ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results, nb * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
    ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-   ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks, c->d_ntasks, 48 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+   ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks, c->d_ntasks, ZH_NCNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
    return 0;
 }
 
@@ -820,7 +833,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    // ---- stage 3 of every run: the sub-block coder, one kernel per step over the run (zh_encode.h) -------------------
    uint32_t nsubs = 0;
    uint32_t lane_sub0[4], lane_nsubs[4];
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, 64 * sizeof(uint32_t), st0));
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, ZH_NCNT * sizeof(uint32_t), st0));
    ZH_CHECK(c, hipEventRecord(c->ev2[0], st0));
    for (int k = 0; k < lanes; k++) {
       hipStream_t st = c->lane_stream[k];
@@ -845,7 +858,11 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       zh_work_t *work = c->d_work + s0;
       zh_sbstate_t *states = c->d_states + s0;
       uint2 *taskmap = c->d_taskmap + t0;
-      uint32_t *ntasks = c->d_ntasks + k;
+      uint32_t *ntasks = c->d_ntasks + (size_t)k * ZH_CNT_STRIDE;   // the run's counters (ZH_CNT_*); [ZH_CNT_TASKS] = its number of tasks
+      uint4 *segtasks = c->d_segtasks + (uint64_t)b0 * c->seg_tasks_per_block;
+      uint2 *segitems = c->d_segitems + (uint64_t)b0 * c->seg_items_per_block;
+      int16_t *vecs = c->d_vecs + (uint64_t)b0 * c->seg_items_per_block * 2 * ZH_VEC;
+      uint32_t *h_cnt = c->h_ntasks + ZH_NCNT + (size_t)k * ZH_CNT_STRIDE;   // read back before the passes are launched
       uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM;
       uint32_t *hugelist = c->d_hugelist + t0;
       uint32_t *task_bits = c->d_task_bits + t0;
@@ -861,16 +878,15 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)(c->d_ntok + b0), (const uint32_t *)(c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1)),
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
       ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
-      ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)ntasks, hugelist,
-                task_grid, ntasks + 4, ntasks + 12, ntasks + 40, ntasks + 8);
+      ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
+                (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, segtasks, segitems, (uint32_t)ZH_CUT_MIN, ntasks);
       // Does this run have chains at all? With none (text without long repeats) zh_parse_tasks gets the whole chip; with chains it
       // runs as a bounded number of persistent waves per CU, so that the chain workgroups find room the moment they are launched.
-      ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks + 48 + 2 * k, ntasks + 4, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks + 49 + 2 * k, ntasks + 12, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks + 56 + k, ntasks + 40, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipMemcpyAsync(h_cnt, ntasks, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipEventRecord(ev[5], st));
       ZH_CHECK(c, hipEventSynchronize(ev[5]));
-      const uint32_t nchains = c->h_ntasks[48 + 2 * k] + c->h_ntasks[49 + 2 * k] + c->h_ntasks[56 + k];
+      const uint32_t nsegtasks = h_cnt[ZH_CNT_SEGTASKS];
+      const uint32_t nchains = h_cnt[ZH_CNT_VLONG] + h_cnt[ZH_CNT_LONG] + h_cnt[ZH_CNT_SHORT] + h_cnt[ZH_CNT_SEGITEMS];
       const uint32_t chain_grid = min(nchains, (uint32_t)ZH_CHAIN_GRID);
       const uint32_t persistent_grid = min(task_grid, c->num_cus * c->task_waves);
       for (int pass = 0; pass <= 3; pass++) {
@@ -880,13 +896,18 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
             ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
             ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
             ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                      (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, (const uint32_t *)(ntasks + 4), (const uint32_t *)(ntasks + 12),
-                      (const uint32_t *)(ntasks + 40), (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, c->d_ntasks + 16 + 4 * k + pass,
+                      (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, (const uint4 *)segtasks, (const uint2 *)segitems, vecs, (const uint32_t *)ntasks,
+                      (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, ntasks + ZH_CNT_CHAIN_TICKET + pass,
                       c->d_chain_trace ? c->d_chain_trace + 3 * (uint64_t)ZH_TRACE_SLOTS * (4 * k + pass) : (uint64_t *)NULL);
+            // the cut tasks: accept or redo their segments, then their histograms (zh_parse_chain.h)
+            if (nsegtasks)
+               ZH_LAUNCH(zh_parse_chain_fix, min(nsegtasks, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride,
+                         (const zh_work_t *)work, (const uint2 *)taskmap, (const uint4 *)segtasks, vecs, ntasks, (const zh_sbstate_t *)states, best, c->best_stride,
+                         hist_part, pass, ntasks + ZH_CNT_FIX_TICKET + pass);
             ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
             ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                       (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
-                      c->d_ntasks + 32 + 4 * k + pass);
+                      ntasks + ZH_CNT_TASK_TICKET + pass);
             ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
          }
          else
@@ -911,7 +932,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_CHECK(c, hipEventRecord(ev[16], st));
    }
    for (int k = 0; k < lanes; k++) ZH_CHECK(c, hipStreamSynchronize(c->lane_stream[k]));
-   ZH_CHECK(c, hipMemcpy(c->h_ntasks, c->d_ntasks, 48 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+   ZH_CHECK(c, hipMemcpy(c->h_ntasks, c->d_ntasks, ZH_NCNT * sizeof(uint32_t), hipMemcpyDeviceToHost));
    ZH_CHECK(c, hipGetLastError());
    // sub-block descriptors in batch coordinates
    c->results.assign(c->h_results, c->h_results + nsubs);
@@ -1109,9 +1130,13 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
    out->blocks = c->nblocks;
    out->subblocks = c->nsubs;
    for (int k = 0; k < 4; k++) {
-      out->tasks += c->h_ntasks[k];
-      out->huge_tasks += c->h_ntasks[4 + k] + c->h_ntasks[12 + k] + c->h_ntasks[40 + k];
-      out->huge_positions += c->h_ntasks[8 + k];
+      const uint32_t *cnt = c->h_ntasks + (size_t)k * ZH_CNT_STRIDE;
+      out->tasks += cnt[ZH_CNT_TASKS];
+      out->huge_tasks += cnt[ZH_CNT_VLONG] + cnt[ZH_CNT_LONG] + cnt[ZH_CNT_SHORT] + cnt[ZH_CNT_SEGTASKS];
+      out->huge_positions += cnt[ZH_CNT_HUGE_POS];
+      out->cut_tasks += cnt[ZH_CNT_SEGTASKS];
+      out->cut_segments += cnt[ZH_CNT_SEGITEMS];
+      out->cut_redone += cnt[ZH_CNT_SEG_FAILED];   // over the four passes
    }
    for (uint32_t b = 0; b < c->nblocks; b++) out->positions += c->blocks[b].n;
 }

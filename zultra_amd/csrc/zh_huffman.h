@@ -71,21 +71,36 @@ struct zh_huff_scratch_t {
 __device__ inline void zh_mk_depths_wave(int32_t *A, int n, uint32_t *tmp) {
    const int lane = (int)zh_lane();
    if (lane == 0) {
-      int leaf = 0, node = 0, t;
-      for (t = 0; t < n - 1; t++) {
+      // The heads of the two queues and the entries behind them stay in registers: a step of the reference's loop reads both
+      // heads from the array after every pick (two dependent LDS round trips per pick); here a queue's register pair is
+      // refilled when it advances and the load has the other pick's time to land.
+      const int inf = 0x7fffffff;
+      int leaf = 0, node = 0;
+      int lw0 = A[0], lw1 = A[1];          // n >= 2
+      int nw0 = inf, nw1 = inf;            // node queue: empty
+      for (int t = 0; t < n - 1; t++) {
          int w = 0;
+#pragma unroll
          for (int pick = 0; pick < 2; pick++) {
-            if (leaf >= n || (node < t && A[node] < A[leaf])) {
-               w += A[node];
+            if (leaf >= n || (node < t && nw0 < lw0)) {   // an internal node only when strictly lighter than the next leaf (:203,215)
+               w += nw0;
                A[node] = t;
                node++;
+               nw0 = nw1;
+               nw1 = node + 1 < t ? A[node + 1] : inf;
             }
             else {
-               w += A[leaf];
+               w += lw0;
                leaf++;
+               lw0 = lw1;
+               lw1 = leaf + 1 < n ? A[leaf + 1] : inf;
             }
          }
          A[t] = w;
+         if (node == t)
+            nw0 = w;                        // the queue was empty: the new node is its head
+         else if (node + 1 == t)
+            nw1 = w;
       }
    }
    zh_wave_sync();
@@ -149,18 +164,49 @@ __device__ inline void zh_mk_depths_wave(int32_t *A, int n, uint32_t *tmp) {
    zh_wave_sync();
 }
 
-// Lane-parallel rank sort of unique 32-bit keys: sorted[rank(k)] = k. All lanes call.
-__device__ inline void zh_rank_sort_wave(const uint32_t *keys, uint32_t *sorted, int n) {
+// Sort of n unique 32-bit keys: sorted[0..n) ascending. All lanes call. `keys` and `sorted` are the scratch arrays of
+// zh_huff_scratch_t, contiguous (2 x ZH_NLIT words); keys is destroyed. Up to 64 keys: rank sort (every lane counts the keys
+// below its own). Above: a bitonic network over the next power of two, padded with all-ones — 45 compare-exchange stages of
+// 4 pairs per lane for 512 entries against 288 x 5 counting steps.
+__device__ inline void zh_rank_sort_wave(uint32_t *keys, uint32_t *sorted, int n) {
    const int lane = (int)zh_lane();
-   for (int base = 0; base < n; base += 64) {
-      int e = base + lane;
-      if (e < n) {
-         uint32_t k = keys[e];
+   if (n <= 64) {
+      if (lane < n) {
+         const uint32_t k = keys[lane];
          int rank = 0;
          for (int j = 0; j < n; j++) rank += (keys[j] < k) ? 1 : 0;
          sorted[rank] = k;
       }
+      zh_wave_sync();
+      return;
    }
+   int P = 128;
+   while (P < n) P <<= 1;                      // 128, 256 or 512 <= 2 * ZH_NLIT
+   uint32_t *a = keys;                         // work area: keys[0..P), running into `sorted` for P = 512
+   for (int e = n + lane; e < P; e += 64) a[e] = 0xFFFFFFFFu;
+   zh_wave_sync();
+   for (int size = 2; size <= P; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+         for (int pr = lane; pr < (P >> 1); pr += 64) {
+            const int lo = ((pr & ~(stride - 1)) << 1) | (pr & (stride - 1)), hi = lo + stride;
+            const bool up = (lo & size) == 0;
+            const uint32_t x = a[lo], y = a[hi];
+            if ((x > y) == up) {
+               a[lo] = y;
+               a[hi] = x;
+            }
+         }
+         zh_wave_sync();
+      }
+   }
+   // the first n entries are the keys in order; `sorted` may overlap the work area: through registers
+   uint32_t v[5];
+#pragma unroll
+   for (int q = 0; q < 5; q++) v[q] = lane + 64 * q < n ? a[lane + 64 * q] : 0u;
+   zh_wave_sync();
+#pragma unroll
+   for (int q = 0; q < 5; q++)
+      if (lane + 64 * q < n) sorted[lane + 64 * q] = v[q];
    zh_wave_sync();
 }
 

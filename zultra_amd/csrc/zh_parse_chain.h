@@ -39,6 +39,51 @@
 #define ZH_CHAIN_VLONG_TASK 24576u  // positions: listed tasks longer than this get the first tickets ...
 #define ZH_CHAIN_LONG_TASK 6144u    // ... those longer than this the next ones
 
+// ---- speculative segments -------------------------------------------------------------------------------------------------
+// A chain of 64 Ki positions is 3.7 ms of one wave, four times per batch: the longest chain IS the pass. But the recurrence
+// forgets: started W positions to the right of a cut b with made-up costs (here: as if the sub-block ended at b + W), the
+// DIFFERENCES cost[b + i] - cost[b], i = 0..258, usually come out exactly as the true ones — on text with long repeats the
+// optimal paths of neighbouring positions funnel through common points within a few hundred positions (measured on the
+// bench's text corpus, W = 1024: 131 of 137 cuts; the exception is periodic data, where every match is 258 long, the costs
+// of positions 258 apart are copies of each other and nothing is ever forgotten). And the choices left of b depend on the costs
+// at b .. b+258 through their differences only (every comparison is between sums that share the constant — the argument that
+// makes barriers restart points, zh_parse.h). So a long task [t0, t1) is cut at b_k = t1 - (K-1-k) ZH_CUT_LEN into K segments,
+// each parsed by its own workgroup: segment k starts at b_k + ZH_CUT_WARM, stores no parse entries above b_k, records the
+// relative costs of [b_k, b_k + 258] as it passes (speculated) and those of [b_{k-1}, b_{k-1} + 258] when it is done (its own
+// left end). zh_parse_chain_fix then walks each cut task from the right: the last segment is exact by construction; segment k
+// is exact if segment k+1 is and its speculated vector equals segment k+1's left one; otherwise it is parsed again from that
+// (exact) vector. The output is the reference's parse bit for bit either way; speculation only decides how much of it was
+// computed in parallel. Periodic tasks (most positions offer a 258-byte match) are not cut: their cuts would all fail.
+#ifndef ZH_CUT_LEN
+#define ZH_CUT_LEN 4096u          // positions per segment (a multiple of ZH_CHAIN_TILE)
+#endif
+#ifndef ZH_CUT_WARM
+#define ZH_CUT_WARM 1024u     // warm-up positions right of a cut (a multiple of ZH_CHAIN_TILE, 288 .. ZH_CUT_LEN)
+#endif
+#define ZH_CUT_MIN (2u * ZH_CUT_LEN)   // tasks shorter than this stay whole
+#ifndef ZH_TRACE_SLOTS
+#define ZH_TRACE_SLOTS 4096u
+#endif
+#define ZH_VEC 264u           // int16 entries per cost vector: cost[x + i] - cost[x], i = 0..258 (+ padding)
+#define ZH_VEC_LIVE 259u
+#define ZH_VEC_BIAS 4096      // imported costs are (bias + difference) << 9: differences are below 258 x 15 in magnitude
+
+// per segmented task (zh_list_huge): x = task, y = number of segments, z = first vector slot (one slot = spec + left vector)
+// counters of a run (device: uint32 per field; one block of ZH_CNT_STRIDE words per run)
+enum {
+   ZH_CNT_TASKS = 0, ZH_CNT_VLONG, ZH_CNT_LONG, ZH_CNT_SHORT, ZH_CNT_HUGE_POS, ZH_CNT_SEGTASKS, ZH_CNT_SEGITEMS, ZH_CNT_SEG_FAILED,
+   ZH_CNT_CHAIN_TICKET = 8, ZH_CNT_TASK_TICKET = 12, ZH_CNT_FIX_TICKET = 16, ZH_CNT_STRIDE = 32
+};
+
+struct zh_chain_job_t {
+   uint32_t t0, t1;        // positions to price: [t0, t1), from t1 - 1 down
+   uint32_t clamp;         // candidates end here at the latest (the sub-block end, or the made-up end of a speculative start)
+   uint32_t store_hi;      // parse entries of positions >= store_hi are not stored (a tile boundary: t1 - store_hi is a multiple of the tile)
+   const int16_t *import;  // relative costs of [t1, t1 + 258], or NULL: cost[t1] = 0 and nothing reaches beyond
+   int16_t *export_spec;   // relative costs of [store_hi, store_hi + 258], written when the recurrence passes store_hi, or NULL
+   int16_t *export_left;   // relative costs of [t0, t0 + 258] at the end (t1 - t0 a multiple of the tile), or NULL
+};
+
 #ifdef ZH_CHAIN_PROFILE
 __device__ uint64_t zh_chain_profile[4];   // probe builds only (tools/probes/chain2_probe.hip): busy cycles per role of the last chain
 #endif
@@ -149,8 +194,8 @@ __device__ __forceinline__ void zh_chain_stage(zh_chain_ws_t &ws, uint32_t buf, 
 // flusher: the winning keys of a priced tile -> parse entries (zh_decode_pick). Thread i = position thi-1-i; the position's match
 // row comes from LDS, where the stager left it (a global load here would put HBM latency into every tile period).
 __device__ __forceinline__ void zh_chain_flush(zh_chain_ws_t &ws, uint32_t buf, uint32_t rbuf, uint32_t prev, uint32_t thi, uint32_t cnt, uint32_t sb_end, uint32_t i,
-                                               uint32_t *best) {
-   if (i >= cnt) return;
+                                               uint32_t *best, uint32_t store_hi) {
+   if (i >= cnt || thi > store_hi) return;   // (store_hi is a tile boundary)
    const uint32_t pos = thi - 1 - i;
    const uint32_t kk = ws.p.bt[buf][i];
    uint32_t pick = 0;
@@ -253,10 +298,21 @@ __device__ __forceinline__ void zh_chain_rebase(zh_chain_ws_t &ws, zh_chain_stat
    for (uint32_t k = lane; k < ZH_CHAIN_RING; k += 64) ws.p.ring[k] -= delta;
 }
 
-// Parse [t0, t1) of a sub-block as one chain, t1 a barrier or the sub-block end (cost[t1] = 0). All ZH_CHAIN_THREADS threads call.
-// ws.litprice / lencost / distcost hold the prices of the pass.
-__device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, const uint4 *rows_hi, const uint8_t *win, uint32_t prev, uint32_t t0, uint32_t t1,
-                                      uint32_t sb_end, uint32_t *best) {
+// consumer, right after a tile's costs went into the ring: the costs of [x, x + 258] relative to cost[x], x = the tile's low end
+__device__ __forceinline__ void zh_chain_export(zh_chain_ws_t &ws, int16_t *out, uint32_t x) {
+   const uint32_t i0 = x & (ZH_CHAIN_RING - 1u);
+   const uint32_t base = ws.p.ring[i0] + (i0 << 23);
+   for (uint32_t i = zh_lane(); i < ZH_VEC_LIVE + 1u; i += 64) {   // (an even number of entries: the vectors are compared word-wise)
+      const uint32_t idx = (x + i) & (ZH_CHAIN_RING - 1u);
+      out[i] = i < ZH_VEC_LIVE ? (int16_t)((int32_t)(ws.p.ring[idx] + (idx << 23) - base) >> 9) : (int16_t)0;
+   }
+}
+
+// Parse job.t0 .. job.t1 of a sub-block as one chain. All ZH_CHAIN_THREADS threads call. ws.litprice / lencost / distcost hold the
+// prices of the pass.
+__device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, const uint4 *rows_hi, const uint8_t *win, uint32_t prev, const zh_chain_job_t &job,
+                                      uint32_t *best) {
+   const uint32_t t0 = job.t0, t1 = job.t1, sb_end = job.clamp;
    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
    const uint32_t ntiles = t1 > t0 ? (t1 - t0 + ZH_CHAIN_TILE - 1) / ZH_CHAIN_TILE : 0u;
    if (!ntiles) return;
@@ -294,8 +350,13 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
       zh_chain_stage(ws, 0, 0, fr[0], t1, ZH_CHAIN_TILE_CNT(0u), sb_end, pl, lcw);
    }
    else if (wave == 0) {
-      // cost[t1] = 0; entries above it are never asked for (t1 is a barrier or the end: no candidate reaches past it)
-      for (uint32_t k = lane; k < ZH_CHAIN_RING; k += 64) ws.p.ring[k] = 0u - (k << 23);
+      // cost[t1] = 0; entries above it are never asked for (t1 is a barrier or the end: no candidate reaches past it) — or the
+      // costs a neighbouring segment left for [t1, t1 + 258]
+      for (uint32_t k = lane; k < ZH_CHAIN_RING; k += 64) {
+         const uint32_t i = (k - t1) & (ZH_CHAIN_RING - 1u);
+         const uint32_t v = (job.import && i < ZH_VEC_LIVE) ? (uint32_t)(ZH_VEC_BIAS + (int32_t)job.import[i]) << 9 : 0u;
+         ws.p.ring[k] = v - (k << 23);
+      }
    }
    else {
       // consumer lanes 48..63 price nothing
@@ -323,13 +384,20 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
       st.cv = 0;   // lane j: cost9[t1 + 2 + j]: beyond the end; lane 0 receives cost9[t1] = 0 when position t1-2 is priced
       st.c1 = 0;   // cost9[t1]
       st.c2 = 0;
+      if (job.import) {
+         st.c1 = (uint32_t)(ZH_VEC_BIAS + (int32_t)job.import[0]) << 9;
+         st.c2 = (uint32_t)(ZH_VEC_BIAS + (int32_t)job.import[1]) << 9;
+         st.cv = (uint32_t)(ZH_VEC_BIAS + (int32_t)job.import[2 + lane]) << 9;
+      }
       for (uint32_t k = 0; k < ntiles; k++) {
          ZH_CHAIN_TIC();
          if (st.c1 >= ZH_CHAIN_REBASE) zh_chain_rebase(ws, st);
          zh_chain_consume(ws, k & 1u, ZH_CHAIN_TILE_HI(k), st);
+         if (job.export_spec && ZH_CHAIN_TILE_HI(k) - ZH_CHAIN_TILE == job.store_hi) zh_chain_export(ws, job.export_spec, job.store_hi);
          ZH_CHAIN_TOC();
          zh_sync_lds();
       }
+      if (job.export_left) zh_chain_export(ws, job.export_left, t0);
    }
    else if (stager) {
       // period k: the rows of tile k+3 are requested into the slot tile k occupied, then tile k+1 (requested two periods ago)
@@ -356,12 +424,12 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
    else {
       for (uint32_t k = 0; k < ntiles; k++) {
          ZH_CHAIN_TIC();
-         if (k) zh_chain_flush(ws, (k - 1) & 1u, (k - 1) & 3u, prev, ZH_CHAIN_TILE_HI(k - 1), ZH_CHAIN_TILE, sb_end, lane, best);
+         if (k) zh_chain_flush(ws, (k - 1) & 1u, (k - 1) & 3u, prev, ZH_CHAIN_TILE_HI(k - 1), ZH_CHAIN_TILE, sb_end, lane, best, job.store_hi);
          ZH_CHAIN_TOC();
          zh_sync_lds();
       }
       const uint32_t k = ntiles - 1;
-      zh_chain_flush(ws, k & 1u, k & 3u, prev, ZH_CHAIN_TILE_HI(k), ZH_CHAIN_TILE_CNT(k), sb_end, lane, best);
+      zh_chain_flush(ws, k & 1u, k & 3u, prev, ZH_CHAIN_TILE_HI(k), ZH_CHAIN_TILE_CNT(k), sb_end, lane, best, job.store_hi);
    }
 #ifdef ZH_CHAIN_PROFILE
    if (lane == 0) zh_chain_profile[wave] = busy;
@@ -374,14 +442,16 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
 #undef ZH_CHAIN_TILE_CNT
 }
 
-// the tasks zh_parse_tasks leaves alone: one wave per task, the same piece computation
+// the tasks zh_parse_tasks leaves alone: one wave per task, the same piece computation. cnt = the run's counters (ZH_CNT_*).
+// Tasks of at least seg_min positions that are not periodic are cut into segments (see the top of this file): listed in segtasks,
+// one entry of segitems per segment.
 __global__ void __launch_bounds__(64)
 zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
-             const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total, uint32_t *hugelist, uint32_t cap, uint32_t *nlong, uint32_t *nshort,
-             uint32_t *nvlong, uint32_t *huge_positions) {
+             const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ longest, uint64_t longest_stride, uint32_t *hugelist, uint32_t cap, uint4 *segtasks,
+             uint2 *segitems, uint32_t seg_min, uint32_t *cnt) {
    __shared__ uint32_t bnd[ZH_MAXPIECES + 1];
    const uint32_t gt = blockIdx.x;
-   if (gt >= *ntasks_total) return;
+   if (gt >= cnt[ZH_CNT_TASKS]) return;
    const uint2 tm = taskmap[gt];
    const zh_work_t wk = work[tm.x];
    const uint32_t prev = blocks[wk.block].prev;
@@ -391,88 +461,221 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
    const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
    const uint32_t np = zh_task_pieces(bnd, bar, prev, t0, t1, lane);
    zh_sync();
-   if (zh_task_is_huge(bnd, np, lane) && lane == 0) {
+   if (!zh_task_is_huge(bnd, np, lane)) return;
+   const uint32_t len = t1 - t0;
+   if (len >= seg_min) {
+      // periodic? (a 258-byte match at most positions: the costs 258 apart copy each other, a speculative start never converges)
+      const uint32_t *lg = longest + (uint64_t)wk.block * longest_stride;
+      uint32_t full = 0;
+      for (uint32_t p = t0 + lane; p < t1; p += 64) full += (lg[p - prev] & 0xffffu) >= ZH_MAX_MATCH ? 1u : 0u;
+      full = zh_wave_sum(full);
+      if (2u * full <= len) {
+         const uint32_t K = len / ZH_CUT_LEN;   // >= 2; segment 0 takes the remainder too
+         uint32_t ti = 0, it = 0;
+         if (lane == 0) {
+            ti = atomicAdd(&cnt[ZH_CNT_SEGTASKS], 1u);
+            it = atomicAdd(&cnt[ZH_CNT_SEGITEMS], K);
+            segtasks[ti] = make_uint4(gt, K, it, 0u);   // vector slot of segment k = its item index
+            atomicAdd(&cnt[ZH_CNT_HUGE_POS], len);      // statistics only (zultra_hip_last_stats)
+         }
+         ti = zh_readfirstlane(ti);
+         it = zh_readfirstlane(it);
+         // the exact (rightmost) segment and the long first one get the earliest tickets of their task
+         for (uint32_t k = lane; k < K; k += 64) segitems[it + k] = make_uint2(ti, K - 1u - k);
+         return;
+      }
+   }
+   if (lane == 0) {
       // three classes by length, handed out longest class first (zh_chain_ticket): what the pass will wait for are its longest
       // chains, so they get the first tickets of zh_parse_chain. The very long ones fill the list from the front, the long ones
       // from its middle, the rest from the back.
-      if (t1 - t0 > ZH_CHAIN_VLONG_TASK)
-         hugelist[atomicAdd(nvlong, 1u)] = gt;
-      else if (t1 - t0 > ZH_CHAIN_LONG_TASK)
-         hugelist[cap / 2u + atomicAdd(nlong, 1u)] = gt;
+      if (len > ZH_CHAIN_VLONG_TASK)
+         hugelist[atomicAdd(&cnt[ZH_CNT_VLONG], 1u)] = gt;
+      else if (len > ZH_CHAIN_LONG_TASK)
+         hugelist[cap / 2u + atomicAdd(&cnt[ZH_CNT_LONG], 1u)] = gt;
       else
-         hugelist[cap - 1u - atomicAdd(nshort, 1u)] = gt;
-      atomicAdd(huge_positions, t1 - t0);   // statistics only (zultra_hip_last_stats)
+         hugelist[cap - 1u - atomicAdd(&cnt[ZH_CNT_SHORT], 1u)] = gt;
+      atomicAdd(&cnt[ZH_CNT_HUGE_POS], len);
    }
 }
 
-// Persistent workgroups take the listed tasks from a ticket: the grid is small and fixed (ZH_CHAIN_GRID), so it is dispatched at
-// once — next to zh_parse_tasks' tens of thousands of waves — and every chain starts at the beginning of the pass.
+// what a chain workgroup needs to know about its task
+struct zh_chain_task_t {
+   const uint8_t *win;
+   const uint4 *rows, *rows_hi;
+   uint32_t *best;
+   const zh_sbstate_t *st;
+   uint32_t prev, t0, t1, sb_end;
+   bool skip;
+};
+
+__device__ __forceinline__ zh_chain_task_t zh_chain_task(uint32_t gt, const uint8_t *data, const zh_block_t *blocks, const zh_match_t *match, uint64_t match_stride,
+                                                         const uint64_t *bars, uint64_t bar_stride, const zh_work_t *work, const uint2 *taskmap, const zh_sbstate_t *states,
+                                                         uint32_t *best_all, uint64_t best_stride, int pass) {
+   zh_chain_task_t T;
+   const uint2 tm = taskmap[gt];
+   const zh_work_t wk = work[tm.x];
+   T.st = states + tm.x;
+   T.skip = T.st->failed || (!T.st->is_dynamic && pass > 0);   // static sub-blocks are parsed once (blockdeflate.c:836-858)
+   const zh_block_t blk = blocks[wk.block];
+   T.win = data + blk.win_off;
+   T.prev = blk.prev;
+   T.rows = (const uint4 *)(match + (uint64_t)wk.block * match_stride);
+   T.rows_hi = T.rows + ZH_ROW_HI_OFF(match_stride);
+   const uint64_t *bar = bars + (uint64_t)wk.block * bar_stride;
+   T.best = best_all + (uint64_t)wk.block * best_stride;
+   T.sb_end = wk.start + wk.size;
+   T.t0 = zh_task_boundary(bar, T.prev, wk.start, T.sb_end, tm.y, wk.ntasks);
+   T.t1 = zh_task_boundary(bar, T.prev, wk.start, T.sb_end, tm.y + 1, wk.ntasks);
+   return T;
+}
+
+// prices of the codes in force; unused symbols price at 9 / 6 bits (blockdeflate.c:873-881). All threads; ends with a barrier.
+__device__ __forceinline__ void zh_chain_prices(zh_chain_ws_t &ws, const zh_sbstate_t *st) {
+   const uint32_t tid = threadIdx.x;
+   for (uint32_t k = tid; k < ZH_NLIT; k += ZH_CHAIN_THREADS) {
+      const uint32_t l = st->lit_len[k];
+      ws.litprice[k] = (uint8_t)(l ? l : 9u);
+   }
+   if (tid < ZH_NDIST) {
+      const uint32_t l = st->dist_len[tid];
+      ws.distcost[tid] = (uint8_t)((l ? l : 6u) + (uint32_t)zh_dist_xbits((int)tid));
+   }
+   __syncthreads();
+   for (uint32_t e = tid; e < 256; e += ZH_CHAIN_THREADS) {
+      const int idx = zh_len_idx(e + 3);
+      ws.lencost[e] = (uint8_t)(ws.litprice[257 + idx] + zh_lenidx_xbits(idx));
+   }
+   __syncthreads();
+}
+
+// histogram of the task's parse (the per-sub-block sum is taken by zh_sb_build). All threads.
+__device__ __forceinline__ void zh_chain_histogram(zh_chain_ws_t &ws, const zh_chain_task_t &T, uint32_t *hp) {
+   const uint32_t tid = threadIdx.x;
+   __threadfence_block();
+   __syncthreads();
+   for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) ws.hist[k] = 0;
+   __syncthreads();
+   zh_walk_histogram_wave(ws.hist, T.win, T.prev, (tid >> 6) == 0 ? T.t0 : T.t1, T.t1, T.best);   // the other waves walk nothing (they join the barrier)
+   for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) hp[k] = ws.hist[k];
+}
+
+// Persistent workgroups take the listed items from a ticket: the grid is small and fixed (ZH_CHAIN_GRID), so it is dispatched at
+// once — next to zh_parse_tasks' tens of thousands of waves — and every chain starts at the beginning of the pass. Ticket order:
+// the whole tasks of the two long classes, the segments of the cut tasks, the short whole tasks.
 #define ZH_CHAIN_GRID 1536
 __global__ void __launch_bounds__(ZH_CHAIN_THREADS)
 zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
-               const uint32_t *__restrict__ hugelist, uint32_t cap, const uint32_t *__restrict__ nlong_p, const uint32_t *__restrict__ nshort_p,
-               const uint32_t *__restrict__ nvlong_p, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket,
-               uint64_t *trace /* diagnostics (ZULTRA_HIP_CHAIN_TRACE): per ticket {positions, start, end} on the 100 MHz clock, or NULL */) {
+               const uint32_t *__restrict__ hugelist, uint32_t cap, const uint4 *__restrict__ segtasks, const uint2 *__restrict__ segitems, int16_t *vecs,
+               const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass,
+               uint32_t *ticket, uint64_t *trace /* diagnostics (ZULTRA_HIP_CHAIN_TRACE): per ticket {positions, start, end} on the 100 MHz clock, or NULL */) {
    __shared__ zh_chain_ws_t ws;
    __shared__ uint32_t s_item;
-   const uint32_t tid = threadIdx.x, wave = tid >> 6;
-   const uint32_t nvlong = *nvlong_p, nlong = *nlong_p, count = nvlong + nlong + *nshort_p;
+   const uint32_t tid = threadIdx.x;
+   const uint32_t nvlong = cnt[ZH_CNT_VLONG], nlong = cnt[ZH_CNT_LONG], nseg = cnt[ZH_CNT_SEGITEMS], count = nvlong + nlong + nseg + cnt[ZH_CNT_SHORT];
    for (;;) {
       __syncthreads();   // the previous task's histogram has left LDS, s_item has been read
       if (tid == 0) s_item = atomicAdd(ticket, 1u);
       __syncthreads();
       const uint32_t item = s_item;
       if (item >= count) return;
-      const uint32_t gt = item < nvlong ? hugelist[item] : (item < nvlong + nlong ? hugelist[cap / 2u + (item - nvlong)] : hugelist[cap - 1u - (item - nvlong - nlong)]);
-      const uint2 tm = taskmap[gt];
-      const zh_work_t wk = work[tm.x];
-      const zh_sbstate_t *st = states + tm.x;
-      if (st->failed) continue;
-      if (!st->is_dynamic && pass > 0) continue;   // static sub-blocks are parsed once (blockdeflate.c:836-858)
-      const zh_block_t blk = blocks[wk.block];
-      const uint8_t *win = data + blk.win_off;
-      const uint32_t prev = blk.prev;
-      const uint4 *rows = (const uint4 *)(match + (uint64_t)wk.block * match_stride);
-      const uint4 *rows_hi = rows + ZH_ROW_HI_OFF(match_stride);
-      const uint64_t *bar = bars + (uint64_t)wk.block * bar_stride;
-      uint32_t *best = best_all + (uint64_t)wk.block * best_stride;
-      const uint32_t sb_end = wk.start + wk.size;
-
-      // ---- prices of the codes in force; unused symbols price at 9 / 6 bits (blockdeflate.c:873-881) ---------------
-      for (uint32_t k = tid; k < ZH_NLIT; k += ZH_CHAIN_THREADS) {
-         const uint32_t l = st->lit_len[k];
-         ws.litprice[k] = (uint8_t)(l ? l : 9u);
+      const bool is_seg = item >= nvlong + nlong && item < nvlong + nlong + nseg;
+      uint32_t gt, K = 1, k = 0, slot = 0;
+      if (is_seg) {
+         slot = item - nvlong - nlong;
+         const uint2 si = segitems[slot];
+         const uint4 stask = segtasks[si.x];
+         gt = stask.x;
+         K = stask.y;
+         k = si.y;
+         slot = stask.z + k;
       }
-      if (tid < ZH_NDIST) {
-         const uint32_t l = st->dist_len[tid];
-         ws.distcost[tid] = (uint8_t)((l ? l : 6u) + (uint32_t)zh_dist_xbits((int)tid));
+      else
+         gt = item < nvlong ? hugelist[item] : (item < nvlong + nlong ? hugelist[cap / 2u + (item - nvlong)] : hugelist[cap - 1u - (item - nvlong - nlong - nseg)]);
+      const zh_chain_task_t T = zh_chain_task(gt, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, pass);
+      if (T.skip) continue;
+      zh_chain_prices(ws, T.st);
+      zh_chain_job_t job;
+      job.t0 = T.t0;
+      job.t1 = T.t1;
+      job.clamp = T.sb_end;
+      job.store_hi = 0xFFFFFFFFu;
+      job.import = NULL;
+      job.export_spec = NULL;
+      job.export_left = NULL;
+      if (is_seg) {
+         int16_t *v = vecs + (uint64_t)slot * (2u * ZH_VEC);   // [0]: speculated at the segment's right end, [1]: its left end
+         const uint32_t b = T.t1 - (K - 1u - k) * ZH_CUT_LEN;     // the segment's right end
+         job.t0 = k ? b - ZH_CUT_LEN : T.t0;
+         if (k) job.export_left = v + ZH_VEC;
+         if (k + 1u < K) {
+            job.t1 = job.clamp = b + ZH_CUT_WARM;            // as if the sub-block ended there
+            job.store_hi = b;
+            job.export_spec = v;
+         }
       }
-      __syncthreads();
-      for (uint32_t e = tid; e < 256; e += ZH_CHAIN_THREADS) {
-         const int idx = zh_len_idx(e + 3);
-         ws.lencost[e] = (uint8_t)(ws.litprice[257 + idx] + zh_lenidx_xbits(idx));
-      }
-      const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y, wk.ntasks);
-      const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
-      __syncthreads();
       const uint64_t trace_t0 = trace ? zh_wall_clock() : 0;
-      zh_chain_parse(ws, rows, rows_hi, win, prev, t0, t1, sb_end, best);
-      if (trace && tid == 0) {
-         trace[3 * (uint64_t)item] = t1 - t0;
+      zh_chain_parse(ws, T.rows, T.rows_hi, T.win, T.prev, job, T.best);
+      if (trace && tid == 0 && item < ZH_TRACE_SLOTS) {
+         trace[3 * (uint64_t)item] = job.t1 - job.t0;
          trace[3 * (uint64_t)item + 1] = trace_t0;
          trace[3 * (uint64_t)item + 2] = zh_wall_clock();
       }
+      if (!is_seg && T.st->is_dynamic) zh_chain_histogram(ws, T, hist_part + (uint64_t)gt * ZH_NSYM);
+   }
+}
 
-      // ---- histogram of the task's parse; the per-sub-block sum is taken by zh_sb_build -------------------------------
-      if (st->is_dynamic) {
-         __threadfence_block();
+// After zh_parse_chain: per cut task, accept the segments whose speculated costs match what their right neighbour left, parse the
+// others again from there, then take the task's histogram. One workgroup per task at a time.
+__global__ void __launch_bounds__(ZH_CHAIN_THREADS)
+zh_parse_chain_fix(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
+                   const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
+                   const uint4 *__restrict__ segtasks, int16_t *vecs, uint32_t *cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all,
+                   uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket) {
+   __shared__ zh_chain_ws_t ws;
+   __shared__ uint32_t s_item, s_bad;
+   const uint32_t tid = threadIdx.x;
+   const uint32_t count = cnt[ZH_CNT_SEGTASKS];
+   for (;;) {
+      __syncthreads();
+      if (tid == 0) s_item = atomicAdd(ticket, 1u);
+      __syncthreads();
+      const uint32_t item = s_item;
+      if (item >= count) return;
+      const uint4 stask = segtasks[item];
+      const uint32_t gt = stask.x, K = stask.y;
+      const zh_chain_task_t T = zh_chain_task(gt, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, pass);
+      if (T.skip) continue;
+      bool priced = false;
+      for (uint32_t k = K - 1u; k-- > 0;) {
+         int16_t *v = vecs + (uint64_t)(stask.z + k) * (2u * ZH_VEC);
+         const int16_t *right = v + 2u * ZH_VEC + ZH_VEC;   // the left-end vector of segment k + 1: exact by now
+         if (tid == 0) s_bad = 0;
          __syncthreads();
-         for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) ws.hist[k] = 0;
+         for (uint32_t i = tid; i < (ZH_VEC_LIVE + 1u) / 2u; i += ZH_CHAIN_THREADS)
+            if (zh_load_agent_u32((const uint32_t *)v + i) != zh_load_agent_u32((const uint32_t *)right + i)) s_bad = 1;
          __syncthreads();
-         zh_walk_histogram_wave(ws.hist, win, prev, wave == 0 ? t0 : t1, t1, best);   // the other waves walk nothing (they join the barrier)
-         uint32_t *hp = hist_part + (uint64_t)gt * ZH_NSYM;
-         for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) hp[k] = ws.hist[k];
+         if (!s_bad) continue;
+         // parse the segment again, from the true costs
+         if (!priced) {
+            zh_chain_prices(ws, T.st);
+            priced = true;
+         }
+         zh_chain_job_t job;
+         const uint32_t b = T.t1 - (K - 1u - k) * ZH_CUT_LEN;
+         job.t0 = k ? b - ZH_CUT_LEN : T.t0;
+         job.t1 = b;
+         job.clamp = T.sb_end;
+         job.store_hi = 0xFFFFFFFFu;
+         job.import = right;
+         job.export_spec = NULL;
+         job.export_left = k ? v + ZH_VEC : (int16_t *)NULL;
+         zh_chain_parse(ws, T.rows, T.rows_hi, T.win, T.prev, job, T.best);
+         if (tid == 0) atomicAdd(&cnt[ZH_CNT_SEG_FAILED], 1u);
+         __threadfence();
+         __syncthreads();   // the new left vector is visible to the next comparison; the workspace is free
       }
+      if (T.st->is_dynamic) zh_chain_histogram(ws, T, hist_part + (uint64_t)gt * ZH_NSYM);
    }
 }
