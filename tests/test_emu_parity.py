@@ -45,21 +45,24 @@ def test_emu_is_not_the_product_library(emu):
     ("byte_runs_first", lambda: corpus.indented(3000, 12), 0, 3000),
     ("near_copies", lambda: corpus.duplicated(14000, 3, 1500), 2000, 12000),
     ("deep_huffman", lambda: corpus.fibonacci_bytes(19), 0, 10945),
-    ("table_cut", lambda: corpus.table_like(30000, 9), 0, 30000),
 ], ids=lambda c: c[0])
 def test_stages_vs_oracle(emu, oracle, case):
     name, gen, prev, n = case
     check_window(emu, oracle, gen(), prev, n, tag=name)
 
 
-def test_chain_segments_are_both_accepted_and_redone(emu):
-    """The speculative segments of the chain parse (zh_parse_chain.h; the emulator build cuts every 512 positions with a
-    288-position warm-up): on table-like data some cuts verify and some are parsed again — test_stages_vs_oracle[table_cut]
-    checks that the parse is the reference's either way; on indented data (matches of 258 everywhere) a task is cut only when
-    less than half of its positions offer a full-length match."""
+@pytest.mark.parametrize("wide", ["1", "1000000"], ids=["as_waves_of_zh_parse_segments", "as_jobs_of_zh_parse_chain"])
+def test_chain_segments_are_both_accepted_and_redone(emu, oracle, monkeypatch, wide):
+    """The speculative segments of long barrier-free tasks (zh_parse.h; the emulator build cuts every 512 positions with a
+    288-position warm-up), parsed either way the host may choose (ZULTRA_HIP_SEG_WIDE = the number of segments in a run from
+    which they go to zh_parse_segments): on table-like data some cuts verify and some segments are parsed again, and the parse
+    is the reference's either way."""
+    monkeypatch.setenv("ZULTRA_HIP_SEG_WIDE", wide)
+    data = corpus.table_like(30000, 9)
+    check_window(emu, oracle, data, 0, 30000, tag="table_cut/" + wide)
     ctx = emu.context(32768, 1)
     try:
-        ctx.compress_blocks(corpus.table_like(30000, 9), [(0, 0, 30000)])
+        ctx.compress_blocks(data, [(0, 0, 30000)])
         st = ctx.stats()
     finally:
         ctx.close()

@@ -83,7 +83,9 @@ struct zultra_hip_ctx_s {
    uint32_t *h_ntasks;          // pinned mirror, read after the batch (zultra_hip_last_stats)
    uint32_t *d_hugelist;
    uint4 *d_segtasks;           // tasks cut into speculative segments (zh_parse_chain.h): per max-block seg_tasks_per_block entries
-   uint2 *d_segitems;           // their segments: per max-block seg_items_per_block entries
+   uint2 *d_segitems;           // their segments, as jobs of zh_parse_chain: per max-block seg_items_per_block entries
+   uint2 *d_segwaves;           // ... or as waves of zh_parse_segments (four segments each), likewise
+   uint32_t seg_wide;           // a run with at least this many segments parses them with zh_parse_segments (ZULTRA_HIP_SEG_WIDE)
    int16_t *d_vecs;             // two cost vectors per segment
    uint64_t seg_tasks_per_block, seg_items_per_block;
    uint64_t *d_chain_trace;     // diagnostics (ZULTRA_HIP_CHAIN_TRACE=1): [run][pass][ticket] {positions, start, end}
@@ -106,6 +108,8 @@ struct zultra_hip_ctx_s {
    hipEvent_t lane_ev[4][24];
    hipStream_t side_stream[4];     // per run: zh_parse_chain runs next to zh_parse_tasks
    hipEvent_t side_ev[4][8];       // per pass: fork, join
+   hipStream_t seg_stream[4];      // per run: zh_parse_segments, likewise
+   hipEvent_t seg_ev[4][4];        // per pass: join
    hipEvent_t ev_input;
    zh_subblock_t *d_results_compact;
    uint8_t *h_stage[2];         // pinned staging for callers that hand over pageable host memory (zultra_hip_staging)
@@ -332,6 +336,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_ntasks);
    (void)hipFree(c->d_hugelist);
    (void)hipFree(c->d_segtasks);
+   (void)hipFree(c->d_segwaves);
    (void)hipFree(c->d_segitems);
    (void)hipFree(c->d_vecs);
    (void)hipFree(c->d_chain_trace);
@@ -346,6 +351,9 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
       for (int i = 0; i < 8; i++)
          if (c->side_ev[k][i]) (void)hipEventDestroy(c->side_ev[k][i]);
       if (c->side_stream[k]) (void)hipStreamDestroy(c->side_stream[k]);
+      for (int i = 0; i < 4; i++)
+         if (c->seg_ev[k][i]) (void)hipEventDestroy(c->seg_ev[k][i]);
+      if (c->seg_stream[k]) (void)hipStreamDestroy(c->seg_stream[k]);
    }
    if (c->ev_input) (void)hipEventDestroy(c->ev_input);
    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -394,6 +402,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
          if (zh_alloc(c, &c->d_chain_trace, (size_t)3 * ZH_TRACE_SLOTS * 16)) return -1;
          ZH_CHECK(c, hipMemset(c->d_chain_trace, 0, (size_t)3 * ZH_TRACE_SLOTS * 16 * sizeof(uint64_t)));
       }
+      const char *sw = getenv("ZULTRA_HIP_SEG_WIDE");
+      c->seg_wide = sw ? (uint32_t)atoi(sw) : 1024u;
       const char *tw = getenv("ZULTRA_HIP_TASK_WAVES");
       c->task_waves = tw ? (uint32_t)atoi(tw) : 26u;
       if (c->task_waves < 1) c->task_waves = 1;
@@ -424,6 +434,12 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
             ZH_CHECK(c, hipStreamCreateWithPriority(&c->side_stream[k], hipStreamNonBlocking, hi_prio));
          }
          for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->side_ev[k][i]));
+         if (!c->files_mode) {
+            int lo_prio = 0, hi_prio = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+            ZH_CHECK(c, hipStreamCreateWithPriority(&c->seg_stream[k], hipStreamNonBlocking, hi_prio));
+            for (int i = 0; i < 4; i++) ZH_CHECK(c, hipEventCreate(&c->seg_ev[k][i]));
+         }
       }
       ZH_CHECK(c, hipEventCreate(&c->ev_input));
       if (zh_alloc(c, &c->d_results_compact, B * c->max_subs)) return -1;
@@ -439,11 +455,11 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
    // a cut task has at least ZH_CUT_MIN positions and lies inside one max-block; its segments have at least ZH_CUT_LEN each
    c->seg_tasks_per_block = c->files_mode ? 1 : N / ZH_CUT_MIN + 1;
-   c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_LEN + 1;
+   c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_LEN + N / ZH_CUT_MIN + 2;   // a task of len positions has ceil(len / ZH_CUT_LEN) segments
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
        zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, c->max_tasks) ||
-       zh_alloc(c, &c->d_segtasks, B * c->seg_tasks_per_block) || zh_alloc(c, &c->d_segitems, B * c->seg_items_per_block) ||
+       zh_alloc(c, &c->d_segtasks, B * c->seg_tasks_per_block) || zh_alloc(c, &c->d_segwaves, B * c->seg_items_per_block) || zh_alloc(c, &c->d_segitems, B * c->seg_items_per_block) ||
        zh_alloc(c, &c->d_vecs, B * c->seg_items_per_block * 2 * ZH_VEC) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
@@ -657,7 +673,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
    // (inputs of a files batch are never cut into speculative segments: seg_min = all ones)
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap,
-             (const uint32_t *)c->d_longest, c->tok_stride, c->d_hugelist, task_grid, c->d_segtasks, c->d_segitems, 0xFFFFFFFFu, c->d_ntasks);
+             (const uint32_t *)c->d_longest, c->tok_stride, c->d_hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu, c->d_ntasks);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       hipStream_t side = c->side_stream[0];
@@ -665,7 +681,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
       ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[0][2 * pass], 0));
       ZH_LAUNCH(zh_parse_chain, min(nb, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride,
                 (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_hugelist, task_grid,
-                (const uint4 *)c->d_segtasks, (const uint2 *)c->d_segitems, c->d_vecs, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
+                (const uint4 *)c->d_segtasks, (const uint2 *)c->d_segitems, c->d_vecs, 0u, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
                 c->best_stride, c->d_hist_part, pass, c->d_ntasks + ZH_CNT_CHAIN_TICKET + pass, (uint64_t *)NULL);
       ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass + 1], side));
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride,
@@ -860,6 +876,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       uint2 *taskmap = c->d_taskmap + t0;
       uint32_t *ntasks = c->d_ntasks + (size_t)k * ZH_CNT_STRIDE;   // the run's counters (ZH_CNT_*); [ZH_CNT_TASKS] = its number of tasks
       uint4 *segtasks = c->d_segtasks + (uint64_t)b0 * c->seg_tasks_per_block;
+      uint2 *segwaves = c->d_segwaves + (uint64_t)b0 * c->seg_items_per_block;
       uint2 *segitems = c->d_segitems + (uint64_t)b0 * c->seg_items_per_block;
       int16_t *vecs = c->d_vecs + (uint64_t)b0 * c->seg_items_per_block * 2 * ZH_VEC;
       uint32_t *h_cnt = c->h_ntasks + ZH_NCNT + (size_t)k * ZH_CNT_STRIDE;   // read back before the passes are launched
@@ -879,14 +896,18 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
       ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
       ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, segtasks, segitems, (uint32_t)ZH_CUT_MIN, ntasks);
+                (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, segtasks, segitems, segwaves, (uint32_t)ZH_CUT_MIN, ntasks);
       // Does this run have chains at all? With none (text without long repeats) zh_parse_tasks gets the whole chip; with chains it
       // runs as a bounded number of persistent waves per CU, so that the chain workgroups find room the moment they are launched.
-      ZH_CHECK(c, hipMemcpyAsync(h_cnt, ntasks, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipMemcpyAsync(h_cnt, ntasks, ZH_CNT_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipEventRecord(ev[5], st));
       ZH_CHECK(c, hipEventSynchronize(ev[5]));
-      const uint32_t nsegtasks = h_cnt[ZH_CNT_SEGTASKS];
-      const uint32_t nchains = h_cnt[ZH_CNT_VLONG] + h_cnt[ZH_CNT_LONG] + h_cnt[ZH_CNT_SHORT] + h_cnt[ZH_CNT_SEGITEMS];
+      // The cut tasks (zh_parse.h): many segments are throughput — four to a wave of zh_parse_segments, which also checks them; a few
+      // are latency — each one a job of zh_parse_chain (five times faster per position), checked by zh_parse_chain_fix after it.
+      const uint32_t nsegtasks = h_cnt[ZH_CNT_SEGTASKS], nsegs = h_cnt[ZH_CNT_SEGITEMS];
+      const bool seg_wide = nsegtasks && nsegs >= c->seg_wide;
+      const uint32_t nseg_chain = (nsegtasks && !seg_wide) ? nsegs : 0u;
+      const uint32_t nchains = h_cnt[ZH_CNT_VLONG] + h_cnt[ZH_CNT_LONG] + h_cnt[ZH_CNT_SHORT] + nseg_chain;
       const uint32_t chain_grid = min(nchains, (uint32_t)ZH_CHAIN_GRID);
       const uint32_t persistent_grid = min(task_grid, c->num_cus * c->task_waves);
       for (int pass = 0; pass <= 3; pass++) {
@@ -896,23 +917,34 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
             ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
             ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
             ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                      (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, (const uint4 *)segtasks, (const uint2 *)segitems, vecs, (const uint32_t *)ntasks,
-                      (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, ntasks + ZH_CNT_CHAIN_TICKET + pass,
+                      (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, (const uint4 *)segtasks, (const uint2 *)segitems, vecs, nseg_chain,
+                      (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, ntasks + ZH_CNT_CHAIN_TICKET + pass,
                       c->d_chain_trace ? c->d_chain_trace + 3 * (uint64_t)ZH_TRACE_SLOTS * (4 * k + pass) : (uint64_t *)NULL);
-            // the cut tasks: accept or redo their segments, then their histograms (zh_parse_chain.h)
-            if (nsegtasks)
+            if (nseg_chain)
                ZH_LAUNCH(zh_parse_chain_fix, min(nsegtasks, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride,
                          (const zh_work_t *)work, (const uint2 *)taskmap, (const uint4 *)segtasks, vecs, ntasks, (const zh_sbstate_t *)states, best, c->best_stride,
                          hist_part, pass, ntasks + ZH_CNT_FIX_TICKET + pass);
             ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
+         }
+         if (seg_wide) {
+            // single-wave workgroups like zh_parse_tasks', but each carries four segments of thousands of positions — on a stream
+            // of their own they start with the pass
+            hipStream_t sg = c->seg_stream[k];
+            if (!nchains) ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
+            ZH_CHECK(c, hipStreamWaitEvent(sg, c->side_ev[k][2 * pass], 0));
+            ZH_LAUNCH(zh_parse_segments, h_cnt[ZH_CNT_SEGWAVES], 64, sg, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+                      (const uint2 *)taskmap, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, segtasks, (const uint2 *)segwaves, vecs, ntasks);
+            ZH_CHECK(c, hipEventRecord(c->seg_ev[k][pass], sg));
+         }
+         if (nchains || seg_wide)
             ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                       (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
                       ntasks + ZH_CNT_TASK_TICKET + pass);
-            ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
-         }
          else
             ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                       (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
+         if (seg_wide) ZH_CHECK(c, hipStreamWaitEvent(st, c->seg_ev[k][pass], 0));
+         if (nchains) ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
          ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));
          ZH_LAUNCH(zh_sb_build, ns, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass);
          ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));

@@ -55,6 +55,44 @@
 #define ZH_RING 320u
 __device__ __forceinline__ uint32_t zh_ring_wrap(uint32_t x) { return min(x, x - ZH_RING); }
 
+// ---- speculative segments -------------------------------------------------------------------------------------------------
+// A barrier-free run of tens of thousands of positions is one recurrence: 64 Ki positions are milliseconds of a single wave,
+// four times per batch. But the recurrence forgets: started W positions to the right of a cut b with made-up costs (here: as if
+// the sub-block ended at b + W), the DIFFERENCES cost[b + i] - cost[b], i = 0..258, usually come out exactly as the true ones —
+// on text with long repeats the optimal paths of neighbouring positions funnel through common points within a few hundred
+// positions (measured on the bench's corpora, W = 1024: 97 % of the cuts on Python sources, all of them on JSON-like records; the
+// exception is data where nearly every position offers a 258-byte match: the costs of positions 258 apart copy each other and
+// nothing is ever forgotten). And the choices left of b depend on the costs at b .. b+258 through their differences only (every
+// comparison is between sums that share the constant — the argument that makes barriers restart points, see the top of this
+// file). So a long task [t0, t1) whose longest matches are mostly shorter than 258 is cut at b_k = t1 - (K-1-k) ZH_CUT_LEN into K
+// segments, and the segments are PIECES like any other: four of them share a wave of zh_parse_tasks, one per row. Segment k
+// starts at b_k + ZH_CUT_WARM, stores no parse entries at or above b_k, records the relative costs of [b_k, b_k + 258] as it
+// passes (speculated) and those of [b_{k-1}, b_{k-1} + 258] when it is done (its own left end). zh_parse_chain_fix
+// (zh_parse_chain.h) then walks each cut task from the right: the last segment is exact by construction; segment k is exact if
+// segment k+1 is and its speculated vector equals segment k+1's left one; otherwise it is parsed again from that (exact)
+// vector, as a chain. The output is the reference's parse bit for bit either way; speculation only decides how much of it was
+// computed in parallel.
+#ifndef ZH_CUT_LEN
+#define ZH_CUT_LEN 4096u          // positions per segment (a multiple of 32)
+#endif
+#ifndef ZH_CUT_WARM
+#define ZH_CUT_WARM 1024u         // warm-up positions right of a cut (a multiple of 32, 288 .. ZH_CUT_LEN)
+#endif
+#define ZH_CUT_MIN (2u * ZH_CUT_LEN)   // tasks shorter than this stay whole
+#define ZH_CUT_ROWS 4u            // segments per wave of zh_parse_tasks
+#define ZH_VEC 264u               // int16 entries per cost vector: cost[x + i] - cost[x], i = 0..258 (+ padding)
+#define ZH_VEC_LIVE 259u
+#define ZH_VEC_BIAS 4096          // imported costs are (bias + difference) << 9: differences are below 258 x 15 in magnitude
+
+// segtasks[] entry of a cut task (zh_list_huge): x = task, y = number of segments K, z = first vector slot (slot of segment k =
+// z + k; a slot holds two vectors: speculated at the segment's right end, computed at its left end); segwaves[] entry: x = index
+// into segtasks, y = first segment of the wave.
+// Counters of a run (device: uint32 per field; one block of ZH_CNT_STRIDE words per run)
+enum {
+   ZH_CNT_TASKS = 0, ZH_CNT_VLONG, ZH_CNT_LONG, ZH_CNT_SHORT, ZH_CNT_HUGE_POS, ZH_CNT_SEGTASKS, ZH_CNT_SEGITEMS, ZH_CNT_SEG_FAILED,
+   ZH_CNT_CHAIN_TICKET = 8, ZH_CNT_TASK_TICKET = 12, ZH_CNT_FIX_TICKET = 16, ZH_CNT_SEGWAVES = 20, ZH_CNT_STRIDE = 32
+};
+
 // sub-block work item produced by zh_plan_subblocks
 struct zh_work_t {
    uint32_t block, start, size;   // start = absolute window offset
@@ -193,6 +231,7 @@ __device__ __forceinline__ void zh_stage_position(zh_parse_ws_t &ws, uint32_t ro
 // This lane's best match candidate for the position at p with record R (tile entries at tile[trow][tslot]), costs in
 // `ring`: lane s prices length 3+s, and in the rarely executed section (taken by the whole wave when any position needs
 // it) lengths 19+s, 35+s and long slot s. Key = (cost - base) << 9 | slot << 6 | (39 - k).
+template <bool SEG>
 __device__ __forceinline__ uint32_t zh_lane_key(zh_parse_ws_t &ws, const uint16_t *ring, uint32_t trow, uint32_t tslot, const uint4 &R, uint32_t p, uint32_t pm,
                                                 uint32_t s, uint32_t base, uint32_t lc0, uint32_t lc1, uint32_t lc2, uint32_t sb_end) {
    const uint32_t kmax = ZH_REC_KMAX(R.w), nlong = ZH_REC_NLONG(R.w), nhi = ZH_REC_NHI(R.w);
@@ -219,7 +258,7 @@ __device__ __forceinline__ uint32_t zh_lane_key(zh_parse_ws_t &ws, const uint16_
       }
       if (s < nlong) {                                                        // long slot s: full (clamped) length only
          const uint32_t e = ws.tile[trow][tslot][s];
-         const uint32_t mlen = min(e & 511u, sb_end - p);
+         const uint32_t mlen = min(e & 511u, (SEG ? ws.bnd[16 + trow] : sb_end) - p);   // (SEG: the row's own end, see zh_parse_one_task)
          uint32_t enc = mlen - ZH_MIN_MATCH;                                  // wraps below 3, then saturates (:289, :216-219)
          if (enc > 255) enc = 255;
          const uint32_t c = ((uint32_t)ws.lencost[enc] + ((e >> 9) & 31u) + (uint32_t)ring[zh_ring_wrap(pm + mlen)] - base) & 0xffffu;
@@ -241,11 +280,17 @@ __device__ __forceinline__ uint32_t zh_decode_pick(zh_parse_ws_t &ws, uint32_t t
    return len | (e & 0xffff0000u);
 }
 
-// one task, by one wave (the calling workgroup); ws = its LDS workspace
+// One task, by one wave (the calling workgroup); ws = its LDS workspace. SEG: the task is a cut one (see above) and the wave's
+// pieces are its segments seg_k0 .. seg_k0 + 3 of seg_K, their cost vectors at slot seg_slot0 + k of `vecs`. The wave that
+// finishes last among the task's waves (*seg_done counts them) checks the cuts from the right, parses the segments whose
+// speculated costs do not match again — one at a time, on row 0, from the costs their right neighbour left — and takes the
+// task's histogram.
+template <bool SEG>
 __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
                                          const zh_match_t *__restrict__ match, uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride,
                                          const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
-                                         uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass) {
+                                         uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t seg_K, uint32_t seg_k0, uint32_t seg_slot0,
+                                         int16_t *vecs, uint32_t *seg_done, uint32_t *seg_failed) {
    const uint2 tm = taskmap[gt];
    const zh_work_t wk = work[tm.x];
    const zh_sbstate_t *st = states + tm.x;
@@ -279,13 +324,37 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
    // ---- task range and its pieces ------------------------------------------------------------------------------
    const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y, wk.ntasks);
    const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
-   const uint32_t np = zh_task_pieces(ws.bnd, bar, prev, t0, t1, lane);
-   zh_sync();
-   // a barrier-free run of more than ZH_COOP_MIN positions: four independent recurrences are of no use when the task is
-   // (mostly) one run. Such tasks are listed by zh_list_huge and parsed by zh_parse_huge, next to this kernel.
-   if (zh_task_is_huge(ws.bnd, np, lane)) return;
+   uint32_t np;
+   if (SEG) {
+      // row j takes segment k = seg_k0 + j: bnd[j] = its low end, [8 + j] = where its recurrence starts, [16 + j] = where its candidates
+      // end at the latest, [24 + j] = parse entries from here on are the right neighbour's, [32 + j] = vector slot | bit 31: has a
+      // left neighbour
+      np = min((uint32_t)ZH_CUT_ROWS, seg_K - seg_k0);
+      if (lane < np) {
+         const uint32_t k = seg_k0 + lane;
+         const bool last = k + 1u == seg_K;
+         const uint32_t b = t1 - (seg_K - 1u - k) * ZH_CUT_LEN;
+         ws.bnd[lane] = k ? b - ZH_CUT_LEN : t0;
+         ws.bnd[8 + lane] = last ? t1 : b + ZH_CUT_WARM;
+         ws.bnd[16 + lane] = last ? sb_end : b + ZH_CUT_WARM;
+         ws.bnd[24 + lane] = last ? 0xFFFFFFFFu : b;
+         ws.bnd[32 + lane] = (seg_slot0 + k) | (k ? 0x80000000u : 0u);
+      }
+      zh_sync();
+   }
+   else {
+      np = zh_task_pieces(ws.bnd, bar, prev, t0, t1, lane);
+      zh_sync();
+      // a barrier-free run of more than ZH_COOP_MIN positions: four independent recurrences are of no use when the task is
+      // (mostly) one run. Such tasks are listed by zh_list_huge: cut into segments and back here (SEG), or parsed as one chain by
+      // zh_parse_chain, next to this kernel.
+      if (zh_task_is_huge(ws.bnd, np, lane)) return;
+   }
    const uint32_t lc0 = ws.lencost[s], lc1 = ws.lencost[16 + s], lc2 = ws.lencost[32 + (s & 7)];
 
+   bool seg_checker = false, seg_import = false;   // (SEG) this wave checks the task's cuts; the round parses a segment again
+   uint32_t seg_exact = seg_K;                     // (SEG, checker) the segments from this one on are exact
+   for (;;) {   // (SEG: the speculative round, then the checker's rounds; otherwise once)
    // ---- row scheduler state (uniform within a row) ---------------------------------------------------------------
    int32_t next_piece = (int32_t)np - 1;   // wave-uniform: pieces are handed out from the task's end
    uint32_t p_lo = 0, p_hi = 0;            // what is left of the row's piece: [p_lo, p_hi)
@@ -331,7 +400,16 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
       }                                                                                                        \
    } while (0)
 
+   if (SEG) {
+      // one segment per row, no scheduler
+      next_piece = -1;
+      if (row < np) {
+         p_lo = ws.bnd[row];
+         p_hi = ws.bnd[8 + row];
+      }
+   }
    if (np) ZH_NEXT_TILE();
+   if (SEG) n_top = row < np;
 
    while (np) {
       const uint32_t c_lo = n_lo, c_cnt = n_cnt;
@@ -340,10 +418,20 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
 
       // ---- stage the tile: every lane digests the 8 slots of its own position (lanes beyond the tile's count digest
       //      zeros into their own, unused, record) ---------------------------------------------------------------------
-      zh_stage_position(ws, row, s, regs, sb_end - (c_lo + s));
+      zh_stage_position(ws, row, s, regs, (SEG ? ws.bnd[16 + row] : sb_end) - (c_lo + s));   // (SEG: the row's candidates end at its own, made-up, end)
       const uint32_t c_lo_m = c_lo % ZH_RING;   // once per tile; the steps below keep indices reduced
       if (c_top && s == 0) ws.ring[row][zh_ring_wrap(c_lo_m + c_cnt)] = 0;   // cost[piece end] = 0
       if (c_top) cost_next = 0;
+      if (SEG && seg_import && c_top) {
+         // ... and the costs of the 258 positions above it, as the segment to the right computed them (relative to cost[piece end])
+         const uint32_t *vl = (const uint32_t *)(vecs + (uint64_t)((ws.bnd[32 + row] & 0x7fffffffu) + 1u) * (2u * ZH_VEC) + ZH_VEC);
+         const uint32_t e_m = zh_ring_wrap(c_lo_m + c_cnt);
+         for (uint32_t i = s; i < (ZH_VEC_LIVE + 1u) / 2u; i += 16) {
+            const uint32_t w2 = zh_load_agent_u32(vl + i);
+            ws.ring[row][(e_m + 2u * i) % ZH_RING] = (uint16_t)w2;
+            ws.ring[row][(e_m + 2u * i + 1u) % ZH_RING] = (uint16_t)(w2 >> 16);   // (entry 259 is padding: a ring slot nobody reads before it is rewritten)
+         }
+      }
       zh_sync();
       ZH_NEXT_TILE();   // the next tile's loads complete while this one is priced
 
@@ -357,7 +445,7 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
          if (!act) R.w = 0;
          const uint32_t base = cost_next - ZH_KEY_BIAS;   // key cost = (candidate cost - base) mod 2^16, below 2^15
          const uint32_t pm = zh_ring_wrap(c_lo_m + a);
-         const uint32_t key = zh_lane_key(ws, ws.ring[row], row, a, R, p, pm, s, base, lc0, lc1, lc2, sb_end);
+         const uint32_t key = zh_lane_key<SEG>(ws, ws.ring[row], row, a, R, p, pm, s, base, lc0, lc1, lc2, sb_end);
          const uint32_t rkey = zh_row_min(key);   // every lane of a row now holds that row's best match candidate
          // literal first; a match must be strictly cheaper (:292,:307). An absent candidate (all ones) prices at 2^23-1,
          // above any literal (5 bits + bias).
@@ -374,14 +462,71 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
       }
       zh_sync();
       // ---- flush: decode the winning (slot, length) of each position and store the parse --------------------------
-      if (s < c_cnt)
+      if (s < c_cnt && (!SEG || c_lo < ws.bnd[24 + row]))   // (the boundary is a tile boundary)
          best[(c_lo + s) - prev] = zh_decode_pick(ws, row, s, ws.rec[row][s].x, sb_end - (c_lo + s), (const uint32_t *)(rows + (c_lo + s - prev)),
                                                   (const uint32_t *)(rows_hi + (c_lo + s - prev)));
+      if (SEG) {
+         // the relative costs of [c_lo, c_lo + 258] — all in the ring — when the row has just passed its cut (speculated: what the
+         // right neighbour will be compared with) or finished its segment (what the left neighbour will be compared with)
+         const uint32_t info = ws.bnd[32 + row];
+         const bool spec = c_cnt != 0 && c_lo == ws.bnd[24 + row];
+         const bool left = c_cnt != 0 && c_lo == ws.bnd[row] && (info >> 31) != 0;
+         if (zh_ballot(spec || left)) {
+            if (spec || left) {
+               int16_t *v = vecs + (uint64_t)(info & 0x7fffffffu) * (2u * ZH_VEC) + (spec ? 0u : ZH_VEC);
+               const uint32_t x = c_lo % ZH_RING;
+               const uint32_t base0 = ws.ring[row][x];
+               for (uint32_t i = s; i < ZH_VEC_LIVE + 1u; i += 16)   // (an even number of entries: the vectors are compared word-wise)
+                  v[i] = i < ZH_VEC_LIVE ? (int16_t)(uint16_t)(ws.ring[row][(x + i) % ZH_RING] - base0) : (int16_t)0;
+            }
+         }
+      }
       zh_sync();
    }
 #undef ZH_NEXT_TILE
+      if (!SEG) break;
+      // ---- the task's waves are counted; the last one checks the cuts, right to left ----------------------------------------
+      __threadfence();   // this round's parse entries and vectors are out
+      if (!seg_checker) {
+         uint32_t old = 0;
+         if (lane == 0) old = atomicAdd(seg_done, 1u);
+         old = zh_readfirstlane(old);
+         if ((old + 1u) % ((seg_K + ZH_CUT_ROWS - 1u) / ZH_CUT_ROWS) != 0u) return;   // (the counter runs on over the passes)
+         __threadfence();   // ... and the other waves' are in
+         seg_checker = true;
+         seg_exact = seg_K - 1u;   // the last segment started from the task's end: exact
+      }
+      bool again = false;
+      while (seg_exact > 0) {
+         const uint32_t k = seg_exact - 1u;
+         const uint32_t *vs = (const uint32_t *)(vecs + (uint64_t)(seg_slot0 + k) * (2u * ZH_VEC));               // speculated at the cut
+         const uint32_t *vl = (const uint32_t *)(vecs + (uint64_t)(seg_slot0 + k + 1u) * (2u * ZH_VEC) + ZH_VEC);   // computed by the (exact) right neighbour
+         bool bad = false;
+         for (uint32_t i = lane; i < (ZH_VEC_LIVE + 1u) / 2u; i += 64) bad |= zh_load_agent_u32(vs + i) != zh_load_agent_u32(vl + i);
+         seg_exact = k;
+         if (zh_ballot(bad)) {
+            again = true;
+            break;
+         }
+      }
+      if (!again) break;
+      zh_sync();
+      if (lane == 0) {
+         const uint32_t k = seg_exact;
+         const uint32_t b = t1 - (seg_K - 1u - k) * ZH_CUT_LEN;
+         ws.bnd[0] = k ? b - ZH_CUT_LEN : t0;
+         ws.bnd[8] = b;
+         ws.bnd[16] = sb_end;
+         ws.bnd[24] = 0xFFFFFFFFu;
+         ws.bnd[32] = (seg_slot0 + k) | (k ? 0x80000000u : 0u);
+         atomicAdd(seg_failed, 1u);   // statistics
+      }
+      np = 1;
+      seg_import = true;
+      zh_sync();
+   }
 
-   // ---- histogram of the task's parse; the per-sub-block sum is taken by zh_sb_build -------------------------------
+   // ---- histogram of the task's parse; the per-sub-block sum is taken by zh_sb_build ------------------------------------
    if (st->is_dynamic) {
       __threadfence_block();
       zh_sync();
@@ -396,15 +541,15 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
 // ticket == NULL: one workgroup (= one wave) per task, the grid covers the task list. Otherwise the workgroups are persistent and
 // take tasks from *ticket: the host launches a BOUNDED number of them per CU when the pass also has chains (zh_parse_chain.h) —
 // a grid of tens of thousands of single-wave workgroups keeps every wave slot, register and LDS granule of the chip taken, and
-// the four-wave workgroup that carries the longest chain of the batch would wait for room until the grid has drained
-// (measured, tools/probes/chain2_probe.hip: a 3.6 ms chain next to such a grid ended after 25 ms).
+// the four-wave workgroup that carries the longest chain of the batch would wait for room until the grid has drained (measured,
+// tools/probes/chain2_probe.hip: a 3.6 ms chain next to such a grid ended after 25 ms).
 __global__ void __launch_bounds__(64)
 zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match,
                uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
-               const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total, const zh_sbstate_t *__restrict__ states,
+               const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states,
                uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket) {
    __shared__ zh_parse_ws_t ws;
-   const uint32_t ntasks = *ntasks_total;
+   const uint32_t ntasks = cnt[ZH_CNT_TASKS];
    for (;;) {
       uint32_t gt = blockIdx.x;
       if (ticket) {
@@ -413,7 +558,23 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       }
       if (gt >= ntasks) return;
       zh_sync();   // (persistent form) the previous task is done with the workspace
-      zh_parse_one_task(ws, gt, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass);
+      zh_parse_one_task<false>(ws, gt, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, 0u, 0u, 0u,
+                               (int16_t *)NULL, (uint32_t *)NULL, (uint32_t *)NULL);
       if (!ticket) return;
    }
+}
+
+// The cut tasks (see "speculative segments" above): one workgroup (= one wave) per entry of segwaves, four segments each; the
+// wave that finishes a task checks it. Launched next to zh_parse_tasks and zh_parse_chain, on a stream of its own.
+__global__ void __launch_bounds__(64)
+zh_parse_segments(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
+                  const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
+                  const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint4 *segtasks,
+                  const uint2 *__restrict__ segwaves, int16_t *vecs, uint32_t *cnt) {
+   __shared__ zh_parse_ws_t ws;
+   if (blockIdx.x >= cnt[ZH_CNT_SEGWAVES]) return;
+   const uint2 sw = segwaves[blockIdx.x];
+   const uint4 stask = segtasks[sw.x];
+   zh_parse_one_task<true>(ws, stask.x, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, stask.y, sw.y,
+                           stask.z, vecs, &segtasks[sw.x].w, cnt + ZH_CNT_SEG_FAILED);
 }

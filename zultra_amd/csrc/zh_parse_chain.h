@@ -39,41 +39,13 @@
 #define ZH_CHAIN_VLONG_TASK 24576u  // positions: listed tasks longer than this get the first tickets ...
 #define ZH_CHAIN_LONG_TASK 6144u    // ... those longer than this the next ones
 
-// ---- speculative segments -------------------------------------------------------------------------------------------------
-// A chain of 64 Ki positions is 3.7 ms of one wave, four times per batch: the longest chain IS the pass. But the recurrence
-// forgets: started W positions to the right of a cut b with made-up costs (here: as if the sub-block ended at b + W), the
-// DIFFERENCES cost[b + i] - cost[b], i = 0..258, usually come out exactly as the true ones — on text with long repeats the
-// optimal paths of neighbouring positions funnel through common points within a few hundred positions (measured on the
-// bench's text corpus, W = 1024: 131 of 137 cuts; the exception is periodic data, where every match is 258 long, the costs
-// of positions 258 apart are copies of each other and nothing is ever forgotten). And the choices left of b depend on the costs
-// at b .. b+258 through their differences only (every comparison is between sums that share the constant — the argument that
-// makes barriers restart points, zh_parse.h). So a long task [t0, t1) is cut at b_k = t1 - (K-1-k) ZH_CUT_LEN into K segments,
-// each parsed by its own workgroup: segment k starts at b_k + ZH_CUT_WARM, stores no parse entries above b_k, records the
-// relative costs of [b_k, b_k + 258] as it passes (speculated) and those of [b_{k-1}, b_{k-1} + 258] when it is done (its own
-// left end). zh_parse_chain_fix then walks each cut task from the right: the last segment is exact by construction; segment k
-// is exact if segment k+1 is and its speculated vector equals segment k+1's left one; otherwise it is parsed again from that
-// (exact) vector. The output is the reference's parse bit for bit either way; speculation only decides how much of it was
-// computed in parallel. Periodic tasks (most positions offer a 258-byte match) are not cut: their cuts would all fail.
-#ifndef ZH_CUT_LEN
-#define ZH_CUT_LEN 4096u          // positions per segment (a multiple of ZH_CHAIN_TILE)
-#endif
-#ifndef ZH_CUT_WARM
-#define ZH_CUT_WARM 1024u     // warm-up positions right of a cut (a multiple of ZH_CHAIN_TILE, 288 .. ZH_CUT_LEN)
-#endif
-#define ZH_CUT_MIN (2u * ZH_CUT_LEN)   // tasks shorter than this stay whole
+// ---- segments of cut tasks (see "speculative segments", zh_parse.h) as chain jobs ---------------------------------------------
+// When a run has few cut tasks their segments are latency, not throughput: a four-wave chain workgroup prices a position in
+// 0.054 us, a row of zh_parse_segments in about 0.3 us. The host then hands the segments to zh_parse_chain (a segment = a job
+// with a made-up end, a limit for its parse entries and vectors to record) and the checking to zh_parse_chain_fix.
 #ifndef ZH_TRACE_SLOTS
 #define ZH_TRACE_SLOTS 4096u
 #endif
-#define ZH_VEC 264u           // int16 entries per cost vector: cost[x + i] - cost[x], i = 0..258 (+ padding)
-#define ZH_VEC_LIVE 259u
-#define ZH_VEC_BIAS 4096      // imported costs are (bias + difference) << 9: differences are below 258 x 15 in magnitude
-
-// per segmented task (zh_list_huge): x = task, y = number of segments, z = first vector slot (one slot = spec + left vector)
-// counters of a run (device: uint32 per field; one block of ZH_CNT_STRIDE words per run)
-enum {
-   ZH_CNT_TASKS = 0, ZH_CNT_VLONG, ZH_CNT_LONG, ZH_CNT_SHORT, ZH_CNT_HUGE_POS, ZH_CNT_SEGTASKS, ZH_CNT_SEGITEMS, ZH_CNT_SEG_FAILED,
-   ZH_CNT_CHAIN_TICKET = 8, ZH_CNT_TASK_TICKET = 12, ZH_CNT_FIX_TICKET = 16, ZH_CNT_STRIDE = 32
-};
 
 struct zh_chain_job_t {
    uint32_t t0, t1;        // positions to price: [t0, t1), from t1 - 1 down
@@ -443,12 +415,13 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
 }
 
 // the tasks zh_parse_tasks leaves alone: one wave per task, the same piece computation. cnt = the run's counters (ZH_CNT_*).
-// Tasks of at least seg_min positions that are not periodic are cut into segments (see the top of this file): listed in segtasks,
-// one entry of segitems per segment.
+// Tasks of at least seg_min positions that are not periodic are cut into segments (zh_parse.h): listed in segtasks, with one
+// entry of segitems per segment (for zh_parse_chain) and one entry of segwaves per four segments (for zh_parse_segments): the
+// host picks one of the two ways by the number of segments in the run.
 __global__ void __launch_bounds__(64)
 zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
              const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ longest, uint64_t longest_stride, uint32_t *hugelist, uint32_t cap, uint4 *segtasks,
-             uint2 *segitems, uint32_t seg_min, uint32_t *cnt) {
+             uint2 *segitems, uint2 *segwaves, uint32_t seg_min, uint32_t *cnt) {
    __shared__ uint32_t bnd[ZH_MAXPIECES + 1];
    const uint32_t gt = blockIdx.x;
    if (gt >= cnt[ZH_CNT_TASKS]) return;
@@ -470,18 +443,21 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
       for (uint32_t p = t0 + lane; p < t1; p += 64) full += (lg[p - prev] & 0xffffu) >= ZH_MAX_MATCH ? 1u : 0u;
       full = zh_wave_sum(full);
       if (2u * full <= len) {
-         const uint32_t K = len / ZH_CUT_LEN;   // >= 2; segment 0 takes the remainder too
-         uint32_t ti = 0, it = 0;
+         const uint32_t K = (len + ZH_CUT_LEN - 1u) / ZH_CUT_LEN;   // >= 2; segment 0 is the short one
+         const uint32_t nw = (K + ZH_CUT_ROWS - 1u) / ZH_CUT_ROWS;   // waves of zh_parse_segments
+         uint32_t ti = 0, w0 = 0, it = 0;
          if (lane == 0) {
             ti = atomicAdd(&cnt[ZH_CNT_SEGTASKS], 1u);
+            w0 = atomicAdd(&cnt[ZH_CNT_SEGWAVES], nw);
             it = atomicAdd(&cnt[ZH_CNT_SEGITEMS], K);
-            segtasks[ti] = make_uint4(gt, K, it, 0u);   // vector slot of segment k = its item index
+            segtasks[ti] = make_uint4(gt, K, it, 0u);   // vector slot of segment k = it + k
             atomicAdd(&cnt[ZH_CNT_HUGE_POS], len);      // statistics only (zultra_hip_last_stats)
          }
          ti = zh_readfirstlane(ti);
+         w0 = zh_readfirstlane(w0);
          it = zh_readfirstlane(it);
-         // the exact (rightmost) segment and the long first one get the earliest tickets of their task
-         for (uint32_t k = lane; k < K; k += 64) segitems[it + k] = make_uint2(ti, K - 1u - k);
+         if (lane < nw) segwaves[w0 + lane] = make_uint2(ti, lane * ZH_CUT_ROWS);
+         for (uint32_t k = lane; k < K; k += 64) segitems[it + k] = make_uint2(ti, K - 1u - k);   // (the exact, rightmost one first)
          return;
       }
    }
@@ -568,12 +544,12 @@ __global__ void __launch_bounds__(ZH_CHAIN_THREADS)
 zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
                const uint32_t *__restrict__ hugelist, uint32_t cap, const uint4 *__restrict__ segtasks, const uint2 *__restrict__ segitems, int16_t *vecs,
-               const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass,
-               uint32_t *ticket, uint64_t *trace /* diagnostics (ZULTRA_HIP_CHAIN_TRACE): per ticket {positions, start, end} on the 100 MHz clock, or NULL */) {
+               uint32_t nseg /* the run's segments if they are parsed here, else 0 */, const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states,
+               uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket, uint64_t *trace /* diagnostics (ZULTRA_HIP_CHAIN_TRACE): per ticket {positions, start, end} on the 100 MHz clock, or NULL */) {
    __shared__ zh_chain_ws_t ws;
    __shared__ uint32_t s_item;
    const uint32_t tid = threadIdx.x;
-   const uint32_t nvlong = cnt[ZH_CNT_VLONG], nlong = cnt[ZH_CNT_LONG], nseg = cnt[ZH_CNT_SEGITEMS], count = nvlong + nlong + nseg + cnt[ZH_CNT_SHORT];
+   const uint32_t nvlong = cnt[ZH_CNT_VLONG], nlong = cnt[ZH_CNT_LONG], count = nvlong + nlong + nseg + cnt[ZH_CNT_SHORT];
    for (;;) {
       __syncthreads();   // the previous task's histogram has left LDS, s_item has been read
       if (tid == 0) s_item = atomicAdd(ticket, 1u);
