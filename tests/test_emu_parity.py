@@ -51,13 +51,14 @@ def test_stages_vs_oracle(emu, oracle, case):
     check_window(emu, oracle, gen(), prev, n, tag=name)
 
 
-@pytest.mark.parametrize("wide", ["1", "1000000"], ids=["as_waves_of_zh_parse_segments", "as_jobs_of_zh_parse_chain"])
+@pytest.mark.parametrize("wide", ["1", "1000000", "whole"], ids=["as_waves_of_zh_parse_segments", "as_jobs_of_zh_parse_chain", "few_and_short_stay_whole"])
 def test_chain_segments_are_both_accepted_and_redone(emu, oracle, monkeypatch, wide):
     """The speculative segments of long barrier-free tasks (zh_parse.h; the emulator build cuts every 512 positions with a
     288-position warm-up), parsed either way the host may choose (ZULTRA_HIP_SEG_WIDE = the number of segments in a run from
     which they go to zh_parse_segments): on table-like data some cuts verify and some segments are parsed again, and the parse
     is the reference's either way."""
-    monkeypatch.setenv("ZULTRA_HIP_SEG_WIDE", wide)
+    monkeypatch.setenv("ZULTRA_HIP_SEG_WIDE", "1000000" if wide == "whole" else wide)
+    monkeypatch.setenv("ZULTRA_HIP_SEG_WHOLE", "1000000" if wide == "whole" else "0")
     data = corpus.table_like(30000, 9)
     check_window(emu, oracle, data, 0, 30000, tag="table_cut/" + wide)
     ctx = emu.context(32768, 1)
@@ -68,7 +69,10 @@ def test_chain_segments_are_both_accepted_and_redone(emu, oracle, monkeypatch, w
         ctx.close()
     cuts = st["cut_segments"] - st["cut_tasks"]
     assert st["cut_tasks"] >= 1 and cuts >= 8
-    assert 0 < st["cut_redone"] < 4 * cuts, st
+    if wide == "whole":
+        assert st["cut_redone"] == 0, st
+    else:
+        assert 0 < st["cut_redone"] < 4 * cuts, st
 
 
 @pytest.mark.parametrize("name", ["tiny_100", "one_byte", "two_bytes", "json_4k", "json_4k_b"])

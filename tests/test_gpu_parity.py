@@ -60,12 +60,13 @@ def test_stages_vs_oracle(gpu, oracle, case):
     check_window(gpu, oracle, gen(), prev, n, max_block=bs, tag=name)
 
 
-@pytest.mark.parametrize("wide", ["1", "1000000"], ids=["as_waves_of_zh_parse_segments", "as_jobs_of_zh_parse_chain"])
+@pytest.mark.parametrize("wide", ["1", "1000000", "whole"], ids=["as_waves_of_zh_parse_segments", "as_jobs_of_zh_parse_chain", "few_and_short_stay_whole"])
 def test_chain_tasks_are_cut_into_speculative_segments(gpu, oracle, monkeypatch, wide):
     """zh_parse.h: barrier-free runs of table-like text are parsed as segments started 1024 positions early — as waves of
     zh_parse_segments or as jobs of zh_parse_chain, by the number of segments in the run (ZULTRA_HIP_SEG_WIDE); the parse is the
     oracle's either way and most of the cuts must verify."""
-    monkeypatch.setenv("ZULTRA_HIP_SEG_WIDE", wide)
+    monkeypatch.setenv("ZULTRA_HIP_SEG_WIDE", "1000000" if wide == "whole" else wide)
+    monkeypatch.setenv("ZULTRA_HIP_SEG_WHOLE", "1000000" if wide == "whole" else "0")
     check_window(gpu, oracle, corpus.table_like(98304, 9), 32768, 65536, 65536, tag="table_cut/" + wide)
     check_window(gpu, oracle, corpus.table_like(300000, 10), 32768, 267232, 1 << 20, tag="table_cut_big/" + wide)
     ctx = gpu.context(65536, 4)

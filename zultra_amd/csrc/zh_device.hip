@@ -85,6 +85,8 @@ struct zultra_hip_ctx_s {
    uint4 *d_segtasks;           // tasks cut into speculative segments (zh_parse_chain.h): per max-block seg_tasks_per_block entries
    uint2 *d_segitems;           // their segments, as jobs of zh_parse_chain: per max-block seg_items_per_block entries
    uint2 *d_segwaves;           // ... or as waves of zh_parse_segments (four segments each), likewise
+   uint32_t cut_min;            // tasks of at least this many positions are cut into segments
+   uint32_t seg_whole;          // ... with fewer, zh_parse_chain takes the segments — and the cut tasks shorter than this whole (ZULTRA_HIP_SEG_WHOLE)
    uint32_t seg_wide;           // a run with at least this many segments parses them with zh_parse_segments (ZULTRA_HIP_SEG_WIDE)
    int16_t *d_vecs;             // two cost vectors per segment
    uint64_t seg_tasks_per_block, seg_items_per_block;
@@ -402,6 +404,11 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
          if (zh_alloc(c, &c->d_chain_trace, (size_t)3 * ZH_TRACE_SLOTS * 16)) return -1;
          ZH_CHECK(c, hipMemset(c->d_chain_trace, 0, (size_t)3 * ZH_TRACE_SLOTS * 16 * sizeof(uint64_t)));
       }
+      const char *cm = getenv("ZULTRA_HIP_CUT_MIN");   // tuning experiments: tasks of at least this many positions are cut (>= 2 * ZH_CUT_WARM)
+      c->cut_min = cm ? (uint32_t)atoi(cm) : (uint32_t)ZH_CUT_MIN;
+      if (c->cut_min < 2u * ZH_CUT_WARM) c->cut_min = 2u * ZH_CUT_WARM;
+      const char *swh = getenv("ZULTRA_HIP_SEG_WHOLE");   // (tuning experiments)
+      c->seg_whole = swh ? (uint32_t)atoi(swh) : 16384u;
       const char *sw = getenv("ZULTRA_HIP_SEG_WIDE");
       c->seg_wide = sw ? (uint32_t)atoi(sw) : 1024u;
       const char *tw = getenv("ZULTRA_HIP_TASK_WAVES");
@@ -453,9 +460,9 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    }
    c->bar_stride = c->tok_stride / 64;
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
-   // a cut task has at least ZH_CUT_MIN positions and lies inside one max-block; its segments have at least ZH_CUT_LEN each
-   c->seg_tasks_per_block = c->files_mode ? 1 : N / ZH_CUT_MIN + 1;
-   c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_LEN + N / ZH_CUT_MIN + 2;   // a task of len positions has ceil(len / ZH_CUT_LEN) segments
+   // a cut task has at least 2 * ZH_CUT_WARM positions (the floor of ZULTRA_HIP_CUT_MIN) and lies inside one max-block
+   c->seg_tasks_per_block = c->files_mode ? 1 : N / (2u * ZH_CUT_WARM) + 1;
+   c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_LEN + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;   // a task of len positions has at most len / ZH_CUT_LEN + ZH_CUT_ROWS segments
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
        zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, c->max_tasks) ||
@@ -681,7 +688,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
       ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[0][2 * pass], 0));
       ZH_LAUNCH(zh_parse_chain, min(nb, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride,
                 (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_hugelist, task_grid,
-                (const uint4 *)c->d_segtasks, (const uint2 *)c->d_segitems, c->d_vecs, 0u, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
+                c->d_segtasks, (const uint2 *)c->d_segitems, c->d_vecs, 0u, 0u, c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
                 c->best_stride, c->d_hist_part, pass, c->d_ntasks + ZH_CNT_CHAIN_TICKET + pass, (uint64_t *)NULL);
       ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass + 1], side));
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride,
@@ -896,14 +903,14 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
       ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
       ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, segtasks, segitems, segwaves, (uint32_t)ZH_CUT_MIN, ntasks);
+                (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, ntasks);
       // Does this run have chains at all? With none (text without long repeats) zh_parse_tasks gets the whole chip; with chains it
       // runs as a bounded number of persistent waves per CU, so that the chain workgroups find room the moment they are launched.
       ZH_CHECK(c, hipMemcpyAsync(h_cnt, ntasks, ZH_CNT_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipEventRecord(ev[5], st));
       ZH_CHECK(c, hipEventSynchronize(ev[5]));
       // The cut tasks (zh_parse.h): many segments are throughput — four to a wave of zh_parse_segments, which also checks them; a few
-      // are latency — each one a job of zh_parse_chain (five times faster per position), checked by zh_parse_chain_fix after it.
+      // are latency — each one a job of zh_parse_chain (five times faster per position), which checks a task when its last segment is done.
       const uint32_t nsegtasks = h_cnt[ZH_CNT_SEGTASKS], nsegs = h_cnt[ZH_CNT_SEGITEMS];
       const bool seg_wide = nsegtasks && nsegs >= c->seg_wide;
       const uint32_t nseg_chain = (nsegtasks && !seg_wide) ? nsegs : 0u;
@@ -917,13 +924,9 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
             ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
             ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
             ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                      (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, (const uint4 *)segtasks, (const uint2 *)segitems, vecs, nseg_chain,
-                      (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, ntasks + ZH_CNT_CHAIN_TICKET + pass,
+                      (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, segtasks, (const uint2 *)segitems, vecs, nseg_chain, c->seg_whole,
+                      ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, ntasks + ZH_CNT_CHAIN_TICKET + pass,
                       c->d_chain_trace ? c->d_chain_trace + 3 * (uint64_t)ZH_TRACE_SLOTS * (4 * k + pass) : (uint64_t *)NULL);
-            if (nseg_chain)
-               ZH_LAUNCH(zh_parse_chain_fix, min(nsegtasks, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride,
-                         (const zh_work_t *)work, (const uint2 *)taskmap, (const uint4 *)segtasks, vecs, ntasks, (const zh_sbstate_t *)states, best, c->best_stride,
-                         hist_part, pass, ntasks + ZH_CNT_FIX_TICKET + pass);
             ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
          }
          if (seg_wide) {

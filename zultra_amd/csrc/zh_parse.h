@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t zh_ring_wrap(uint32_t x) { return min(x, x -
 // exception is data where nearly every position offers a 258-byte match: the costs of positions 258 apart copy each other and
 // nothing is ever forgotten). And the choices left of b depend on the costs at b .. b+258 through their differences only (every
 // comparison is between sums that share the constant — the argument that makes barriers restart points, see the top of this
-// file). So a long task [t0, t1) whose longest matches are mostly shorter than 258 is cut at b_k = t1 - (K-1-k) ZH_CUT_LEN into K
+// file). So a long task [t0, t1) whose longest matches are mostly shorter than 258 is cut at b_k = t1 - (K-1-k) S into K
 // segments, and the segments are PIECES like any other: four of them share a wave of zh_parse_tasks, one per row. Segment k
 // starts at b_k + ZH_CUT_WARM, stores no parse entries at or above b_k, records the relative costs of [b_k, b_k + 258] as it
 // passes (speculated) and those of [b_{k-1}, b_{k-1} + 258] when it is done (its own left end). zh_parse_chain_fix
@@ -73,13 +73,17 @@ __device__ __forceinline__ uint32_t zh_ring_wrap(uint32_t x) { return min(x, x -
 // vector, as a chain. The output is the reference's parse bit for bit either way; speculation only decides how much of it was
 // computed in parallel.
 #ifndef ZH_CUT_LEN
-#define ZH_CUT_LEN 4096u          // positions per segment (a multiple of 32)
+#define ZH_CUT_LEN 4096u          // positions per segment, about (zh_list_huge picks the number of segments, then their length)
 #endif
 #ifndef ZH_CUT_WARM
 #define ZH_CUT_WARM 1024u         // warm-up positions right of a cut (a multiple of 32, 288 .. ZH_CUT_LEN)
 #endif
-#define ZH_CUT_MIN (2u * ZH_CUT_LEN)   // tasks shorter than this stay whole
-#define ZH_CUT_ROWS 4u            // segments per wave of zh_parse_tasks
+#define ZH_CUT_MIN ZH_CUT_LEN      // tasks shorter than this stay whole (measured on JSON-like records, 50 MB: 8192 -> 45.4 ms, 4096 -> 43.6 ms, 2048 -> 43.3 ms)
+#define ZH_CUT_ROWS 4u            // segments per wave of zh_parse_segments
+// segtasks[].y: number of segments | their length / 32 << 12
+#define ZH_CUT_PACK(K, S) ((K) | (((S) >> 5) << 12))
+#define ZH_CUT_K(y) ((y) & 0xfffu)
+#define ZH_CUT_S(y) (((y) >> 12) << 5)
 #define ZH_VEC 264u               // int16 entries per cost vector: cost[x + i] - cost[x], i = 0..258 (+ padding)
 #define ZH_VEC_LIVE 259u
 #define ZH_VEC_BIAS 4096          // imported costs are (bias + difference) << 9: differences are below 258 x 15 in magnitude
@@ -289,8 +293,9 @@ template <bool SEG>
 __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
                                          const zh_match_t *__restrict__ match, uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride,
                                          const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
-                                         uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t seg_K, uint32_t seg_k0, uint32_t seg_slot0,
+                                         uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t seg_KS, uint32_t seg_k0, uint32_t seg_slot0,
                                          int16_t *vecs, uint32_t *seg_done, uint32_t *seg_failed) {
+   const uint32_t seg_K = ZH_CUT_K(seg_KS), seg_S = ZH_CUT_S(seg_KS);
    const uint2 tm = taskmap[gt];
    const zh_work_t wk = work[tm.x];
    const zh_sbstate_t *st = states + tm.x;
@@ -333,8 +338,8 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
       if (lane < np) {
          const uint32_t k = seg_k0 + lane;
          const bool last = k + 1u == seg_K;
-         const uint32_t b = t1 - (seg_K - 1u - k) * ZH_CUT_LEN;
-         ws.bnd[lane] = k ? b - ZH_CUT_LEN : t0;
+         const uint32_t b = t1 - (seg_K - 1u - k) * seg_S;
+         ws.bnd[lane] = k ? b - seg_S : t0;
          ws.bnd[8 + lane] = last ? t1 : b + ZH_CUT_WARM;
          ws.bnd[16 + lane] = last ? sb_end : b + ZH_CUT_WARM;
          ws.bnd[24 + lane] = last ? 0xFFFFFFFFu : b;
@@ -513,8 +518,8 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
       zh_sync();
       if (lane == 0) {
          const uint32_t k = seg_exact;
-         const uint32_t b = t1 - (seg_K - 1u - k) * ZH_CUT_LEN;
-         ws.bnd[0] = k ? b - ZH_CUT_LEN : t0;
+         const uint32_t b = t1 - (seg_K - 1u - k) * seg_S;
+         ws.bnd[0] = k ? b - seg_S : t0;
          ws.bnd[8] = b;
          ws.bnd[16] = sb_end;
          ws.bnd[24] = 0xFFFFFFFFu;

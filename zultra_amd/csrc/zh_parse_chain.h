@@ -42,7 +42,8 @@
 // ---- segments of cut tasks (see "speculative segments", zh_parse.h) as chain jobs ---------------------------------------------
 // When a run has few cut tasks their segments are latency, not throughput: a four-wave chain workgroup prices a position in
 // 0.054 us, a row of zh_parse_segments in about 0.3 us. The host then hands the segments to zh_parse_chain (a segment = a job
-// with a made-up end, a limit for its parse entries and vectors to record) and the checking to zh_parse_chain_fix.
+// with a made-up end, a limit for its parse entries and vectors to record); the workgroup that finishes a task's last
+// segment checks the task (zh_chain_check_task).
 #ifndef ZH_TRACE_SLOTS
 #define ZH_TRACE_SLOTS 4096u
 #endif
@@ -443,14 +444,19 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
       for (uint32_t p = t0 + lane; p < t1; p += 64) full += (lg[p - prev] & 0xffffu) >= ZH_MAX_MATCH ? 1u : 0u;
       full = zh_wave_sum(full);
       if (2u * full <= len) {
-         const uint32_t K = (len + ZH_CUT_LEN - 1u) / ZH_CUT_LEN;   // >= 2; segment 0 is the short one
+         // K segments of S positions, segment 0 the short one: as many as fill whole waves of zh_parse_segments (ZH_CUT_ROWS each)
+         // with about ZH_CUT_LEN positions per row
+         uint32_t K = ZH_CUT_ROWS * ((len + ZH_CUT_ROWS * ZH_CUT_LEN - 1u) / (ZH_CUT_ROWS * ZH_CUT_LEN));
+         if (len / K < ZH_CUT_WARM) K = max(2u, len / ZH_CUT_WARM);   // (a segment is never shorter than the warm-up)
+         const uint32_t S = ((len + K - 1u) / K + 31u) & ~31u;
+         K = (len + S - 1u) / S;
          const uint32_t nw = (K + ZH_CUT_ROWS - 1u) / ZH_CUT_ROWS;   // waves of zh_parse_segments
          uint32_t ti = 0, w0 = 0, it = 0;
          if (lane == 0) {
             ti = atomicAdd(&cnt[ZH_CNT_SEGTASKS], 1u);
             w0 = atomicAdd(&cnt[ZH_CNT_SEGWAVES], nw);
             it = atomicAdd(&cnt[ZH_CNT_SEGITEMS], K);
-            segtasks[ti] = make_uint4(gt, K, it, 0u);   // vector slot of segment k = it + k
+            segtasks[ti] = make_uint4(gt, ZH_CUT_PACK(K, S), it, 0u);   // vector slot of segment k = it + k
             atomicAdd(&cnt[ZH_CNT_HUGE_POS], len);      // statistics only (zultra_hip_last_stats)
          }
          ti = zh_readfirstlane(ti);
@@ -536,6 +542,40 @@ __device__ __forceinline__ void zh_chain_histogram(zh_chain_ws_t &ws, const zh_c
    for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) hp[k] = ws.hist[k];
 }
 
+// The workgroup that finishes the last segment of a cut task checks the task: accept the segments whose speculated costs match
+// what their right neighbour left, parse the others again from there, then take the task's histogram. All threads call; the
+// prices of the pass are in ws.
+__device__ inline void zh_chain_check_task(zh_chain_ws_t &ws, uint32_t *s_bad_p, const zh_chain_task_t &T, uint32_t gt, uint32_t K, uint32_t S, uint32_t slot0, int16_t *vecs,
+                                           uint32_t *cnt, uint32_t *hist_part) {
+   const uint32_t tid = threadIdx.x;
+   for (uint32_t k = K - 1u; k-- > 0;) {
+      int16_t *v = vecs + (uint64_t)(slot0 + k) * (2u * ZH_VEC);
+      const int16_t *right = v + 2u * ZH_VEC + ZH_VEC;   // the left-end vector of segment k + 1: exact by now
+      if (tid == 0) *s_bad_p = 0;
+      __syncthreads();
+      for (uint32_t i = tid; i < (ZH_VEC_LIVE + 1u) / 2u; i += ZH_CHAIN_THREADS)
+         if (zh_load_agent_u32((const uint32_t *)v + i) != zh_load_agent_u32((const uint32_t *)right + i)) *s_bad_p = 1;
+      __syncthreads();
+      if (!*s_bad_p) continue;
+      // parse the segment again, from the true costs
+      zh_chain_job_t job;
+      const uint32_t b = T.t1 - (K - 1u - k) * S;
+      job.t0 = k ? b - S : T.t0;
+      job.t1 = b;
+      job.clamp = T.sb_end;
+      job.store_hi = 0xFFFFFFFFu;
+      job.import = right;
+      job.export_spec = NULL;
+      job.export_left = k ? v + ZH_VEC : (int16_t *)NULL;
+      __syncthreads();   // (s_bad has been read)
+      zh_chain_parse(ws, T.rows, T.rows_hi, T.win, T.prev, job, T.best);
+      if (tid == 0) atomicAdd(&cnt[ZH_CNT_SEG_FAILED], 1u);
+      __threadfence();
+      __syncthreads();   // the new left vector is visible to the next comparison; the workspace is free
+   }
+   if (T.st->is_dynamic) zh_chain_histogram(ws, T, hist_part + (uint64_t)gt * ZH_NSYM);
+}
+
 // Persistent workgroups take the listed items from a ticket: the grid is small and fixed (ZH_CHAIN_GRID), so it is dispatched at
 // once — next to zh_parse_tasks' tens of thousands of waves — and every chain starts at the beginning of the pass. Ticket order:
 // the whole tasks of the two long classes, the segments of the cut tasks, the short whole tasks.
@@ -543,11 +583,12 @@ __device__ __forceinline__ void zh_chain_histogram(zh_chain_ws_t &ws, const zh_c
 __global__ void __launch_bounds__(ZH_CHAIN_THREADS)
 zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
-               const uint32_t *__restrict__ hugelist, uint32_t cap, const uint4 *__restrict__ segtasks, const uint2 *__restrict__ segitems, int16_t *vecs,
-               uint32_t nseg /* the run's segments if they are parsed here, else 0 */, const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states,
+               const uint32_t *__restrict__ hugelist, uint32_t cap, uint4 *segtasks, const uint2 *__restrict__ segitems, int16_t *vecs,
+               uint32_t nseg /* the run's segments if they are parsed here, else 0 */, uint32_t seg_whole /* ... cut tasks shorter than this as one job */,
+               uint32_t *cnt, const zh_sbstate_t *__restrict__ states,
                uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket, uint64_t *trace /* diagnostics (ZULTRA_HIP_CHAIN_TRACE): per ticket {positions, start, end} on the 100 MHz clock, or NULL */) {
    __shared__ zh_chain_ws_t ws;
-   __shared__ uint32_t s_item;
+   __shared__ uint32_t s_item, s_bad;
    const uint32_t tid = threadIdx.x;
    const uint32_t nvlong = cnt[ZH_CNT_VLONG], nlong = cnt[ZH_CNT_LONG], count = nvlong + nlong + nseg + cnt[ZH_CNT_SHORT];
    for (;;) {
@@ -557,13 +598,15 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       const uint32_t item = s_item;
       if (item >= count) return;
       const bool is_seg = item >= nvlong + nlong && item < nvlong + nlong + nseg;
-      uint32_t gt, K = 1, k = 0, slot = 0;
+      uint32_t gt, K = 1, S = 0, k = 0, slot = 0, ti = 0;
       if (is_seg) {
          slot = item - nvlong - nlong;
          const uint2 si = segitems[slot];
-         const uint4 stask = segtasks[si.x];
+         ti = si.x;
+         const uint4 stask = segtasks[ti];
          gt = stask.x;
-         K = stask.y;
+         K = ZH_CUT_K(stask.y);
+         S = ZH_CUT_S(stask.y);
          k = si.y;
          slot = stask.z + k;
       }
@@ -580,10 +623,16 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       job.import = NULL;
       job.export_spec = NULL;
       job.export_left = NULL;
-      if (is_seg) {
+      bool whole = !is_seg;
+      if (is_seg && T.t1 - T.t0 < seg_whole) {
+         // a few short cut tasks: a chain of this length is over before the check of its segments would be
+         if (k + 1u != K) continue;
+         whole = true;
+      }
+      else if (is_seg) {
          int16_t *v = vecs + (uint64_t)slot * (2u * ZH_VEC);   // [0]: speculated at the segment's right end, [1]: its left end
-         const uint32_t b = T.t1 - (K - 1u - k) * ZH_CUT_LEN;     // the segment's right end
-         job.t0 = k ? b - ZH_CUT_LEN : T.t0;
+         const uint32_t b = T.t1 - (K - 1u - k) * S;     // the segment's right end
+         job.t0 = k ? b - S : T.t0;
          if (k) job.export_left = v + ZH_VEC;
          if (k + 1u < K) {
             job.t1 = job.clamp = b + ZH_CUT_WARM;            // as if the sub-block ended there
@@ -598,60 +647,18 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          trace[3 * (uint64_t)item + 1] = trace_t0;
          trace[3 * (uint64_t)item + 2] = zh_wall_clock();
       }
-      if (!is_seg && T.st->is_dynamic) zh_chain_histogram(ws, T, hist_part + (uint64_t)gt * ZH_NSYM);
+      if (whole) {
+         if (T.st->is_dynamic) zh_chain_histogram(ws, T, hist_part + (uint64_t)gt * ZH_NSYM);
+         continue;
+      }
+      // a segment: the task's segments are counted (the counter runs on over the passes), the workgroup that finishes the last one checks them
+      __threadfence();   // this segment's parse entries and vectors are out
+      __syncthreads();
+      if (tid == 0) s_bad = (atomicAdd(&segtasks[ti].w, 1u) + 1u) % K;
+      __syncthreads();
+      if (s_bad != 0) continue;
+      __threadfence();   // ... and the other segments' are in
+      zh_chain_check_task(ws, &s_bad, T, gt, K, S, slot - k, vecs, cnt, hist_part);
    }
 }
 
-// After zh_parse_chain: per cut task, accept the segments whose speculated costs match what their right neighbour left, parse the
-// others again from there, then take the task's histogram. One workgroup per task at a time.
-__global__ void __launch_bounds__(ZH_CHAIN_THREADS)
-zh_parse_chain_fix(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
-                   const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
-                   const uint4 *__restrict__ segtasks, int16_t *vecs, uint32_t *cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all,
-                   uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket) {
-   __shared__ zh_chain_ws_t ws;
-   __shared__ uint32_t s_item, s_bad;
-   const uint32_t tid = threadIdx.x;
-   const uint32_t count = cnt[ZH_CNT_SEGTASKS];
-   for (;;) {
-      __syncthreads();
-      if (tid == 0) s_item = atomicAdd(ticket, 1u);
-      __syncthreads();
-      const uint32_t item = s_item;
-      if (item >= count) return;
-      const uint4 stask = segtasks[item];
-      const uint32_t gt = stask.x, K = stask.y;
-      const zh_chain_task_t T = zh_chain_task(gt, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, pass);
-      if (T.skip) continue;
-      bool priced = false;
-      for (uint32_t k = K - 1u; k-- > 0;) {
-         int16_t *v = vecs + (uint64_t)(stask.z + k) * (2u * ZH_VEC);
-         const int16_t *right = v + 2u * ZH_VEC + ZH_VEC;   // the left-end vector of segment k + 1: exact by now
-         if (tid == 0) s_bad = 0;
-         __syncthreads();
-         for (uint32_t i = tid; i < (ZH_VEC_LIVE + 1u) / 2u; i += ZH_CHAIN_THREADS)
-            if (zh_load_agent_u32((const uint32_t *)v + i) != zh_load_agent_u32((const uint32_t *)right + i)) s_bad = 1;
-         __syncthreads();
-         if (!s_bad) continue;
-         // parse the segment again, from the true costs
-         if (!priced) {
-            zh_chain_prices(ws, T.st);
-            priced = true;
-         }
-         zh_chain_job_t job;
-         const uint32_t b = T.t1 - (K - 1u - k) * ZH_CUT_LEN;
-         job.t0 = k ? b - ZH_CUT_LEN : T.t0;
-         job.t1 = b;
-         job.clamp = T.sb_end;
-         job.store_hi = 0xFFFFFFFFu;
-         job.import = right;
-         job.export_spec = NULL;
-         job.export_left = k ? v + ZH_VEC : (int16_t *)NULL;
-         zh_chain_parse(ws, T.rows, T.rows_hi, T.win, T.prev, job, T.best);
-         if (tid == 0) atomicAdd(&cnt[ZH_CNT_SEG_FAILED], 1u);
-         __threadfence();
-         __syncthreads();   // the new left vector is visible to the next comparison; the workspace is free
-      }
-      if (T.st->is_dynamic) zh_chain_histogram(ws, T, hist_part + (uint64_t)gt * ZH_NSYM);
-   }
-}
