@@ -366,6 +366,20 @@ def test_two_threads_compress_different_streams(gpu, oracle):
             assert got[i][rep] == want[i], (i, rep)
 
 
+@pytest.mark.parametrize("runs", ["1", "3", "4"])
+def test_number_of_staggered_runs_does_not_change_the_bytes(gpu, monkeypatch, runs):
+    """zh_device.hip cuts a batch into ZULTRA_HIP_STREAMS staggered runs (default 2), each with its own block of device counters
+    (ZH_CNT_*): any number of runs yields the same stream. 24 MiB of table-like and repetitive text: chains and cut tasks in
+    every run."""
+    data = np.concatenate([corpus.table_like(8 << 20, 3), corpus.duplicated(8 << 20, 4, 900), corpus.text_like_fast(8 << 20, 5)])
+    monkeypatch.setenv("ZULTRA_HIP_CACHE", "0")   # a fresh context per call: the number of runs is fixed when it is created
+    gpu.L.zultra_release_cached_contexts()
+    want = gpu.memory_compress(data, 2, 65536)
+    assert zlib.decompress(want, 31) == data.tobytes()
+    monkeypatch.setenv("ZULTRA_HIP_STREAMS", runs)
+    assert gpu.memory_compress(data, 2, 65536) == want
+
+
 def test_bench_refuses_more_gpus_than_present(gpu):
     """`bench.py --gpus N` must never report a smaller job as N: on a box with fewer GPUs it fails loudly."""
     import os

@@ -85,6 +85,7 @@ struct zultra_hip_ctx_s {
    uint4 *d_segtasks;           // tasks cut into speculative segments (zh_parse_chain.h): per max-block seg_tasks_per_block entries
    uint2 *d_segitems;           // their segments, as jobs of zh_parse_chain: per max-block seg_items_per_block entries
    uint2 *d_segwaves;           // ... or as waves of zh_parse_segments (four segments each), likewise
+   uint32_t cut_len;            // ... into segments of about this many positions
    uint32_t cut_min;            // tasks of at least this many positions are cut into segments
    uint32_t seg_whole;          // ... with fewer, zh_parse_chain takes the segments — and the cut tasks shorter than this whole (ZULTRA_HIP_SEG_WHOLE)
    uint32_t seg_wide;           // a run with at least this many segments parses them with zh_parse_segments (ZULTRA_HIP_SEG_WIDE)
@@ -404,6 +405,10 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
          if (zh_alloc(c, &c->d_chain_trace, (size_t)3 * ZH_TRACE_SLOTS * 16)) return -1;
          ZH_CHECK(c, hipMemset(c->d_chain_trace, 0, (size_t)3 * ZH_TRACE_SLOTS * 16 * sizeof(uint64_t)));
       }
+      const char *cl = getenv("ZULTRA_HIP_CUT_LEN");   // tuning experiments: positions per segment, about (ZH_CUT_WARM .. ZH_CUT_LEN)
+      c->cut_len = cl ? (uint32_t)atoi(cl) : (uint32_t)ZH_CUT_LEN;
+      if (c->cut_len < ZH_CUT_WARM) c->cut_len = ZH_CUT_WARM;
+      if (c->cut_len > ZH_CUT_LEN) c->cut_len = ZH_CUT_LEN;   // (the buffers are sized for ZH_CUT_WARM, the smallest)
       const char *cm = getenv("ZULTRA_HIP_CUT_MIN");   // tuning experiments: tasks of at least this many positions are cut (>= 2 * ZH_CUT_WARM)
       c->cut_min = cm ? (uint32_t)atoi(cm) : (uint32_t)ZH_CUT_MIN;
       if (c->cut_min < 2u * ZH_CUT_WARM) c->cut_min = 2u * ZH_CUT_WARM;
@@ -462,7 +467,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->max_tasks = B * (N / ZH_TASK + c->max_subs);
    // a cut task has at least 2 * ZH_CUT_WARM positions (the floor of ZULTRA_HIP_CUT_MIN) and lies inside one max-block
    c->seg_tasks_per_block = c->files_mode ? 1 : N / (2u * ZH_CUT_WARM) + 1;
-   c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_LEN + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;   // a task of len positions has at most len / ZH_CUT_LEN + ZH_CUT_ROWS segments
+   c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_WARM + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;   // a task of len positions has at most len / ZH_CUT_LEN + ZH_CUT_ROWS segments
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
        zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, c->max_tasks) ||
@@ -680,7 +685,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
    // (inputs of a files batch are never cut into speculative segments: seg_min = all ones)
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap,
-             (const uint32_t *)c->d_longest, c->tok_stride, c->d_hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu, c->d_ntasks);
+             (const uint32_t *)c->d_longest, c->tok_stride, c->d_hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu, (uint32_t)ZH_CUT_LEN, c->d_ntasks);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       hipStream_t side = c->side_stream[0];
@@ -903,7 +908,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
       ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
       ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, ntasks);
+                (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, c->cut_len, ntasks);
       // Does this run have chains at all? With none (text without long repeats) zh_parse_tasks gets the whole chip; with chains it
       // runs as a bounded number of persistent waves per CU, so that the chain workgroups find room the moment they are launched.
       ZH_CHECK(c, hipMemcpyAsync(h_cnt, ntasks, ZH_CNT_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -422,7 +422,7 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
 __global__ void __launch_bounds__(64)
 zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
              const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ longest, uint64_t longest_stride, uint32_t *hugelist, uint32_t cap, uint4 *segtasks,
-             uint2 *segitems, uint2 *segwaves, uint32_t seg_min, uint32_t *cnt) {
+             uint2 *segitems, uint2 *segwaves, uint32_t seg_min, uint32_t cut_len, uint32_t *cnt) {
    __shared__ uint32_t bnd[ZH_MAXPIECES + 1];
    const uint32_t gt = blockIdx.x;
    if (gt >= cnt[ZH_CNT_TASKS]) return;
@@ -445,8 +445,8 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
       full = zh_wave_sum(full);
       if (2u * full <= len) {
          // K segments of S positions, segment 0 the short one: as many as fill whole waves of zh_parse_segments (ZH_CUT_ROWS each)
-         // with about ZH_CUT_LEN positions per row
-         uint32_t K = ZH_CUT_ROWS * ((len + ZH_CUT_ROWS * ZH_CUT_LEN - 1u) / (ZH_CUT_ROWS * ZH_CUT_LEN));
+         // with about cut_len (ZH_CUT_LEN) positions per row
+         uint32_t K = ZH_CUT_ROWS * ((len + ZH_CUT_ROWS * cut_len - 1u) / (ZH_CUT_ROWS * cut_len));
          if (len / K < ZH_CUT_WARM) K = max(2u, len / ZH_CUT_WARM);   // (a segment is never shorter than the warm-up)
          const uint32_t S = ((len + K - 1u) / K + 31u) & ~31u;
          K = (len + S - 1u) / S;
