@@ -321,6 +321,10 @@ inline hipError_t hipGetDeviceCount(int *n) {
    return 0;
 }
 inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDevice(int *d) {
+   *d = 0;
+   return hipSuccess;
+}
 enum { hipDeviceAttributeMultiprocessorCount = 1, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return 0; }
 inline hipError_t hipDeviceGetAttribute(int *v, int, int) {

@@ -64,6 +64,7 @@ struct zultra_hip_ctx_s {
    std::vector<zh_seg_t> segs;
    std::vector<uint32_t> seg_base;
    zh_match_t *d_match;
+   uint32_t *d_pay;             // zh_mf_group: 3 x sort_stride words per persistent workgroup (payload of the refining sort passes)
    uint32_t *d_longest;         // per block position: slot 0 of its match row (tok_stride per max-block)
    uint32_t *d_tok_pos;
    uint16_t *d_tok_info;
@@ -320,6 +321,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_chunk_ctr);
    (void)hipFree(c->d_match);
    (void)hipFree(c->d_longest);
+   (void)hipFree(c->d_pay);
    (void)hipFree(c->d_tok_pos);
    (void)hipFree(c->d_tok_info);
    (void)hipFree(c->d_ntok);
@@ -476,6 +478,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) || zh_alloc(c, &c->d_longest, B * c->tok_stride) ||
+       zh_alloc(c, &c->d_pay, (size_t)c->nlanes * min((uint64_t)c->total_cus, B * c->segs_per_block) * 3 * c->sort_stride) ||   // (the runs' kernels may overlap)
        zh_alloc(c, &c->d_tok_pos, B * c->tok_stride) || zh_alloc(c, &c->d_tok_info, B * c->tok_stride) ||
        zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_chunkmax, B * c->chunks_per_block) || zh_alloc(c, &c->d_spanstart, B * c->chunks_per_block) ||
        zh_alloc(c, &c->d_spancnt, B * c->chunks_per_block) || zh_alloc(c, &c->d_split_tok, B * (ZH_MAX_SPLITS + 1)) || zh_alloc(c, &c->d_split_cnt, B) ||
@@ -599,6 +602,17 @@ extern "C" size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max
    bytes += subs * (sizeof(zh_sbstate_t) + sizeof(zh_work_t) + 2 * sizeof(zh_subblock_t) + sizeof(zh_stitch_item_t));
    bytes += tasks * (sizeof(uint2) + 4 + 4 + ZH_NSYM * 4);           // task map, chain list, bit counts, histograms
    bytes += B * (S * (sizeof(zh_seg_t) + 8) + sizeof(zh_block_t) + cpb * 12 + (ZH_MAX_SPLITS + 1) * 4 + 6 * 4) + 8192;
+   {
+      // payload of the matchfinder's refining passes: per run (ZULTRA_HIP_STREAMS) and persistent workgroup (one per CU)
+      int cus = 0, dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      const char *e = getenv("ZULTRA_HIP_STREAMS");
+      const uint64_t lanes = (uint64_t)max(1, min(4, e ? atoi(e) : 2));
+      bytes += lanes * min((uint64_t)cus, B * S) * 3 * sort_stride * 4;
+      // cut tasks (zh_parse.h): lists and two cost vectors per segment
+      const uint64_t seg_tasks = N / (2u * ZH_CUT_WARM) + 1, seg_items = N / ZH_CUT_WARM + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;
+      bytes += B * (seg_tasks * sizeof(uint4) + seg_items * (2 * sizeof(uint2) + 2 * ZH_VEC * sizeof(int16_t)));
+   }
    return (size_t)bytes;
 }
 extern "C" size_t zultra_hip_data_capacity(const zultra_hip_ctx_t *c) { return c ? c->data_cap : 0; }
@@ -671,7 +685,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
    const uint32_t mf_grid = min(nb, c->num_cus);   // persistent workgroups, one per CU (zh_matchfinder.h)
    ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr, 0, ((size_t)nb * 2 + 2) * sizeof(uint32_t), st));
    ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)c->d_segs, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride,
-             c->run_stride, 0, nb, c->d_chunk_ctr + (size_t)nb * 2 + 1);
+             c->run_stride, 0, nb, c->d_chunk_ctr + (size_t)nb * 2 + 1, c->d_pay);
    ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, (const zh_seg_t *)c->d_segs, (const uint32_t *)c->d_sort_a,
              (const uint2 *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
    if (zh_enqueue_tokenize(c, st, blk, 0, nb) != 0) return -1;
@@ -832,7 +846,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       // token bits are ORed into the payload slots: cleared here, long before stage 3 needs them (the fill runs next to the matchfinder)
       ZH_CHECK(c, hipMemsetAsync(c->d_payload + (uint64_t)b0 * c->slot_stride, 0, (size_t)nb * c->slot_stride, st));
       ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, rn, c->sort_stride, c->run_stride, mf_stop, nsg,
-                ctr + (size_t)nsg * 2 + 1);
+                ctr + (size_t)nsg * 2 + 1, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride);
       ZH_CHECK(c, hipEventRecord(ev[2], st));
       if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
       // (segment descriptors carry batch-wide block indices: the rows go to d_match + block * match_stride)

@@ -86,10 +86,12 @@ __device__ __forceinline__ uint32_t zh_mf_slice(uint32_t M) { return (((M + ZH_M
 
 // MODE 8/9: the elements are indices into the run table (aux_rs = run starts, aux_rl = run lengths): digit = the byte that follows the
 // run (0 where the run reaches the window end) / the run's byte. MODE 8 with src == nullptr reads the identity permutation.
-template <int MODE, bool HAVE = false, int NEXT = -1>
+// PAY: the elements carry a payload through the pass — 1: one word (psrc -> pdst), 2: two words (psrc, qsrc -> the pairs pdst2).
+template <int MODE, bool HAVE = false, int NEXT = -1, int PAY = 0>
 __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, uint32_t M, const uint32_t *src, uint32_t *dst, uint32_t *hist,
                                        uint32_t *wave_tot, uint32_t W = 0, uint32_t *hist_next = nullptr, uint32_t M_next = 0,
-                                       const uint32_t *aux_rs = nullptr, const uint32_t *aux_rl = nullptr) {
+                                       const uint32_t *aux_rs = nullptr, const uint32_t *aux_rl = nullptr, const uint32_t *psrc = nullptr,
+                                       uint32_t *pdst = nullptr, const uint32_t *qsrc = nullptr, uint2 *pdst2 = nullptr) {
    const uint32_t tid = threadIdx.x;
    const uint32_t lane = tid & 63, wave = tid >> 6;
    const uint32_t seg = zh_mf_slice(M);
@@ -171,13 +173,17 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
 
    // stable scatter: each wave walks its slice in order, 64 elements per step; the fetches of four steps are issued together
    for (uint32_t base4 = lo; base4 < hi; base4 += 256) {
-      uint32_t e4[4], d4[4];
+      uint32_t e4[4], d4[4], p4[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0};
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
          const uint32_t idx = base4 + u * 64 + lane;
          e4[u] = 0;
          d4[u] = 0xffffffffu;
-         if (idx < hi) ZH_MF_FETCH(idx, e4[u], d4[u]);
+         if (idx < hi) {
+            ZH_MF_FETCH(idx, e4[u], d4[u]);
+            if (PAY >= 1) p4[u] = psrc[idx];
+            if (PAY >= 2) q4[u] = qsrc[idx];
+         }
       }
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
@@ -193,7 +199,13 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
          }
          if (valid) {
             const uint32_t out = slot + (uint32_t)zh_popc64(peers & lt_mask);
+#ifdef ZH_MF_FAKE_SCATTER   // timing experiment (tools/probes/mf_stop_probe.py, with ZH_MF_STOP=2 only): what do the scattered stores cost?
+            dst[out & 4095u] = e;
+#else
             dst[out] = e;
+            if (PAY == 1) pdst[out] = p4[u];
+            if (PAY == 2) pdst2[out] = make_uint2(p4[u], q4[u]);
+#endif
             if ((peers & lt_mask) == 0) hist[wave * 256 + d] = slot + (uint32_t)zh_popc64(peers);
             if (NEXT >= 0) {
                // the next pass's digit of this element, counted for the wave whose slice position `out` will fall into
@@ -297,25 +309,49 @@ __device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin,
    }
 }
 
-// X = the K-gram order (MK entries, K = 4 or 5): prev[pos].y half K-4 = distance - 1 to the nearest earlier position
-// sharing K bytes, or 0xffff if there is none within ZH_MAX_DIST. Only block positions need it.
+// The nearest earlier position sharing K bytes (K = 3, 4, 5) with the position at entry idx of the K-gram order X (MK entries) is
+// the entry before it, when that one is in the same class (classes ascend in position). Recorded as distance - 1 in 16 bits
+// (0xffff: none within ZH_MAX_DIST) IN THE ORDER OF X, and carried along by the passes that refine the order (zh_mf_sort_pass,
+// PAY): in the end the three distances of a position sit next to its entry of the 6-gram order, where zh_mf_frontier reads them
+// with the entries, coalesced. (Round 1 scattered them into a table indexed by position: three partial writes per position,
+// to lines that had long left the L2 — 8.1 GB of HBM writes per 50 MB of input, most of this kernel's time.)
+//   K = 3: pay[idx] = d3 | none << 16        K = 4: pay[idx] = d3 (as carried) | d4 << 16        K = 5: pay[idx] = d5
+// The last five window positions drop out of the orders before they reach the 6-gram order: theirs go to tail[pos] (the
+// frontier's position-indexed table: entries from W - 5 on are free, the 6-gram order has at most W - 5 entries).
 template <int K>
-__device__ inline void zh_mf_prev_level(const uint32_t *__restrict__ X, uint32_t MK, const uint8_t *gwin, uint32_t first_needed, uint2 *__restrict__ prev) {
+__device__ inline void zh_mf_prev_level(const uint32_t *__restrict__ X, uint32_t MK, const uint8_t *gwin, uint32_t W, uint32_t *pay, uint2 *tail) {
    for (uint32_t idx0 = threadIdx.x; idx0 < MK; idx0 += 4 * ZH_MF_THREADS) {
-      uint32_t pos[4], q[4];
+      uint32_t pos[4], q[4], old[4] = {0, 0, 0, 0};
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
          const uint32_t idx = idx0 + u * ZH_MF_THREADS;
          pos[u] = idx < MK ? X[idx] : 0u;
          q[u] = (idx < MK && idx > 0) ? X[idx - 1] : ZH_MF_NONE;
+         if (K == 4 && idx < MK) old[u] = pay[idx];
       }
 #pragma unroll
       for (uint32_t u = 0; u < 4; u++) {
          const uint32_t idx = idx0 + u * ZH_MF_THREADS;
-         if (idx < MK && pos[u] >= first_needed) {
-            const bool same = q[u] != ZH_MF_NONE && zh_ld32(gwin + q[u]) == zh_ld32(gwin + pos[u]) && (K == 4 || gwin[q[u] + 4] == gwin[pos[u] + 4]);
-            const uint32_t d = pos[u] - q[u];   // classes ascend in position
-            ((uint16_t *)&prev[pos[u]].y)[K - 4] = (same && d <= ZH_MAX_DIST) ? (uint16_t)(d - 1) : (uint16_t)0xffffu;
+         if (idx < MK) {
+            bool same = q[u] != ZH_MF_NONE;
+            if (same) {
+               if (K == 3)
+                  same = zh_ld24(gwin + q[u]) == zh_ld24(gwin + pos[u]);
+               else
+                  same = zh_ld32(gwin + q[u]) == zh_ld32(gwin + pos[u]) && (K == 4 || gwin[q[u] + 4] == gwin[pos[u] + 4]);
+            }
+            const uint32_t dist = pos[u] - q[u];
+            const uint32_t d = (same && dist <= ZH_MAX_DIST) ? dist - 1u : 0xffffu;
+            const uint32_t v = K == 3 ? (d | 0xffff0000u) : (K == 4 ? ((old[u] & 0xffffu) | (d << 16)) : d);
+            pay[idx] = v;
+            if (pos[u] + 5u >= W) {
+               if (K == 3)
+                  tail[pos[u]] = make_uint2(v, 0xffffu);
+               else if (K == 4)
+                  tail[pos[u]].x = v;
+               else
+                  tail[pos[u]].y = v;
+            }
          }
       }
    }
@@ -324,7 +360,8 @@ __device__ inline void zh_mf_prev_level(const uint32_t *__restrict__ X, uint32_t
 
 // `win` is read linearly (global memory); `gwin` is the copy used for scattered reads (LDS when the window fits)
 __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin, uint32_t W, uint32_t Qn, uint32_t first_needed, uint32_t *A, uint32_t *B,
-                                        uint2 *prev, uint32_t *runs, uint32_t *hist, uint32_t *wave_tot, int stop) {
+                                        uint2 *prev, uint32_t *pay, uint64_t pay_stride, uint32_t *runs, uint32_t *hist, uint32_t *wave_tot, int stop) {
+   uint32_t *Pa = pay, *Pb = pay + pay_stride, *Pq = pay + 2 * pay_stride;   // payload ping, pong, and the 5-gram distances
    const uint32_t tid = threadIdx.x;
    // W = window bytes, Qn = positions that are candidates or get rows (the rest of the window is look-ahead)
    const uint32_t M3 = min(Qn, W >= 3 ? W - 2 : 0u);   // positions that start a trigram
@@ -338,30 +375,7 @@ __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin,
    zh_mf_sort_pass<1, true, 2>(win, gwin, M3, A, B, hist2, wave_tot, W, hist, M3);
    zh_mf_sort_pass<2, true, 5>(win, gwin, M3, B, A, hist, wave_tot, W, hist2, M3);
    if (stop == 3) return;
-   {
-      // only block positions need it (history positions get no rows); four entries per thread keep the loads overlapped
-      const uint32_t *__restrict__ Ar = A;
-      uint2 *__restrict__ P3 = prev;
-      for (uint32_t idx0 = tid; idx0 < M3; idx0 += 4 * ZH_MF_THREADS) {
-         uint32_t pos[4], q[4];
-#pragma unroll
-         for (uint32_t u = 0; u < 4; u++) {
-            const uint32_t idx = idx0 + u * ZH_MF_THREADS;
-            pos[u] = idx < M3 ? Ar[idx] : 0u;
-            q[u] = (idx < M3 && idx > 0) ? Ar[idx - 1] : ZH_MF_NONE;
-         }
-#pragma unroll
-         for (uint32_t u = 0; u < 4; u++) {
-            const uint32_t idx = idx0 + u * ZH_MF_THREADS;
-            if (idx < M3 && pos[u] >= first_needed) {
-               // same class => the nearest earlier occurrence (classes ascend in position)
-               const bool same = q[u] != ZH_MF_NONE && zh_ld24(gwin + q[u]) == zh_ld24(gwin + pos[u]);
-               P3[pos[u]].x = same ? q[u] : ZH_MF_NONE;
-            }
-         }
-      }
-   }
-   __syncthreads();
+   zh_mf_prev_level<3>(A, M3, gwin, W, Pa, prev);
    if (stop == 4) return;
 
    // ---- 4-, 5- and 6-gram classes: one more stable pass each over the previous order ------------------------------
@@ -369,11 +383,12 @@ __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin,
    // matches of 6 and more are found by walking a class, and 6-gram classes are several times smaller than 4-gram
    // classes (on text the walk shrinks 2.3x, on source code 1.5x).
    const uint32_t M5 = min(Qn, W >= 5 ? W - 4 : 0u), M6 = min(Qn, W >= 6 ? W - 5 : 0u);
-   zh_mf_sort_pass<5, true, 6>(win, gwin, M3, A, B, hist2, wave_tot, W, hist, M4);   // B: 4-gram order, M4 entries
-   zh_mf_prev_level<4>(B, M4, gwin, first_needed, prev);
-   zh_mf_sort_pass<6, true, 7>(win, gwin, M4, B, A, hist, wave_tot, W, hist2, M5);   // A: 5-gram order, M5 entries
-   zh_mf_prev_level<5>(A, M5, gwin, first_needed, prev);
-   zh_mf_sort_pass<7, true>(win, gwin, M5, A, B, hist2, wave_tot, W);                // B: 6-gram order, M6 entries
+   zh_mf_sort_pass<5, true, 6, 1>(win, gwin, M3, A, B, hist2, wave_tot, W, hist, M4, nullptr, nullptr, Pa, Pb);   // B: 4-gram order, M4 entries
+   zh_mf_prev_level<4>(B, M4, gwin, W, Pb, prev);
+   zh_mf_sort_pass<6, true, 7, 1>(win, gwin, M4, B, A, hist, wave_tot, W, hist2, M5, nullptr, nullptr, Pb, Pa);   // A: 5-gram order, M5 entries
+   zh_mf_prev_level<5>(A, M5, gwin, W, Pq, prev);
+   // B: 6-gram order, M6 entries; prev[idx] = the distances of the position at B[idx]
+   zh_mf_sort_pass<7, true, -1, 2>(win, gwin, M5, A, B, hist2, wave_tot, W, nullptr, 0, nullptr, nullptr, Pa, nullptr, Pq, prev);
    if (stop == 5) return;
    {
       const uint32_t *__restrict__ Br = B;
@@ -405,7 +420,7 @@ template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
 zh_mf_group(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs, uint32_t *sort_a,
             uint32_t *sort_b, uint2 *prev_all, uint32_t *runs_all, uint64_t sort_stride, uint64_t run_stride, int stop, uint32_t nsegs,
-            uint32_t *ticket) {
+            uint32_t *ticket, uint32_t *pay_all /* 3 x sort_stride words per workgroup: the payload of the refining passes */) {
    // All of this kernel's LDS is dynamic (ZH_MF_GROUP_LDS bytes at launch). Measured on gfx950: next to a workgroup with
    // 128 KiB of STATIC LDS, workgroups of another stream's kernel that use static LDS are not scheduled at all although
    // they would fit (a 0.3 ms kernel took 6.4 ms); with the allocation made dynamic on either side they run side by side
@@ -436,7 +451,8 @@ zh_mf_group(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs,
       zh_stage_window(lwin32, win, W);
       gwin = (const uint8_t *)lwin32;
    }
-   zh_mf_group_body(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, runs, hist, wave_tot, stop);
+   zh_mf_group_body(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, pay_all + (uint64_t)blockIdx.x * 3u * sort_stride, sort_stride, runs, hist, wave_tot,
+                    stop);
    }
 }
 
@@ -578,7 +594,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
    const uint32_t W = Qn + blk.tail;                                 // window incl. look-ahead: match lengths clamp here
    const uint32_t M = min(Qn, W >= 6 ? W - 5 : 0u);                  // entries of the 6-gram order
    const uint32_t *S = sorted + (uint64_t)seg_id * sort_stride;
-   const uint2 *prevs = prev_all + (uint64_t)seg_id * sort_stride;   // x: previous trigram occurrence, y: distances of prev4 | prev5
+   const uint2 *prevs = prev_all + (uint64_t)seg_id * sort_stride;   // per entry of the 6-gram order: x = distance - 1 to the previous occurrence of the trigram | of the 4-gram << 16, y = of the 5-gram (0xffff: none)
    const uint32_t *runs = runs_all + (uint64_t)seg_id * run_stride;
    // row r = segment position prev + r: slots 0..3 in rows_lo[r], slots 4..7 in rows_hi[r] (zh_common.h); its longest match again in
    // longest[r], for the kernels that only follow the greedy chain (zh_split.h)
@@ -607,10 +623,12 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       if (i >= prev && i < Qn) {
          uint32_t m[3] = {0, 0, 0}, n = 0;
          if (maxlen >= 3) {
-            const uint2 pv = prevs[i];
-            if (pv.x != ZH_MF_NONE && i - pv.x <= ZH_MAX_DIST) {
-               if (maxlen == 3 || gwin[pv.x + 3] != gwin[i + 3]) m[n++] = 3u | ((i - pv.x) << 16);
-               const uint32_t d4 = pv.y & 0xffffu, d5 = pv.y >> 16;
+            const uint2 pv = prevs[i];   // (the last positions' records are indexed by position, zh_mf_prev_level)
+            const uint32_t d3 = pv.x & 0xffffu;
+            if (d3 != 0xffffu) {
+               const uint32_t p3 = i - 1u - d3;
+               if (maxlen == 3 || gwin[p3 + 3] != gwin[i + 3]) m[n++] = 3u | ((d3 + 1u) << 16);
+               const uint32_t d4 = pv.x >> 16, d5 = pv.y & 0xffffu;
                if (maxlen >= 4 && d4 != 0xffffu) {
                   if (maxlen == 4 || gwin[i - 1 - d4 + 4] != gwin[i + 4]) m[n++] = 4u | ((d4 + 1) << 16);
                   if (maxlen >= 5 && d5 != 0xffffu) m[n++] = 5u | ((d5 + 1) << 16);
@@ -683,11 +701,11 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       if (mine) {
          // nearest occurrence of the trigram: without it there is no match at all; if its 4th byte differs it is the
          // (only) length-3 entry. Likewise the nearest occurrences of the 4-gram and the 5-gram.
-         const uint2 pv = prevs[i];
-         const uint32_t p3 = pv.x;
-         if (p3 != ZH_MF_NONE && i - p3 <= ZH_MAX_DIST) {
-            d4 = pv.y & 0xffffu;
-            d5 = pv.y >> 16;
+         const uint2 pv = prevs[t];   // the record travels with the entry of the 6-gram order (zh_mf_prev_level)
+         const uint32_t d3 = pv.x & 0xffffu, p3 = i - 1u - d3;
+         if (d3 != 0xffffu) {
+            d4 = pv.x >> 16;
+            d5 = pv.y & 0xffffu;
             has4 = d4 != 0xffffu;
             const uint32_t q4 = LDS_WIN ? zh_load32_at(lwin32, p3) : zh_ld32(win + p3);
             if (q4 != first4) {
