@@ -2,13 +2,15 @@
 import numpy as np
 
 
-def check_window(lib, oracle, win, prev, n, max_block=32768, tag=""):
+def check_window(lib, oracle, win, prev, n, max_block=32768, tag="", stats_out=None):
     """Run one max-block through zultra_hip_compress_blocks and compare every stage with the oracle:
     match rows, split offsets, per-sub-block costs / type / bit count / bits / final parse."""
     win = np.ascontiguousarray(win, dtype=np.uint8)
     ctx = lib.context(max_block, 1)
     try:
         ctx.compress_blocks(win, [(0, prev, n)])
+        if stats_out is not None:
+            stats_out.update(ctx.stats())
         mo = oracle.find_matches(win, prev, n)
         mg = ctx.matches(0)
         if not np.array_equal(mo, mg):
