@@ -89,6 +89,7 @@ struct zultra_hip_ctx_s {
    uint32_t cut_len;            // ... into segments of about this many positions
    uint32_t cut_min;            // tasks of at least this many positions are cut into segments
    uint32_t seg_whole;          // ... with fewer, zh_parse_chain takes the segments — and the cut tasks shorter than this whole (ZULTRA_HIP_SEG_WHOLE)
+   uint32_t first_run_pct;      // share of the first run of a batch in percent of an equal share
    uint32_t seg_wide;           // a run with at least this many segments parses them with zh_parse_segments (ZULTRA_HIP_SEG_WIDE)
    int16_t *d_vecs;             // two cost vectors per segment
    uint64_t seg_tasks_per_block, seg_items_per_block;
@@ -422,6 +423,10 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->task_waves = tw ? (uint32_t)atoi(tw) : 26u;
       if (c->task_waves < 1) c->task_waves = 1;
       if (c->task_waves > 32) c->task_waves = 32;
+      const char *fr = getenv("ZULTRA_HIP_FIRST_RUN");   // share of the first run, in percent of an equal share (tuning experiments)
+      c->first_run_pct = fr ? (uint32_t)atoi(fr) : 100u;
+      if (c->first_run_pct < 10u) c->first_run_pct = 10u;
+      if (c->first_run_pct > 100u) c->first_run_pct = 100u;
       const char *e = getenv("ZULTRA_HIP_STREAMS");
       c->nlanes = e ? atoi(e) : 2;
       if (c->nlanes < 1) c->nlanes = 1;
@@ -806,6 +811,14 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    for (uint32_t b = 0; b < nblocks; b++) batch_bytes += blocks[b].n;
    const int lanes = (nblocks >= 4u * (uint32_t)c->nlanes && batch_bytes >= ((uint64_t)c->nlanes << 22)) ? c->nlanes : 1;
    const int mf_stop = getenv("ZH_MF_STOP") ? atoi(getenv("ZH_MF_STOP")) : 0;   // timing experiments only
+   // run k = blocks [run_lo(k), run_lo(k + 1)): the first run may be given a smaller share (c->first_run_pct of an equal share), so that the
+   // other runs' matchfinders start earlier
+   auto run_lo = [&](int k) -> uint32_t {
+      if (k <= 0) return 0u;
+      if (k >= lanes) return nblocks;
+      const uint64_t first = (uint64_t)nblocks * c->first_run_pct / (100ull * (uint64_t)lanes);
+      return (uint32_t)(first + ((uint64_t)nblocks - first) * (uint64_t)(k - 1) / (uint64_t)(lanes - 1));
+   };
    const uint64_t tasks_per_block = c->max_tasks / c->max_blocks;
    hipStream_t st0 = c->lane_stream[0];
 
@@ -825,7 +838,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    for (int k = 0; k < lanes; k++) {
       hipStream_t st = c->lane_stream[k];
       hipEvent_t *ev = c->lane_ev[k];
-      const uint32_t b0 = (uint32_t)(((uint64_t)nblocks * k) / lanes), b1 = (uint32_t)(((uint64_t)nblocks * (k + 1)) / lanes);
+      const uint32_t b0 = run_lo(k), b1 = run_lo(k + 1);
       const uint32_t nb = b1 - b0;
       const zh_block_t *blk = c->d_blocks + b0;
       if (k) {
@@ -880,7 +893,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    for (int k = 0; k < lanes; k++) {
       hipStream_t st = c->lane_stream[k];
       hipEvent_t *ev = c->lane_ev[k];
-      const uint32_t b0 = (uint32_t)(((uint64_t)nblocks * k) / lanes), b1 = (uint32_t)(((uint64_t)nblocks * (k + 1)) / lanes);
+      const uint32_t b0 = run_lo(k), b1 = run_lo(k + 1);
       const uint32_t nb = b1 - b0;
       const zh_block_t *blk = c->d_blocks + b0;
       ZH_CHECK(c, hipEventSynchronize(ev[4]));   // split counts of this run are on the host; later runs keep the GPU busy meanwhile
@@ -993,7 +1006,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    memcpy(c->crc.data(), c->h_crc, nblocks * sizeof(uint32_t));
    c->adler.assign(c->h_adler, c->h_adler + 2 * (size_t)nblocks);
    for (int k = 0; k < lanes; k++) {
-      const uint32_t b0 = (uint32_t)(((uint64_t)nblocks * k) / lanes);
+      const uint32_t b0 = run_lo(k);
       for (uint32_t i = 0; i < lane_nsubs[k]; i++) {
          zh_subblock_t &r = c->results[lane_sub0[k] + i];
          r.block += b0;
