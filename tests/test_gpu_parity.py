@@ -120,6 +120,27 @@ def test_fuzz_streams_vs_oracle(gpu, oracle):
         assert gpu.memory_compress(d, flags, bs) == oracle.memory_compress(d, flags, bs), (it, n, flags, bs)
 
 
+@pytest.mark.parametrize("wide", ["1", "1000000", "whole"], ids=["as_waves_of_zh_parse_segments", "as_jobs_of_zh_parse_chain", "few_and_short_stay_whole"])
+def test_fuzz_streams_with_long_barrier_free_runs(gpu, oracle, monkeypatch, wide):
+    """Whole streams made of the kinds of data that produce chains and cut tasks (tables, records, near-copies, byte runs,
+    periodic data) next to data that produces none, under each way of parsing the segments: the bytes are the oracle's."""
+    monkeypatch.setenv("ZULTRA_HIP_SEG_WIDE", "1000000" if wide == "whole" else wide)
+    monkeypatch.setenv("ZULTRA_HIP_SEG_WHOLE", "1000000" if wide == "whole" else "0")
+    monkeypatch.setenv("ZULTRA_HIP_CACHE", "0")   # the thresholds are read when a context is created
+    gpu.L.zultra_release_cached_contexts()
+    rs = np.random.RandomState(4242)
+    makers = [lambda n, sd: corpus.table_like(n, sd), lambda n, sd: corpus.duplicated(n, sd, int(rs.randint(40, 3000))),
+              lambda n, sd: corpus.json_like(n, sd), lambda n, sd: corpus.indented(n, sd), lambda n, sd: corpus.periodic(n, 1 + sd % 7),
+              lambda n, sd: corpus.noise(n, sd), lambda n, sd: corpus.text_like(n, sd), lambda n, sd: corpus.constant(n, 32 + sd % 64)]
+    for it in range(4):
+        parts = []
+        for _ in range(int(rs.randint(3, 8))):
+            parts.append(makers[int(rs.randint(0, len(makers)))](int(rs.randint(2000, 160000)), int(rs.randint(1, 1000))))
+        d = np.concatenate(parts)
+        flags, bs = int(rs.randint(0, 3)), [65536, 32768, 0, 262144][it % 4]
+        assert gpu.memory_compress(d, flags, bs) == oracle.memory_compress(d, flags, bs), (wide, it, len(d), flags, bs)
+
+
 def test_streaming_api_chunking(gpu, oracle):
     d = corpus.text_like(500000, 12)
     want = oracle.memory_compress(d, 2, 65536)
