@@ -379,11 +379,9 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
                    "zh_barriers+zh_tokenize_spans+zh_split": avg["tokenize_split_ms"], "zh_plan_subblocks+zh_sb_init": avg["init_ms"],
                    "zh_parse_tasks+zh_parse_chain": avg["parse_ms"], "zh_sb_build": avg["build_ms"], "zh_post_tasks": avg["post_ms"],
                    "zh_emit_tasks": avg["emit_ms"], "zh_stitch": avg["stitch_ms"]}
-        # the library runs a batch as `runs` staggered runs of max-blocks on separate streams (ZULTRA_HIP_STREAMS, default 2):
-        # every kernel is launched once per run (the parse / code-rebuild pair once per pass and run) over 1/runs of the batch
-        runs = max(1, min(4, int(os.environ.get("ZULTRA_HIP_STREAMS", "2"))))
-        if nblocks < 4 * runs or n < (runs << 22):
-            runs = 1
+        # the library runs a batch as staggered runs of max-blocks on separate streams (ZULTRA_HIP_STREAMS): every kernel is launched
+        # once per run (the parse / code-rebuild pair once per pass and run) over 1/runs of the batch
+        runs = max(1, int(res["stats"]["runs"]))
         launches = {k: runs for k in kernels}
         launches["zh_parse_tasks+zh_parse_chain"] = launches["zh_sb_build"] = 4 * runs
         launches["zh_stitch"] = 1

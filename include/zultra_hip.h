@@ -113,7 +113,8 @@ typedef struct zultra_hip_stats_s {
    uint64_t positions, huge_positions;
    uint32_t blocks, subblocks, tasks, huge_tasks;
    uint32_t cut_tasks, cut_segments;   /* chain tasks parsed as speculative segments, and their segments */
-   uint32_t cut_redone, pad;           /* segments whose speculated costs did not match and were parsed again (sum over the passes) */
+   uint32_t cut_redone;                /* segments whose speculated costs did not match and were parsed again (sum over the passes) */
+   uint32_t runs;                      /* staggered runs the batch was cut into (ZULTRA_HIP_STREAMS, fewer for small batches) */
 } zultra_hip_stats_t;
 void zultra_hip_last_stats(const zultra_hip_ctx_t *ctx, zultra_hip_stats_t *out);
 

@@ -34,7 +34,8 @@
 #include "zh_split.h"
 #include "zh_stitch.h"
 
-#define ZH_NCNT (4u * ZH_CNT_STRIDE)   // device counters: one block of ZH_CNT_* words per run
+#define ZH_MAX_RUNS 8           // staggered runs of a batch (ZULTRA_HIP_STREAMS)
+#define ZH_NCNT ((uint32_t)ZH_MAX_RUNS * ZH_CNT_STRIDE)   // device counters: one block of ZH_CNT_* words per run
 
 static_assert(sizeof(zultra_hip_block_t) == sizeof(zh_block_t), "ABI");
 static_assert(sizeof(zultra_hip_subblock_t) == sizeof(zh_subblock_t), "ABI");
@@ -89,6 +90,9 @@ struct zultra_hip_ctx_s {
    uint32_t cut_len;            // ... into segments of about this many positions
    uint32_t cut_min;            // tasks of at least this many positions are cut into segments
    uint32_t seg_whole;          // ... with fewer, zh_parse_chain takes the segments — and the cut tasks shorter than this whole (ZULTRA_HIP_SEG_WHOLE)
+   int auto_runs;               // ZULTRA_HIP_STREAMS not set: the number of runs follows the batch size
+   int last_runs;               // runs the last batch was cut into
+   int stagger_ev;              // event of the previous run that a run's matchfinder waits for (0: none)
    uint32_t first_run_pct;      // share of the first run of a batch in percent of an equal share
    uint32_t seg_wide;           // a run with at least this many segments parses them with zh_parse_segments (ZULTRA_HIP_SEG_WIDE)
    int16_t *d_vecs;             // two cost vectors per segment
@@ -109,12 +113,12 @@ struct zultra_hip_ctx_s {
    const uint8_t *graph_data;
    std::vector<uint64_t> file_off;
    int nlanes;
-   hipStream_t lane_stream[4];
-   hipEvent_t lane_ev[4][24];
-   hipStream_t side_stream[4];     // per run: zh_parse_chain runs next to zh_parse_tasks
-   hipEvent_t side_ev[4][8];       // per pass: fork, join
-   hipStream_t seg_stream[4];      // per run: zh_parse_segments, likewise
-   hipEvent_t seg_ev[4][4];        // per pass: join
+   hipStream_t lane_stream[ZH_MAX_RUNS];
+   hipEvent_t lane_ev[ZH_MAX_RUNS][24];
+   hipStream_t side_stream[ZH_MAX_RUNS];     // per run: zh_parse_chain runs next to zh_parse_tasks
+   hipEvent_t side_ev[ZH_MAX_RUNS][8];       // per pass: fork, join
+   hipStream_t seg_stream[ZH_MAX_RUNS];      // per run: zh_parse_segments, likewise
+   hipEvent_t seg_ev[ZH_MAX_RUNS][4];        // per pass: join
    hipEvent_t ev_input;
    zh_subblock_t *d_results_compact;
    uint8_t *h_stage[2];         // pinned staging for callers that hand over pageable host memory (zultra_hip_staging)
@@ -350,7 +354,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_task_bits);
    for (int i = 0; i < 16; i++)
       if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
-   for (int k = 0; k < 4; k++) {
+   for (int k = 0; k < ZH_MAX_RUNS; k++) {
       for (int i = 0; i < 24; i++)
          if (c->lane_ev[k][i]) (void)hipEventDestroy(c->lane_ev[k][i]);
       if (c->lane_stream[k]) (void)hipStreamDestroy(c->lane_stream[k]);
@@ -405,8 +409,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    for (int i = 0; i < 16; i++) ZH_CHECK(c, hipEventCreate(&c->ev2[i]));
    {
       if (getenv("ZULTRA_HIP_CHAIN_TRACE") && atoi(getenv("ZULTRA_HIP_CHAIN_TRACE"))) {
-         if (zh_alloc(c, &c->d_chain_trace, (size_t)3 * ZH_TRACE_SLOTS * 16)) return -1;
-         ZH_CHECK(c, hipMemset(c->d_chain_trace, 0, (size_t)3 * ZH_TRACE_SLOTS * 16 * sizeof(uint64_t)));
+         if (zh_alloc(c, &c->d_chain_trace, (size_t)3 * ZH_TRACE_SLOTS * 4 * ZH_MAX_RUNS)) return -1;   // (the getter returns the first four runs)
+         ZH_CHECK(c, hipMemset(c->d_chain_trace, 0, (size_t)3 * ZH_TRACE_SLOTS * 4 * ZH_MAX_RUNS * sizeof(uint64_t)));
       }
       const char *cl = getenv("ZULTRA_HIP_CUT_LEN");   // tuning experiments: positions per segment, about (ZH_CUT_WARM .. ZH_CUT_LEN)
       c->cut_len = cl ? (uint32_t)atoi(cl) : (uint32_t)ZH_CUT_LEN;
@@ -423,14 +427,19 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->task_waves = tw ? (uint32_t)atoi(tw) : 26u;
       if (c->task_waves < 1) c->task_waves = 1;
       if (c->task_waves > 32) c->task_waves = 32;
+      const char *sg = getenv("ZULTRA_HIP_STAGGER");   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group, 3 zh_mf_frontier (default), 4 the splitter
+      c->stagger_ev = sg ? atoi(sg) : 2;   // measured, 2 instead of 3: 100 MB of real text 51.9 -> 49.8 ms, configuration 3 31.6 -> 30.5, configuration 4 972 -> 910
+      if (c->stagger_ev != 0 && (c->stagger_ev < 2 || c->stagger_ev > 4)) c->stagger_ev = 3;
       const char *fr = getenv("ZULTRA_HIP_FIRST_RUN");   // share of the first run, in percent of an equal share (tuning experiments)
       c->first_run_pct = fr ? (uint32_t)atoi(fr) : 100u;
       if (c->first_run_pct < 10u) c->first_run_pct = 10u;
       if (c->first_run_pct > 100u) c->first_run_pct = 100u;
       const char *e = getenv("ZULTRA_HIP_STREAMS");
-      c->nlanes = e ? atoi(e) : 2;
+      c->nlanes = e ? atoi(e) : 4;
+      c->auto_runs = e ? 0 : 1;   // not set: three runs, four for batches of 256 MiB and more (measured with the stagger above, runs = 2 / 3 / 4 / 6: 100 MB
+                                  // of real text 49.8 / 49.6 / 51.2 / - ms; configuration 3 31.0 / 29.1 / 29.5 / -; 1 GiB of configuration 4 910 / 883 / 789 / 812)
       if (c->nlanes < 1) c->nlanes = 1;
-      if (c->nlanes > 4) c->nlanes = 4;
+      if (c->nlanes > ZH_MAX_RUNS) c->nlanes = ZH_MAX_RUNS;
       for (int k = 0; k < c->nlanes; k++) {
          // The run's main stream keeps off the last `chain_cus` CUs: whatever it launches — the matchfinder's one-workgroup-per-CU
          // kernels, tens of thousands of single-wave task workgroups — those CUs stay free for the kernels of the other streams,
@@ -612,7 +621,7 @@ extern "C" size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max
       int cus = 0, dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
       const char *e = getenv("ZULTRA_HIP_STREAMS");
-      const uint64_t lanes = (uint64_t)max(1, min(4, e ? atoi(e) : 2));
+      const uint64_t lanes = (uint64_t)max(1, min((int)ZH_MAX_RUNS, e ? atoi(e) : 4));
       bytes += lanes * min((uint64_t)cus, B * S) * 3 * sort_stride * 4;
       // cut tasks (zh_parse.h): lists and two cost vectors per segment
       const uint64_t seg_tasks = N / (2u * ZH_CUT_WARM) + 1, seg_items = N / ZH_CUT_WARM + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;
@@ -809,7 +818,8 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    // (zh_split, zh_sb_build, ...) then overlap with the wide kernels of the others.
    uint64_t batch_bytes = 0;
    for (uint32_t b = 0; b < nblocks; b++) batch_bytes += blocks[b].n;
-   const int lanes = (nblocks >= 4u * (uint32_t)c->nlanes && batch_bytes >= ((uint64_t)c->nlanes << 22)) ? c->nlanes : 1;
+   const uint64_t want_runs = c->auto_runs ? (batch_bytes >= (256ull << 20) ? 4u : 3u) : (uint64_t)c->nlanes;
+   const int lanes = c->last_runs = (int)max((uint64_t)1, min(want_runs, min((uint64_t)nblocks / 4u, batch_bytes >> 22)));   // at least four max-blocks and 4 MiB per run
    const int mf_stop = getenv("ZH_MF_STOP") ? atoi(getenv("ZH_MF_STOP")) : 0;   // timing experiments only
    // run k = blocks [run_lo(k), run_lo(k + 1)): the first run may be given a smaller share (c->first_run_pct of an equal share), so that the
    // other runs' matchfinders start earlier
@@ -845,7 +855,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          ZH_CHECK(c, hipStreamWaitEvent(st, c->ev_input, 0));
          // stagger the runs by one stage: this run's wide matchfinder kernels start when the previous run reaches its
          // narrow ones (token chain, splitter), so narrow and wide kernels of different runs share the chip
-         ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k - 1][3], 0));
+         if (c->stagger_ev) ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k - 1][c->stagger_ev], 0));
       }
       ZH_CHECK(c, hipEventRecord(ev[1], st));
       const uint32_t sg0 = c->seg_base[b0], nsg = c->seg_base[b1] - sg0;   // this run's matchfinder segments
@@ -887,7 +897,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
 
    // ---- stage 3 of every run: the sub-block coder, one kernel per step over the run (zh_encode.h) -------------------
    uint32_t nsubs = 0;
-   uint32_t lane_sub0[4], lane_nsubs[4];
+   uint32_t lane_sub0[ZH_MAX_RUNS], lane_nsubs[ZH_MAX_RUNS];
    ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, ZH_NCNT * sizeof(uint32_t), st0));
    ZH_CHECK(c, hipEventRecord(c->ev2[0], st0));
    for (int k = 0; k < lanes; k++) {
@@ -1196,7 +1206,7 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
    memset(out, 0, sizeof(*out));
    out->blocks = c->nblocks;
    out->subblocks = c->nsubs;
-   for (int k = 0; k < 4; k++) {
+   for (int k = 0; k < ZH_MAX_RUNS; k++) {
       const uint32_t *cnt = c->h_ntasks + (size_t)k * ZH_CNT_STRIDE;
       out->tasks += cnt[ZH_CNT_TASKS];
       out->huge_tasks += cnt[ZH_CNT_VLONG] + cnt[ZH_CNT_LONG] + cnt[ZH_CNT_SHORT] + cnt[ZH_CNT_SEGTASKS];
@@ -1206,6 +1216,7 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
       out->cut_redone += cnt[ZH_CNT_SEG_FAILED];   // over the four passes
    }
    for (uint32_t b = 0; b < c->nblocks; b++) out->positions += c->blocks[b].n;
+   out->runs = c->files_mode ? 1u : (uint32_t)c->last_runs;
 }
 
 extern "C" int zultra_hip_get_matches(zultra_hip_ctx_t *c, uint32_t block, uint16_t *out) {
