@@ -92,6 +92,7 @@ struct zultra_hip_ctx_s {
    uint32_t seg_whole;          // ... with fewer, zh_parse_chain takes the segments — and the cut tasks shorter than this whole (ZULTRA_HIP_SEG_WHOLE)
    int auto_runs;               // ZULTRA_HIP_STREAMS not set: the number of runs follows the batch size
    int last_runs;               // runs the last batch was cut into
+   uint32_t split_waves;        // waves per splitter workgroup, 0 = by max-block size
    int stagger_ev;              // event of the previous run that a run's matchfinder waits for (0: none)
    uint32_t first_run_pct;      // share of the first run of a batch in percent of an equal share
    uint32_t seg_wide;           // a run with at least this many segments parses them with zh_parse_segments (ZULTRA_HIP_SEG_WIDE)
@@ -427,6 +428,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->task_waves = tw ? (uint32_t)atoi(tw) : 26u;
       if (c->task_waves < 1) c->task_waves = 1;
       if (c->task_waves > 32) c->task_waves = 32;
+      const char *spw = getenv("ZULTRA_HIP_SPLIT_WAVES");   // waves per splitter workgroup (2, 4, 8, 16; default by max-block size)
+      c->split_waves = spw ? (uint32_t)atoi(spw) : 0u;
       const char *sg = getenv("ZULTRA_HIP_STAGGER");   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group, 3 zh_mf_frontier (default), 4 the splitter
       c->stagger_ev = sg ? atoi(sg) : 2;   // measured, 2 instead of 3: 100 MB of real text 51.9 -> 49.8 ms, configuration 3 31.6 -> 30.5, configuration 4 972 -> 910
       if (c->stagger_ev != 0 && (c->stagger_ev < 2 || c->stagger_ev > 4)) c->stagger_ev = 3;
@@ -877,14 +880,21 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, ctr, nsg, 1u);
       ZH_CHECK(c, hipEventRecord(ev[3], st));
       if (zh_enqueue_tokenize(c, st, blk, b0, nb) != 0) return -1;
-      if (c->max_block > 131072) {
-         ZH_LAUNCH(zh_split<16>, nb, 64 * 16, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride),
-                   c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0);
+#define ZH_LAUNCH_SPLIT(W_)                                                                                                                                   \
+   ZH_LAUNCH(zh_split<W_>, nb, 64 * W_, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), \
+             c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0)
+      {
+         const uint32_t sw = c->split_waves ? c->split_waves : (c->max_block > 131072 ? 16u : 8u);
+         if (sw >= 16)
+            ZH_LAUNCH_SPLIT(16);
+         else if (sw >= 8)
+            ZH_LAUNCH_SPLIT(8);
+         else if (sw >= 4)
+            ZH_LAUNCH_SPLIT(4);
+         else
+            ZH_LAUNCH_SPLIT(2);
       }
-      else {
-         ZH_LAUNCH(zh_split<8>, nb, 64 * 8, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride),
-                   c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0);
-      }
+#undef ZH_LAUNCH_SPLIT
       ZH_CHECK(c, hipMemcpyAsync(c->h_split_cnt + b0, c->d_split_cnt + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipEventRecord(ev[4], st));
    }

@@ -266,7 +266,7 @@ struct zh_split_wave_ws_t {   // private to one wave
 };
 struct zh_split_shared_t {
    int32_t tot_lit[ZH_NLIT], tot_dist[ZH_NDIST];
-   uint32_t fresh[ZH_SPLIT_MAXCP][18];
+   uint32_t fresh[ZH_SPLIT_MAXCP][9];   // 18 bin counts of 16 bits per interval (an interval has at most 512 tokens)
    int32_t gain[ZH_SPLIT_MAXCP];   // per triggered checkpoint: price of the two halves
    int32_t total_cost;             // price of the whole range (wave 0)
    uint32_t next_eval;             // the next triggered checkpoint to hand to a wave
@@ -338,7 +338,7 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
       const uint32_t nj = min((uint32_t)ZH_SPLIT_MAXCP, ncp - j0);
       __syncthreads();   // the previous chunk's statistics have been read
       // 18-bin statistics of every interval of the chunk: interval j = tokens [c(j-1), c(j)), c(-1) = t0, c(j) = c0 + 256 j
-      for (uint32_t k = tid; k < nj * 18; k += (64u * WAVES)) sh->fresh[k / 18][k % 18] = 0;
+      for (uint32_t k = tid; k < nj * 9; k += (64u * WAVES)) sh->fresh[k / 9][k % 9] = 0;
       for (uint32_t k = tid; k < nj; k += (64u * WAVES)) sh->gain[k] = 0;
       if (tid == 0) sh->next_eval = 0;
       __syncthreads();
@@ -348,7 +348,7 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
          for (uint32_t t = lo + lane; t < hi; t += 64) {
             const uint32_t s = ZH_TOK_SYM(ti[t]);
             const uint32_t bin = (s < 256) ? (((s >> 4) & 0xc) | (s & 3)) : (s >= 263 ? 17u : 16u);   // :689-699 (len >= 9 <=> symbol >= 263)
-            atomicAdd(&sh->fresh[jj][bin], 1u);
+            atomicAdd(&sh->fresh[jj][bin >> 1], 1u << (16u * (bin & 1u)));
          }
       }
       __syncthreads();
@@ -357,7 +357,7 @@ __device__ inline uint32_t zh_split_search_wg(zh_split_shared_t *sh, zh_split_wa
       for (uint32_t jj = 0; jj < nj; jj++) {
          const uint32_t j = j0 + jj;
          const uint32_t nfresh = j == 0 ? c0 - t0 : 256u;
-         const uint32_t fr = lane < 18 ? sh->fresh[jj][lane] : 0u;
+         const uint32_t fr = lane < 18 ? (sh->fresh[jj][lane >> 1] >> (16u * (lane & 1u))) & 0xffffu : 0u;
          if (nseen) {
             uint32_t d = 0;
             if (lane < 18) {
