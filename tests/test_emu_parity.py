@@ -154,6 +154,27 @@ def test_files_mode_each_input_is_its_own_stream(emu, oracle):
         ctx.close()
 
 
+def test_files_mode_in_staggered_runs(emu, oracle, monkeypatch):
+    """A files batch runs as staggered runs of inputs like a batch of max-blocks (zh_enqueue_files): with ZULTRA_HIP_STREAMS=3 twelve
+    inputs are three runs of four; the sub-block descriptors come back in batch coordinates."""
+    monkeypatch.setenv("ZULTRA_HIP_STREAMS", "3")
+    sizes = (4096, 1500, 1, 3000, 777, 4000, 2048, 12, 3500, 4096, 100, 2500)
+    files = [corpus.json_like(n, 60 + k) if k % 3 else corpus.text_like(n, 60 + k) for k, n in enumerate(sizes)]
+    data = np.concatenate(files)
+    offs = np.cumsum([0] + [len(f) for f in files[:-1]])
+    ctx = emu.files_context(4096, len(files))
+    try:
+        fo = ctx.compress_files(data, offs, [len(f) for f in files])
+        assert ctx.stats()["runs"] == 3
+        stream = ctx.stream_read(int(fo[-1]))
+        for k, f in enumerate(files):
+            assert stream[int(fo[k]):int(fo[k + 1])].tobytes() == oracle.memory_compress(f, 0, 32768), k
+        for k, lin in enumerate(ctx.block_crc32()):
+            assert emu.crc32_append(0, lin, len(files[k])) == zlib.crc32(files[k].tobytes())
+    finally:
+        ctx.close()
+
+
 def test_edge_sizes_and_tiny_alphabets_vs_oracle(emu, oracle):
     # every size 1..48 over alphabets of 1, 2 and 3 symbols: window ends, the last five positions of a window (not in the
     # 6-gram order), byte runs of every residue (the GPU suite runs the full grid: test_gpu_parity.py)

@@ -189,9 +189,13 @@ def test_full_size_properties(gpu, oracle):
         check_window(gpu, oracle, d[lo - prev: lo + 65536], prev, 65536, max_block=65536, tag="blk%d" % blk)
 
 
-def test_files_mode_graph_replay_vs_oracle(gpu, oracle):
+@pytest.mark.parametrize("runs", ["default", "3"])
+def test_files_mode_graph_replay_vs_oracle(gpu, oracle, monkeypatch, runs):
     """BASELINE configuration 5 in miniature: many small JSON-like inputs, one raw deflate stream each, the kernel sequence
-    captured in a hipGraph on the first batch and replayed on the second (different contents, same batch shape)."""
+    captured in a hipGraph on the first batch and replayed on the second (different contents, same batch shape) — as one run of
+    inputs (the default for so few) and as three staggered runs forked inside the graph."""
+    if runs != "default":
+        monkeypatch.setenv("ZULTRA_HIP_STREAMS", runs)
     nfiles = 300
     ctx = gpu.files_context(4096, nfiles)
     try:
@@ -202,6 +206,7 @@ def test_files_mode_graph_replay_vs_oracle(gpu, oracle):
             data = np.concatenate(files)
             offs = np.cumsum([0] + sizes[:-1])
             fo = ctx.compress_files(data, offs, sizes)
+            assert ctx.stats()["runs"] == (1 if runs == "default" else int(runs))
             stream = ctx.stream_read(int(fo[-1]))
             crcs = ctx.block_crc32()
             for k in range(0, nfiles, 1 if batch == 0 else 3):

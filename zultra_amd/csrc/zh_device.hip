@@ -111,6 +111,7 @@ struct zultra_hip_ctx_s {
    hipGraph_t graph;
    hipGraphExec_t graph_exec;
    uint32_t graph_nblocks;
+   int graph_runs;
    const uint8_t *graph_data;
    std::vector<uint64_t> file_off;
    int nlanes;
@@ -695,61 +696,115 @@ __global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, 
    sub_base[b] = b;
 }
 
-// The kernel sequence of a files-mode batch on one stream, with no host decision in it. Captured into a hipGraph the
-// first time a (batch size, input pointer) pair is seen and replayed afterwards: one graph launch per batch.
-static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nb, hipStream_t st) {
-   const zh_block_t *blk = c->d_blocks;
+// The kernel sequence of one run (inputs b0 .. b0 + nb) of a files-mode batch, with no host decision in it: run k on stream st,
+// its chains on `side`. Per-block buffers are addressed as base + block * stride, so a run sees the base pointers advanced to its
+// first input; sub-block indices are local to the run (zh_run_files shifts the descriptors).
+static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, hipStream_t st, hipStream_t side) {
+   const zh_block_t *blk = c->d_blocks + b0;
    const uint32_t mf_grid = min(nb, c->num_cus);   // persistent workgroups, one per CU (zh_matchfinder.h)
-   ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr, 0, ((size_t)nb * 2 + 2) * sizeof(uint32_t), st));
-   ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)c->d_segs, c->d_sort_a, c->d_sort_b, c->d_prev3, c->d_runs, c->sort_stride,
-             c->run_stride, 0, nb, c->d_chunk_ctr + (size_t)nb * 2 + 1, c->d_pay);
-   ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, (const zh_seg_t *)c->d_segs, (const uint32_t *)c->d_sort_a,
-             (const uint2 *)c->d_prev3, (const uint32_t *)c->d_runs, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, c->d_chunk_ctr, nb, 0u);   // small inputs: nothing worth sharing
-   if (zh_enqueue_tokenize(c, st, blk, 0, nb) != 0) return -1;
-   ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)c->d_ntok, c->d_split_tok, c->d_split_cnt, c->d_sub_base);
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, ZH_NCNT * sizeof(uint32_t), st));
-   ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, (size_t)nb * c->slot_stride, st));
-   ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)c->d_tok_pos, c->tok_stride, (const uint32_t *)c->d_ntok,
-             (const uint32_t *)c->d_split_tok, (const uint32_t *)c->d_split_cnt, (const uint32_t *)c->d_sub_base, c->slot_stride, c->d_work, c->d_taskmap,
-             c->d_ntasks);
-   ZH_LAUNCH(zh_sb_init, nb, 64, st, (const uint16_t *)c->d_tok_info, c->tok_stride, (const zh_work_t *)c->d_work, c->d_states);
+   const uint64_t tasks_per_block = c->max_tasks / c->max_blocks;
+   const uint64_t t0 = (uint64_t)b0 * tasks_per_block;
+   uint32_t *ctr = c->d_chunk_ctr + (size_t)b0 * 2 + 2 * (size_t)k;   // this run's counters: 2 per segment (= input) + the two tickets
+   uint32_t *sa = c->d_sort_a + (uint64_t)b0 * c->sort_stride, *sb = c->d_sort_b + (uint64_t)b0 * c->sort_stride;
+   uint2 *p3 = c->d_prev3 + (uint64_t)b0 * c->sort_stride;
+   uint32_t *rn = c->d_runs + (uint64_t)b0 * c->run_stride;
+   uint32_t *cnt = c->d_ntasks + (size_t)k * ZH_CNT_STRIDE;
+   zh_work_t *work = c->d_work + b0;
+   zh_sbstate_t *states = c->d_states + b0;
+   uint2 *taskmap = c->d_taskmap + t0;
+   uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM, *hugelist = c->d_hugelist + t0, *task_bits = c->d_task_bits + t0;
+   uint8_t *payload = c->d_payload + (uint64_t)b0 * c->slot_stride;
+   uint32_t *best = c->d_best + (uint64_t)b0 * c->best_stride;
+   const uint64_t *bars = c->d_bars + (uint64_t)b0 * c->bar_stride;
+   const zh_match_t *match = c->d_match + (uint64_t)b0 * c->match_stride;
+   // (counters, payload slots and the copies of the results are the caller's, on the stream the runs fork from: zh_enqueue_files)
+   ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), sa, sb, p3, rn, c->sort_stride, c->run_stride, 0, nb,
+             ctr + (size_t)nb * 2 + 1, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride);
+   ZH_CHECK(c, hipEventRecord(c->lane_ev[k][2], st));   // the next run's matchfinder starts here
+   // (segment descriptors carry batch-wide input indices: the rows go to d_match + input * match_stride)
+   ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), (const uint32_t *)sa, (const uint2 *)p3,
+             (const uint32_t *)rn, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, ctr, nb, 0u);   // small inputs: nothing worth sharing
+   if (zh_enqueue_tokenize(c, st, blk, b0, nb) != 0) return -1;
+   ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0,
+             c->d_sub_base + b0);
+   ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)(c->d_tok_pos + (uint64_t)b0 * c->tok_stride), c->tok_stride, (const uint32_t *)(c->d_ntok + b0),
+             (const uint32_t *)(c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1)), (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride,
+             work, taskmap, cnt);
+   ZH_LAUNCH(zh_sb_init, nb, 64, st, (const uint16_t *)(c->d_tok_info + (uint64_t)b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
    const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
    // (inputs of a files batch are never cut into speculative segments: seg_min = all ones)
-   ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap,
-             (const uint32_t *)c->d_longest, c->tok_stride, c->d_hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu, (uint32_t)ZH_CUT_LEN, c->d_ntasks);
+   ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
+             (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu,
+             (uint32_t)ZH_CUT_LEN, cnt);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
-      hipStream_t side = c->side_stream[0];
-      ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass], st));
-      ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[0][2 * pass], 0));
-      ZH_LAUNCH(zh_parse_chain, min(nb, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride,
-                (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_hugelist, task_grid,
-                c->d_segtasks, (const uint2 *)c->d_segitems, c->d_vecs, 0u, 0u, c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
-                c->best_stride, c->d_hist_part, pass, c->d_ntasks + ZH_CNT_CHAIN_TICKET + pass, (uint64_t *)NULL);
-      ZH_CHECK(c, hipEventRecord(c->side_ev[0][2 * pass + 1], side));
-      ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, (const zh_match_t *)c->d_match, c->match_stride, (const uint64_t *)c->d_bars, c->bar_stride,
-                (const zh_work_t *)c->d_work, (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best,
-                c->best_stride, c->d_hist_part, pass, (uint32_t *)NULL);
-      ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[0][2 * pass + 1], 0));
-      ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)c->d_work, c->d_states, (const uint32_t *)c->d_hist_part, c->d_payload, pass);
+      ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
+      ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
+      ZH_LAUNCH(zh_parse_chain, min(nb, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+                (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, c->d_segtasks, (const uint2 *)c->d_segitems, c->d_vecs, 0u, 0u, cnt, (const zh_sbstate_t *)states, best,
+                c->best_stride, hist_part, pass, cnt + ZH_CNT_CHAIN_TICKET + pass, (uint64_t *)NULL);
+      ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
+      ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
+                (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
+      ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
+      ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass);
    }
-   ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work,
-             (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, c->d_best, c->best_stride, c->d_task_bits);
-   ZH_LAUNCH(zh_emit_tasks, task_grid, 64, st, c->cur_data, blk, (const uint64_t *)c->d_bars, c->bar_stride, (const zh_work_t *)c->d_work,
-             (const uint2 *)c->d_taskmap, (const uint32_t *)c->d_ntasks, (const zh_sbstate_t *)c->d_states, (const uint32_t *)c->d_best, c->best_stride,
-             (const uint32_t *)c->d_task_bits, c->d_payload, c->d_results);
-   ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc, c->d_adler);
-   ZH_CHECK(c, hipMemcpyAsync(c->h_adler, c->d_adler, 2 * nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-   ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results, nb * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
-   ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-   ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks, c->d_ntasks, ZH_NCNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+   ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt,
+             (const zh_sbstate_t *)states, best, c->best_stride, task_bits);
+   ZH_LAUNCH(zh_emit_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt,
+             (const zh_sbstate_t *)states, (const uint32_t *)best, c->best_stride, (const uint32_t *)task_bits, payload, c->d_results + b0);
+   ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
+   return 0;
+}
+
+// A files-mode batch: runs of inputs on streams of their own, each run's matchfinder behind the previous run's sort, exactly as a
+// batch of max-blocks (zultra_hip_compress_blocks) — but with nothing for the host to decide in between. On stream st0 and the
+// streams forked from it; captured into a hipGraph the first time a (batch size, input pointer) pair is seen and replayed
+// afterwards: one graph launch per batch.
+static uint32_t zh_files_run_lo(const zultra_hip_ctx_t *c, uint32_t nblocks, int k) { return (uint32_t)((uint64_t)nblocks * (uint64_t)k / (uint64_t)c->last_runs); }
+
+static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nblocks, hipStream_t st0) {
+   const int runs = c->last_runs;
+   // what the runs need cleared, and (below) the copies of what they produce, on the stream the runs fork from
+   ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr, 0, ((size_t)nblocks * 2 + 2 * (size_t)runs) * sizeof(uint32_t), st0));
+   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, ZH_NCNT * sizeof(uint32_t), st0));
+   ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, (size_t)nblocks * c->slot_stride, st0));
+   ZH_CHECK(c, hipEventRecord(c->ev2[1], st0));   // fork
+   for (int k = 0; k < runs; k++) {
+      hipStream_t st = k ? c->lane_stream[k] : st0;
+      if (k) {
+         ZH_CHECK(c, hipStreamWaitEvent(st, c->ev2[1], 0));
+         if (c->stagger_ev) ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k - 1][2], 0));
+      }
+      const uint32_t b0 = zh_files_run_lo(c, nblocks, k), b1 = zh_files_run_lo(c, nblocks, k + 1);
+      if (zh_enqueue_files_run(c, k, b0, b1 - b0, st, c->side_stream[k]) != 0) return -1;
+      if (k) ZH_CHECK(c, hipEventRecord(c->lane_ev[k][17], st));
+   }
+   for (int k = 1; k < runs; k++) ZH_CHECK(c, hipStreamWaitEvent(st0, c->lane_ev[k][17], 0));   // join
+   ZH_CHECK(c, hipMemcpyAsync(c->h_adler, c->d_adler, 2 * (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));
+   ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results, (size_t)nblocks * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st0));
+   ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));
+   ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks, c->d_ntasks, ZH_NCNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));
    return 0;
 }
 
 static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
    hipStream_t st = c->lane_stream[0];
+   {
+      // one run — the captured graph — unless ZULTRA_HIP_STREAMS asks for more (down to four inputs per run). Measured, 1 M inputs of
+      // 4 KiB in batches of 65 536: 621 k files/s as one run, 582 / 634 / 637 k as 2 / 3 / 4 runs: not worth leaving the graph for.
+      const uint64_t want = c->auto_runs ? 1u : min((uint64_t)c->nlanes, (uint64_t)nblocks / 4u);
+      c->last_runs = (int)max((uint64_t)1, want);
+   }
 #ifndef ZH_EMU
-   if (!c->graph_exec || c->graph_nblocks != nblocks || c->graph_data != c->cur_data) {
+   if (c->last_runs > 1) {
+      // Several runs: launched directly, ~35 launches per run and batch. (Forking the runs' streams inside a stream capture crashes in
+      // hipStreamEndCapture when another HIP runtime — torch's — lives in the process; the launches of a batch are 0.5 ms of host time.)
+      ZH_CHECK(c, hipEventRecord(c->lane_ev[0][1], st));
+      if (zh_enqueue_files(c, nblocks, st) != 0) return -1;
+   }
+   else {
+   if (!c->graph_exec || c->graph_nblocks != nblocks || c->graph_data != c->cur_data || c->graph_runs != c->last_runs) {
       if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
       if (c->graph) (void)hipGraphDestroy(c->graph);
       c->graph_exec = NULL;
@@ -763,9 +818,11 @@ static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
       ZH_CHECK(c, hipGraphInstantiate(&c->graph_exec, c->graph, NULL, NULL, 0));
       c->graph_nblocks = nblocks;
       c->graph_data = c->cur_data;
+      c->graph_runs = c->last_runs;
    }
    ZH_CHECK(c, hipEventRecord(c->lane_ev[0][1], st));
    ZH_CHECK(c, hipGraphLaunch(c->graph_exec, st));
+   }
 #else
    ZH_CHECK(c, hipEventRecord(c->lane_ev[0][1], st));
    if (zh_enqueue_files(c, nblocks, st) != 0) return -1;
@@ -778,6 +835,13 @@ static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
       c->sub_base[b] = b;
    }
    c->results.assign(c->h_results, c->h_results + nblocks);
+   for (int k = 1; k < c->last_runs; k++) {   // sub-block descriptors in batch coordinates
+      const uint32_t b0 = zh_files_run_lo(c, nblocks, k), b1 = zh_files_run_lo(c, nblocks, k + 1);
+      for (uint32_t b = b0; b < b1; b++) {
+         c->results[b].block += b0;
+         c->results[b].bits_off += (uint64_t)b0 * c->slot_stride;
+      }
+   }
    memcpy(c->crc.data(), c->h_crc, nblocks * sizeof(uint32_t));
    c->adler.assign(c->h_adler, c->h_adler + 2 * (size_t)nblocks);
    c->nsubs = nblocks;
@@ -1226,7 +1290,7 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
       out->cut_redone += cnt[ZH_CNT_SEG_FAILED];   // over the four passes
    }
    for (uint32_t b = 0; b < c->nblocks; b++) out->positions += c->blocks[b].n;
-   out->runs = c->files_mode ? 1u : (uint32_t)c->last_runs;
+   out->runs = (uint32_t)c->last_runs;
 }
 
 extern "C" int zultra_hip_get_matches(zultra_hip_ctx_t *c, uint32_t block, uint16_t *out) {
