@@ -92,6 +92,7 @@ struct zultra_hip_ctx_s {
    uint32_t seg_whole;          // ... with fewer, zh_parse_chain takes the segments — and the cut tasks shorter than this whole (ZULTRA_HIP_SEG_WHOLE)
    int auto_runs;               // ZULTRA_HIP_STREAMS not set: the number of runs follows the batch size
    int last_runs;               // runs the last batch was cut into
+   uint32_t mf_cu_pct;          // share of the CUs the matchfinder kernels' grids cover, percent
    uint32_t split_waves;        // waves per splitter workgroup, 0 = by max-block size
    int stagger_ev;              // event of the previous run that a run's matchfinder waits for (0: none)
    uint32_t first_run_pct;      // share of the first run of a batch in percent of an equal share
@@ -431,6 +432,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       if (c->task_waves > 32) c->task_waves = 32;
       const char *spw = getenv("ZULTRA_HIP_SPLIT_WAVES");   // waves per splitter workgroup (2, 4, 8, 16; default by max-block size)
       c->split_waves = spw ? (uint32_t)atoi(spw) : 0u;
+      const char *mfp = getenv("ZULTRA_HIP_MF_CUS");   // share of the CUs the matchfinder's persistent workgroups take, in percent (tuning experiments)
+      c->mf_cu_pct = mfp ? (uint32_t)max(1, min(100, atoi(mfp))) : 100u;
       const char *sg = getenv("ZULTRA_HIP_STAGGER");   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group, 3 zh_mf_frontier (default), 4 the splitter
       c->stagger_ev = sg ? atoi(sg) : 2;   // measured, 2 instead of 3: 100 MB of real text 51.9 -> 49.8 ms, configuration 3 31.6 -> 30.5, configuration 4 972 -> 910
       if (c->stagger_ev != 0 && (c->stagger_ev < 2 || c->stagger_ev > 4)) c->stagger_ev = 3;
@@ -931,7 +934,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       uint2 *p3 = c->d_prev3 + (uint64_t)sg0 * c->sort_stride;
       uint32_t *rn = c->d_runs + (uint64_t)sg0 * c->run_stride;
       uint32_t *ctr = c->d_chunk_ctr + (size_t)sg0 * 2 + 2 * (size_t)k;   // this run's counters: 2 per segment + the two tickets
-      const uint32_t mf_grid = min(nsg, c->num_cus);                      // persistent workgroups, one per CU (zh_matchfinder.h)
+      const uint32_t mf_grid = min(nsg, max(1u, c->num_cus * c->mf_cu_pct / 100u));   // persistent workgroups, one per CU (zh_matchfinder.h)
       ZH_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nsg * 2 + 2) * sizeof(uint32_t), st));
       // token bits are ORed into the payload slots: cleared here, long before stage 3 needs them (the fill runs next to the matchfinder)
       ZH_CHECK(c, hipMemsetAsync(c->d_payload + (uint64_t)b0 * c->slot_stride, 0, (size_t)nb * c->slot_stride, st));
