@@ -368,11 +368,16 @@ zh_post_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ b
    zh_sync();
 
    if (dynamic) {   // the static path has no post-optimisation (blockdeflate.c:836-858)
+      // (a task can be tens of thousands of positions — a whole chain — and a tile's work hangs on one global load: the next tile's is
+      // issued before this tile is worked on. A tile's literalisations may reach into the tiles loaded ahead, but only at positions the
+      // chain jumps over: what the walk reads of a position that is a token start is never changed under it.)
       uint32_t carry = 0;
+      uint32_t b_next = (t0 + lane < t1) ? best[t0 + lane - prev] : 0;
       for (uint32_t base = t0; base < t1; base += 64) {
          const uint32_t limit = min(64u, t1 - base);
          const uint32_t pos = base + lane;
-         const uint32_t b = (pos < t1) ? best[pos - prev] : 0;
+         const uint32_t b = b_next;
+         b_next = (pos + 64 < t1) ? best[pos + 64 - prev] : 0;
          const uint32_t len = b & 0xffffu;
          const uint64_t mask = zh_chain_mask(len, carry, limit);
          if (((mask >> lane) & 1ull) && len >= ZH_MIN_MATCH) {
@@ -400,13 +405,19 @@ zh_post_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ b
 
    // bits of the task's tokens under the final codes
    uint32_t bits = 0, carry = 0;
+   uint32_t b_next = 0, byte_next = 0;
+   if (t0 + lane < t1) {
+      b_next = best[t0 + lane - prev];
+      byte_next = win[t0 + lane];
+   }
    for (uint32_t base = t0; base < t1; base += 64) {
       const uint32_t limit = min(64u, t1 - base);
       const uint32_t pos = base + lane;
-      uint32_t b = 0, byte = 0;
-      if (pos < t1) {
-         b = best[pos - prev];
-         byte = win[pos];
+      const uint32_t b = b_next, byte = byte_next;
+      b_next = 0;
+      if (pos + 64 < t1) {   // the next tile's loads, under this tile's work
+         b_next = best[pos + 64 - prev];
+         byte_next = win[pos + 64];
       }
       const uint32_t len = b & 0xffffu;
       const uint64_t mask = zh_chain_mask(len, carry, limit);
@@ -506,13 +517,19 @@ zh_emit_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ b
       zh_sync();
 
       uint32_t carry = 0;
+      uint32_t b_next = 0, byte_next = 0;
+      if (t0 + lane < t1) {
+         b_next = best[t0 + lane - prev];
+         byte_next = win[t0 + lane];
+      }
       for (uint32_t base = t0; base < t1; base += 64) {
          const uint32_t limit = min(64u, t1 - base);
          const uint32_t pos = base + lane;
-         uint32_t b = 0, byte = 0;
-         if (pos < t1) {
-            b = best[pos - prev];
-            byte = win[pos];
+         const uint32_t b = b_next, byte = byte_next;
+         b_next = 0;
+         if (pos + 64 < t1) {   // the next tile's loads, under this tile's work
+            b_next = best[pos + 64 - prev];
+            byte_next = win[pos + 64];
          }
          const uint32_t len = b & 0xffffu;
          const uint64_t mask = zh_chain_mask(len, carry, limit);

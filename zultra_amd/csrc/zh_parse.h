@@ -149,13 +149,19 @@ __device__ inline void zh_walk_histogram_wave(uint32_t *hist /* ZH_NSYM, zeroed 
                                               const uint32_t *best) {
    const uint32_t lane = zh_lane();
    uint32_t carry = 0;
+   uint32_t b_next = 0, byte_next = 0;
+   if (t0 + lane < t1) {
+      b_next = best[t0 + lane - prev];
+      byte_next = win[t0 + lane];
+   }
    for (uint32_t base = t0; base < t1; base += 64) {
       const uint32_t limit = min(64u, t1 - base);
       const uint32_t pos = base + lane;
-      uint32_t b = 0, byte = 0;
-      if (pos < t1) {
-         b = best[pos - prev];
-         byte = win[pos];
+      const uint32_t b = b_next, byte = byte_next;
+      b_next = 0;
+      if (pos + 64 < t1) {   // the next tile's loads, under this tile's work (the walk of a chain task is thousands of tiles long)
+         b_next = best[pos + 64 - prev];
+         byte_next = win[pos + 64];
       }
       const uint32_t len = b & 0xffffu;
       const uint64_t mask = zh_chain_mask(len, carry, limit);
