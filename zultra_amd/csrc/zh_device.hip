@@ -92,6 +92,7 @@ struct zultra_hip_ctx_s {
    uint32_t seg_whole;          // ... with fewer, zh_parse_chain takes the segments — and the cut tasks shorter than this whole (ZULTRA_HIP_SEG_WHOLE)
    int auto_runs;               // ZULTRA_HIP_STREAMS not set: the number of runs follows the batch size
    int last_runs;               // runs the last batch was cut into
+   int always_persistent;       // zh_parse_tasks always runs as persistent waves (ZULTRA_HIP_TASK_WAVES per CU)
    uint32_t mf_cu_pct;          // share of the CUs the matchfinder kernels' grids cover, percent
    uint32_t split_waves;        // waves per splitter workgroup, 0 = by max-block size
    int stagger_ev;              // event of the previous run that a run's matchfinder waits for (0: none)
@@ -432,6 +433,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       if (c->task_waves > 32) c->task_waves = 32;
       const char *spw = getenv("ZULTRA_HIP_SPLIT_WAVES");   // waves per splitter workgroup (2, 4, 8, 16; default by max-block size)
       c->split_waves = spw ? (uint32_t)atoi(spw) : 0u;
+      const char *ap = getenv("ZULTRA_HIP_PERSISTENT_TASKS");   // zh_parse_tasks as a bounded number of persistent waves per CU even when a run has no chains
+      c->always_persistent = ap ? atoi(ap) : 0;
       const char *mfp = getenv("ZULTRA_HIP_MF_CUS");   // share of the CUs the matchfinder's persistent workgroups take, in percent (tuning experiments)
       c->mf_cu_pct = mfp ? (uint32_t)max(1, min(100, atoi(mfp))) : 100u;
       const char *sg = getenv("ZULTRA_HIP_STAGGER");   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group, 3 zh_mf_frontier (default), 4 the splitter
@@ -1058,7 +1061,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                       (const uint2 *)taskmap, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, segtasks, (const uint2 *)segwaves, vecs, ntasks);
             ZH_CHECK(c, hipEventRecord(c->seg_ev[k][pass], sg));
          }
-         if (nchains || seg_wide)
+         if (nchains || seg_wide || c->always_persistent)
             ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                       (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
                       ntasks + ZH_CNT_TASK_TICKET + pass);
