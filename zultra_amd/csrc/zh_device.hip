@@ -96,6 +96,7 @@ struct zultra_hip_ctx_s {
    uint32_t mf_cu_pct;          // share of the CUs the matchfinder kernels' grids cover, percent
    uint32_t split_waves;        // waves per splitter workgroup, 0 = by max-block size
    int stagger_ev;              // event of the previous run that a run's matchfinder waits for (0: none)
+   uint32_t last_run_pct;       // share of the last run, likewise
    uint32_t first_run_pct;      // share of the first run of a batch in percent of an equal share
    uint32_t seg_wide;           // a run with at least this many segments parses them with zh_parse_segments (ZULTRA_HIP_SEG_WIDE)
    int16_t *d_vecs;             // two cost vectors per segment
@@ -444,6 +445,10 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->first_run_pct = fr ? (uint32_t)atoi(fr) : 100u;
       if (c->first_run_pct < 10u) c->first_run_pct = 10u;
       if (c->first_run_pct > 100u) c->first_run_pct = 100u;
+      const char *lr = getenv("ZULTRA_HIP_LAST_RUN");   // share of the last run, likewise (three runs and more)
+      c->last_run_pct = lr ? (uint32_t)atoi(lr) : 100u;
+      if (c->last_run_pct < 10u) c->last_run_pct = 10u;
+      if (c->last_run_pct > 100u) c->last_run_pct = 100u;
       const char *e = getenv("ZULTRA_HIP_STREAMS");
       c->nlanes = e ? atoi(e) : 4;
       c->auto_runs = e ? 0 : 1;   // not set: three runs, four for batches of 256 MiB and more (measured with the stagger above, runs = 2 / 3 / 4 / 6: 100 MB
@@ -900,7 +905,11 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       if (k <= 0) return 0u;
       if (k >= lanes) return nblocks;
       const uint64_t first = (uint64_t)nblocks * c->first_run_pct / (100ull * (uint64_t)lanes);
-      return (uint32_t)(first + ((uint64_t)nblocks - first) * (uint64_t)(k - 1) / (uint64_t)(lanes - 1));
+      if (lanes < 3) return (uint32_t)(first + ((uint64_t)nblocks - first) * (uint64_t)(k - 1) / (uint64_t)(lanes - 1));
+      const uint64_t last = (uint64_t)nblocks * c->last_run_pct / (100ull * (uint64_t)lanes);   // likewise the last run: its passes are the tail of the batch
+      const uint64_t mid = (uint64_t)nblocks - first - last;
+      if (k == lanes - 1) return (uint32_t)(nblocks - last);
+      return (uint32_t)(first + mid * (uint64_t)(k - 1) / (uint64_t)(lanes - 2));
    };
    const uint64_t tasks_per_block = c->max_tasks / c->max_blocks;
    hipStream_t st0 = c->lane_stream[0];
