@@ -170,6 +170,10 @@ inline void zh_wave_sync() {
    zh_emu::collect(0, [] { return (uint64_t)0; });
 }
 
+inline void zh_lockstep_sync() {
+   zh_emu::collect(0, [] { return (uint64_t)0; });
+}
+
 inline unsigned zh_lane() { return (unsigned)zh_emu::g_cur & 63u; }
 inline uint64_t zh_ballot(bool p) {
    using namespace zh_emu;
@@ -225,6 +229,23 @@ inline uint32_t zh_row_min(uint32_t v) {
       for (int i = lo; i < lo + 16 && i < (int)blockDim.x; i++) m = std::min(m, g_slot[i]);
       return m;
    });
+}
+inline uint32_t zh_quad_min(uint32_t v) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [] {
+      int lo = g_cur & ~3;
+      uint64_t m = ~0ull;
+      for (int i = lo; i < lo + 4 && i < (int)blockDim.x; i++) m = std::min(m, g_slot[i]);
+      return m;
+   });
+}
+inline uint32_t zh_quad_shr1(uint32_t v) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [] { return (g_cur & 3) ? g_slot[g_cur - 1] : g_slot[g_cur]; });
+}
+inline uint32_t zh_quad_lo2(uint32_t v) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [] { return (g_cur & 2) ? g_slot[g_cur - 2] : g_slot[g_cur]; });
 }
 inline uint32_t zh_wave_min(uint32_t v) {
    using namespace zh_emu;

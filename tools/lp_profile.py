@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Diagnostics: step and lane utilisation of zh_parse_lanes, from a profiling build of the library (-DZH_LP_PROFILE, built into build/).
+usage: python tools/lp_profile.py --build            (here, no GPU needed)
+       python tools/lp_profile.py [bytes] [corpus]   (on the GPU box)"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+SO = os.path.join(ROOT, "build", "libzultra_amd_lpprof.so")
+CSRC = os.path.join(ROOT, "zultra_amd", "csrc")
+if "--build" in sys.argv:
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-DZH_LP_PROFILE=1", "-I", CSRC, "-o", SO,
+                    os.path.join(CSRC, "zh_device.hip"), os.path.join(CSRC, "libzultra.cpp")], check=True)
+    sys.exit(0)
+import numpy as np  # noqa: E402
+
+import corpus  # noqa: E402
+from zultra_amd._ffi import Lib  # noqa: E402
+
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+kind = sys.argv[2] if len(sys.argv) > 2 else "pysrc"
+L = Lib(SO)
+d = corpus.real_text(size) if kind == "pysrc" else corpus.text_like_fast(size, 1000) if kind == "text" else corpus.mixed_config4(0, size >> 20)
+size, bs = len(d), 65536
+nb = (size + bs - 1) // bs
+blocks = [(b * bs - (32768 if b else 0), 32768 if b else 0, min(bs, size - b * bs)) for b in range(nb)]
+ctx = L.context(bs, nb)
+ctx.compress_blocks(d, blocks)
+f = L.L.zultra_hip_lp_profile
+f.argtypes = [C.c_void_p, C.c_int]
+f(None, 1)
+ctx.compress_blocks(d, blocks)
+out = np.zeros(8, dtype=np.uint64)
+f(out.ctypes.data, 0)
+t = ctx.timing()
+o = [float(x) for x in out]
+print("%s %d bytes: parse %.2f ms (all runs, 4 passes)" % (kind, size, t["parse_ms"]))
+print("   groups %d, pieces per group %.1f, steps per group %.1f" % (o[3], o[6] / max(1, o[3]), o[0] / max(1, o[3])))
+print("   quads with a position per step %.1f of 16, batches with a second plane %.2f" % (o[1] / max(1, o[0]), 4 * o[7] / max(1, o[0])))
+print("   cycles per step %.0f; per group: setup %.0f, steps %.0f, histogram %.0f cycles" % (o[2] / max(1, o[0]), o[4] / max(1, o[3]), o[2] / max(1, o[3]), o[5] / max(1, o[3])))

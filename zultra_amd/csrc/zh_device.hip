@@ -31,6 +31,7 @@
 #include "zh_matchfinder.h"
 #include "zh_parse.h"
 #include "zh_parse_chain.h"
+#include "zh_parse_lanes.h"
 #include "zh_split.h"
 #include "zh_stitch.h"
 
@@ -93,6 +94,8 @@ struct zultra_hip_ctx_s {
    int auto_runs;               // ZULTRA_HIP_STREAMS not set: the number of runs follows the batch size
    int last_runs;               // runs the last batch was cut into
    int always_persistent;       // zh_parse_tasks always runs as persistent waves (ZULTRA_HIP_TASK_WAVES per CU)
+   int parse_lanes;             // 1: zh_parse_lanes (a lane per piece) parses the tasks, 0: zh_parse_tasks (a 16-lane row per piece) (ZULTRA_HIP_PARSE_LANES)
+   uint32_t lane_waves;         // persistent zh_parse_lanes waves per CU next to chains
    uint32_t mf_cu_pct;          // share of the CUs the matchfinder kernels' grids cover, percent
    uint32_t split_waves;        // waves per splitter workgroup, 0 = by max-block size
    int stagger_ev;              // event of the previous run that a run's matchfinder waits for (0: none)
@@ -436,6 +439,10 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->split_waves = spw ? (uint32_t)atoi(spw) : 0u;
       const char *ap = getenv("ZULTRA_HIP_PERSISTENT_TASKS");   // zh_parse_tasks as a bounded number of persistent waves per CU even when a run has no chains
       c->always_persistent = ap ? atoi(ap) : 0;
+      const char *pl = getenv("ZULTRA_HIP_PARSE_LANES");
+      c->parse_lanes = pl ? atoi(pl) : 1;
+      const char *lw = getenv("ZULTRA_HIP_LANE_WAVES");
+      c->lane_waves = lw ? (uint32_t)max(1, min(16, atoi(lw))) : 8u;
       const char *mfp = getenv("ZULTRA_HIP_MF_CUS");   // share of the CUs the matchfinder's persistent workgroups take, in percent (tuning experiments)
       c->mf_cu_pct = mfp ? (uint32_t)max(1, min(100, atoi(mfp))) : 100u;
       const char *sg = getenv("ZULTRA_HIP_STAGGER");   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group, 3 zh_mf_frontier (default), 4 the splitter
@@ -755,6 +762,10 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
                 (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, c->d_segtasks, (const uint2 *)c->d_segitems, c->d_vecs, 0u, 0u, cnt, (const zh_sbstate_t *)states, best,
                 c->best_stride, hist_part, pass, cnt + ZH_CNT_CHAIN_TICKET + pass, (uint64_t *)NULL);
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
+      if (c->parse_lanes)
+         ZH_LAUNCH(zh_parse_lanes, (task_grid + ZH_LP_TASKS - 1) / ZH_LP_TASKS, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
+      else
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
                 (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
       ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
@@ -1049,6 +1060,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       const uint32_t chain_grid = min(nchains, (uint32_t)ZH_CHAIN_GRID);
       const uint32_t persistent_grid = min(task_grid, c->num_cus * c->task_waves);
       for (int pass = 0; pass <= 3; pass++) {
+         if (getenv("ZH_DEBUG_ONEPASS") && pass > 0) break;
          // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
          hipStream_t side = c->side_stream[k];
          if (nchains) {
@@ -1070,7 +1082,17 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                       (const uint2 *)taskmap, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, segtasks, (const uint2 *)segwaves, vecs, ntasks);
             ZH_CHECK(c, hipEventRecord(c->seg_ev[k][pass], sg));
          }
-         if (nchains || seg_wide || c->always_persistent)
+         if (c->parse_lanes) {
+            const uint32_t lane_grid = (task_grid + ZH_LP_TASKS - 1) / ZH_LP_TASKS;
+            if (nchains || seg_wide || c->always_persistent)
+               ZH_LAUNCH(zh_parse_lanes, min(lane_grid, c->num_cus * c->lane_waves), 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
+                         ntasks + ZH_CNT_TASK_TICKET + pass);
+            else
+               ZH_LAUNCH(zh_parse_lanes, lane_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
+         }
+         else if (nchains || seg_wide || c->always_persistent)
             ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                       (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
                       ntasks + ZH_CNT_TASK_TICKET + pass);
@@ -1285,6 +1307,17 @@ extern "C" int zultra_hip_mf_profile(unsigned long long *out, int reset) {
    if (reset) {
       unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (hipMemcpyToSymbol(HIP_SYMBOL(zh_mf_prof), z, sizeof(z)) != hipSuccess) return -1;
+   }
+   return 0;
+}
+#endif
+
+#ifdef ZH_LP_PROFILE
+extern "C" int zultra_hip_lp_profile(unsigned long long *out, int reset) {
+   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(zh_lp_prof), sizeof(zh_lp_prof)) != hipSuccess) return -1;
+   if (reset) {
+      unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (hipMemcpyToSymbol(HIP_SYMBOL(zh_lp_prof), z, sizeof(z)) != hipSuccess) return -1;
    }
    return 0;
 }

@@ -1,0 +1,465 @@
+// zh_parse_lanes.h — the backward optimal parse (reference src/blockdeflate.c:254-323, zultra_optimize_matches_lwd) with a
+// QUAD OF LANES PER PIECE: a wave advances 16 independent recurrences per step, and a step is ~140 wave instructions.
+//
+// Why. zh_parse_tasks (zh_parse.h) gives a piece to a 16-lane row, lane s pricing length 3+s: whatever the position offers, a
+// step costs the same ~120 wave instructions for four positions (profiles/r02e_sq_counters.csv: 31.7 vector instructions per
+// position and pass, the vector unit saturated). What a position needs is much less once the work is ordered differently.
+//
+// One step for the position p of a piece (a barrier-to-barrier run, zh_parse.h), by the four lanes q = 0..3 of its quad:
+//   * costs live in an LDS ring [slot][piece] of uint16: cost[p + k] sits k slots behind the slot written this step, the same
+//     slot for every piece of the wave (all pieces step together), so the reads are at immediate offsets from a per-lane base.
+//     A piece is at most ZH_COOP_MIN positions and a position costs at most 15 bits: absolute costs from the piece's end fit 16 bits.
+//   * prefix minima over the lengths: G(k) = cost[p+k] + price of length k, P(L) = min over k <= L of (G(k), larger k first),
+//     L = 3..39 — none of it depends on the position's matches. Lane q scans the ten lengths 3+10q .. 12+10q, the lanes' totals are
+//     combined with two DPP steps, P goes to an LDS scratch [L][piece].
+//   * the reference tries every pair (slot m, k <= len_m) in the order m ascending, k descending, and takes strict improvements
+//     only: the winner is the minimum of (cost, m, -k). For slot m all of its k's at once: P(min(len_m, room)) + distance price.
+//     So each slot costs one gather from the scratch and one add (lane q takes slots q and 4+q); slots stored with length >= 40
+//     are tried at their clamped length only (blockdeflate.c:286-297): one gather from the ring.
+//   * a quad minimum picks the position's best match; literal first, a match must be strictly cheaper (:292,:307).
+// Keys: cost << 9 | slot << 6 | (39 - k), as in zh_parse.h.
+// (A lane per piece — 64 recurrences per wave — needs 4 x the LDS per wave, leaves one wave per SIMD and, measured, 10 to 20 of
+// the 64 lanes with a position: barrier-free runs of a few hundred positions are common enough that one of 64 pieces always is one.)
+//
+// Memory: the quad fetches four positions per request — lane q the row, the second plane of the row and the byte of position
+// p-1-q — two batches ahead of their use, stages them in LDS, and stores the four parse entries of a batch with one instruction.
+//
+// Work: a wave takes ZH_LP_TASKS consecutive tasks of the run's task list (zh_parse.h: a task = ~2048 positions between two
+// barriers), groups them by sub-block (prices differ), cuts each task into the same pieces as zh_parse_tasks did and hands the
+// pieces to its quads, the long ones first, a new one whenever a quad runs out. Tasks with a barrier-free run of more than
+// ZH_COOP_MIN positions are left to zh_parse_chain / zh_parse_segments exactly as before (zh_list_huge lists them with the same
+// test). The histogram of the chosen parse (blockdeflate.c:371-400) is taken by the 64 lanes, each walking pieces forward (a
+// piece starts on a token boundary), and stored in the slot of the group's first task (zh_sb_build sums a sub-block's slots).
+#pragma once
+#include <zh_platform.h>
+#include "zh_common.h"
+#include "zh_parse.h"
+
+#ifndef ZH_LP_TASKS
+#define ZH_LP_TASKS 8u             // tasks per wave
+#endif
+#define ZH_LP_C 16u                // pieces in flight per wave (one per quad)
+#define ZH_LP_RING 258u            // a step reads cost[p+1 .. p+258] and then writes cost[p]
+#define ZH_LP_KPL 10u              // lengths per lane: lane q scans 3 + 10 q .. 12 + 10 q (40 .. 42 do not exist)
+#define ZH_LP_NL (4u * ZH_LP_KPL)  // rows of the prefix scratch
+#define ZH_LP_MIRROR (3u + ZH_LP_NL)   // the first rows of the ring are kept twice: slot + 3 .. slot + 42 never wraps
+#define ZH_LP_MAXP (ZH_LP_TASKS * 32u) // pieces per group: a task without a run of more than ZH_COOP_MIN positions has fewer than 32
+#define ZH_LP_LONG 192u            // pieces of at least this many positions are handed out first
+#define ZH_LP_NOKEY 0xFFFFFFFFu
+#define ZH_LP_NOPRICE 0x80000000u  // "price" of a length that does not exist: above every real key, and no overflow when a cost is added
+
+#ifdef ZH_LP_PROFILE
+// probe builds only (tools/lp_profile.py): 0 steps, 1 quad-steps with a position, 2 cycles of the step loops, 3 groups, 4 cycles of the
+// group setup, 5 cycles of the histogram walks, 6 pieces, 7 batches with a second plane
+__device__ unsigned long long zh_lp_prof[8];
+#define ZH_LP_COUNT(slot_, n_) do { if (zh_lane() == 0) atomicAdd(&zh_lp_prof[slot_], (unsigned long long)(n_)); } while (0)
+#define ZH_LP_CLOCK() zh_clock()
+#else
+#define ZH_LP_COUNT(slot_, n_)
+#define ZH_LP_CLOCK() 0
+#endif
+
+struct alignas(16) zh_lp_ws_t {
+   uint16_t ring[ZH_LP_RING + ZH_LP_MIRROR][ZH_LP_C];   // [slot][piece]: cost of the piece, absolute from the piece's end
+   uint32_t pmin[ZH_LP_NL][ZH_LP_C];      // [L - 3][piece]: prefix minimum P(L) of this step
+   uint32_t stage0[ZH_LP_C][4][4];        // the batch: [piece][entry][slot 0..3] of the entries' rows,
+   uint32_t stage1[ZH_LP_C][4][4];        //            slots 4..7,
+   uint32_t stageb[ZH_LP_C][4];           //            the entries' bytes
+   uint32_t outp[ZH_LP_C][4];             // the batch's parse entries
+   uint32_t hist[ZH_NSYM];                // after the parse: histogram of the group
+   uint32_t plo[ZH_LP_MAXP], phi[ZH_LP_MAXP];   // the group's pieces: the long ones from the front, the others from the back
+   uint32_t bnd[ZH_MAXPIECES + 1];
+   uint8_t litprice[ZH_NLIT];             // code lengths with the 9-bit fill (blockdeflate.c:873-876)
+   uint8_t lencost[256];                  // price of length e+3 incl. extra bits (blockdeflate.c:216-219,263-264)
+   uint8_t distprice[512];                // price of a distance incl. extra bits, by the reference's table index (blockdeflate.c:45-58,127-136)
+};
+
+// index of distance d = v + 1 into the 512-entry distance tables of the reference (blockdeflate.c:45-58): v below 256 -> v, else
+// 256 + ((v - 256) >> 7)  [= 254 + (v >> 7), which is >= v exactly up to v = 255]
+__device__ __forceinline__ uint32_t zh_lp_dist_index(uint32_t v) { return min(v, 254u + (v >> 7)); }
+__device__ __forceinline__ uint32_t zh_lp_index_dist(uint32_t idx) { return idx < 256u ? idx + 1u : ((idx - 254u) << 7) + 1u; }   // smallest distance of the index
+
+// a batch of up to four positions of one piece: its entries off .. off + n - 1 are the positions p0, p0 - 1, ...; fresh = p0 is the
+// piece's last position (the recurrence starts there). A piece's first batch has at most three positions, in its LAST entries: the
+// step before a piece is always an empty one, which zeroes its ring slot — cost[piece end] — and nothing interrupts a piece.
+struct zh_lp_batch_t {
+   uint32_t p0, n, off;
+   bool fresh;
+};
+
+// Parses the tasks [g0, g1) of one sub-block (all of sub-block tm.x). All 64 lanes call.
+__device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_t g1, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
+                                            const zh_match_t *__restrict__ match, uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride,
+                                            const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
+                                            uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass) {
+   const uint2 tm0 = taskmap[g0];
+   const zh_work_t wk = work[tm0.x];
+   const zh_sbstate_t *st = states + tm0.x;
+   if (st->failed) return;
+   if (!st->is_dynamic && pass > 0) return;   // static sub-blocks are parsed once (blockdeflate.c:836-858)
+   const zh_block_t blk = blocks[wk.block];
+   const uint8_t *win = data + blk.win_off;
+   const uint32_t prev = blk.prev;
+   const uint4 *rows = (const uint4 *)(match + (uint64_t)wk.block * match_stride);   // row r = pos - prev: slots 0..3 (zh_common.h)
+   const uint4 *rows_hi = rows + ZH_ROW_HI_OFF(match_stride);                        // ... and 4..7, present when slot 3 holds a match
+   const uint64_t *bar = bars + (uint64_t)wk.block * bar_stride;
+   uint32_t *best = best_all + (uint64_t)wk.block * best_stride;
+   const uint32_t lane = zh_lane(), q = lane & 3u, piece = lane >> 2;
+   const uint32_t sb_end = wk.start + wk.size;
+   const uint64_t lt_mask = (1ull << lane) - 1ull, lt_quad = (1ull << (lane & ~3u)) - 1ull;
+
+   const uint64_t tic0 = ZH_LP_CLOCK();
+   zh_sync();   // the previous group is done with the workspace
+   // ---- prices of the codes in force; unused symbols price at 9 / 6 bits (blockdeflate.c:873-881) ---------------
+   for (uint32_t k = lane; k < ZH_NLIT; k += 64) {
+      const uint32_t l = st->lit_len[k];
+      ws.litprice[k] = (uint8_t)(l ? l : 9u);
+   }
+   for (uint32_t k = lane; k < 512u; k += 64) {
+      const int sym = zh_dist_sym(zh_lp_index_dist(k));
+      const uint32_t l = st->dist_len[sym];
+      ws.distprice[k] = (uint8_t)((l ? l : 6u) + (uint32_t)zh_dist_xbits(sym));
+   }
+   zh_sync();
+   for (uint32_t e = lane; e < 256; e += 64) {
+      const int idx = zh_len_idx(e + 3);
+      ws.lencost[e] = (uint8_t)(ws.litprice[257 + idx] + zh_lenidx_xbits(idx));
+   }
+   zh_sync();
+   // price << 9 | (39 - k) of the lane's ten lengths k = 3 + 10 q + j
+   uint32_t kc[ZH_LP_KPL];
+#pragma unroll
+   for (uint32_t j = 0; j < ZH_LP_KPL; j++) {
+      const uint32_t e = ZH_LP_KPL * q + j;   // k - 3
+      kc[j] = e < ZH_LEAVE_ALONE - ZH_MIN_MATCH ? (((uint32_t)ws.lencost[e] << 9) | (36u - e)) : ZH_LP_NOPRICE;
+   }
+
+   // ---- the group's pieces ---------------------------------------------------------------------------------------------
+   uint32_t nlongp = 0, nshortp = 0;
+   uint64_t parsed = 0;   // bit j: task g0 + j is parsed here
+   for (uint32_t gt = g0; gt < g1; gt++) {
+      const uint32_t j = taskmap[gt].y;
+      const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, j, wk.ntasks);
+      const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, j + 1, wk.ntasks);
+      const uint32_t np = zh_task_pieces(ws.bnd, bar, prev, t0, t1, lane);
+      zh_sync();
+      // a barrier-free run of more than ZH_COOP_MIN positions: zh_list_huge has listed the task for zh_parse_chain / zh_parse_segments
+      const bool huge = zh_task_is_huge(ws.bnd, np, lane);
+      if (!huge && nlongp + nshortp + np <= ZH_LP_MAXP) {
+         const uint32_t lo = lane < np ? ws.bnd[lane] : 0u, hi = lane < np ? ws.bnd[lane + 1] : 0u;
+         const bool is_l = hi - lo >= ZH_LP_LONG, is_s = hi > lo && !is_l;   // (empty pieces are dropped)
+         const uint64_t ml = zh_ballot(is_l), ms = zh_ballot(is_s);
+         if (is_l) {
+            const uint32_t at = nlongp + (uint32_t)zh_popc64(ml & lt_mask);
+            ws.plo[at] = lo;
+            ws.phi[at] = hi;
+         }
+         if (is_s) {
+            const uint32_t at = ZH_LP_MAXP - 1u - nshortp - (uint32_t)zh_popc64(ms & lt_mask);
+            ws.plo[at] = lo;
+            ws.phi[at] = hi;
+         }
+         nlongp += (uint32_t)zh_popc64(ml);
+         nshortp += (uint32_t)zh_popc64(ms);
+         parsed |= 1ull << (gt - g0);
+      }
+      zh_sync();
+   }
+   const uint32_t npieces = nlongp + nshortp;
+   ZH_LP_COUNT(3, 1);
+   ZH_LP_COUNT(6, npieces);
+   ZH_LP_COUNT(4, ZH_LP_CLOCK() - tic0);
+   const uint64_t tic1 = ZH_LP_CLOCK();
+#ifdef ZH_LP_PROFILE
+   uint32_t prof_steps = 0, prof_quads = 0, prof_hi = 0;
+   (void)prof_hi;
+#endif
+
+   // ---- the recurrences ----------------------------------------------------------------------------------------------------
+   // The only thing a step needs from the step before it is cost[p + 1], for the literal: everything about the matches of p looks
+   // at cost[p + 3] and beyond. So the steps are software-pipelined over three consecutive entries of the wave's stream — while
+   // entry i takes its decision (stage C), entry i+1 scans its prefix minima (stage B) and entry i+2 has its LDS reads in flight
+   // (stage A) — and no LDS round trip is waited for with nothing else to issue.
+   uint32_t next = 0;              // wave-uniform: pieces handed out so far
+   uint32_t slot = ZH_LP_RING - 4u;   // wave-uniform: the ring slot of the entry in stage A; cost[p + k] is at slot + k (mod ring)
+   uint32_t sp = 0, sleft = 0;     // the quad's fetch cursor: the next position to request is sp - 1, sleft are left of its piece
+   uint32_t c1 = 0;                // cost[p + 1] of the position deciding next: the literal's continuation
+   zh_lp_batch_t cur = {0, 0, 0, false}, old = {0, 0, 0, false}, b1 = {0, 0, 0, false}, b2 = {0, 0, 0, false};   // the batch entering stage A, the one before it, the next two
+   uint4 a1 = make_uint4(0, 0, 0, 0), a2 = make_uint4(0, 0, 0, 0), h1 = make_uint4(0, 0, 0, 0);   // this lane's entry of batch b1 / b2: first plane; of b1: second plane
+   uint32_t y1 = 0, y2 = 0;        // ... and its byte
+   uint16_t *const rq = &ws.ring[0][piece];       // the quad's ring column
+   uint32_t *const pq = &ws.pmin[0][piece];       // ... and its column of the prefix scratch
+
+   // the quad's next batch: a new piece when the current one is used up; requests its rows and bytes
+#define ZH_LP_FETCH(bt_, a_, y_)                                                                                    \
+   do {                                                                                                            \
+      const uint64_t idle_ = zh_ballot(sleft == 0 && q == 0);                                                      \
+      bool fresh_ = false;                                                                                         \
+      if (idle_ && next < npieces) {                                                                               \
+         const uint32_t i_ = next + (uint32_t)zh_popc64(idle_ & lt_quad);                                          \
+         if (sleft == 0 && i_ < npieces) {                                                                         \
+            const uint32_t at_ = i_ < nlongp ? i_ : ZH_LP_MAXP - nshortp + (i_ - nlongp);                          \
+            sp = ws.phi[at_];                                                                                      \
+            sleft = sp - ws.plo[at_];                                                                              \
+            fresh_ = true;                                                                                         \
+         }                                                                                                         \
+         next += (uint32_t)zh_popc64(idle_);                                                                       \
+      }                                                                                                            \
+      bt_.n = min(fresh_ ? 3u : 4u, sleft);                                                                        \
+      bt_.off = fresh_ ? 4u - bt_.n : 0u;                                                                          \
+      bt_.p0 = sp - 1u;                                                                                            \
+      bt_.fresh = fresh_;                                                                                          \
+      a_ = make_uint4(0, 0, 0, 0);                                                                                 \
+      y_ = 0;                                                                                                      \
+      if (q - bt_.off < bt_.n) {                                                                                   \
+         a_ = rows[bt_.p0 - (q - bt_.off) - prev];                                                                 \
+         y_ = win[bt_.p0 - (q - bt_.off)];                                                                         \
+      }                                                                                                            \
+      sp -= bt_.n;                                                                                                 \
+      sleft -= bt_.n;                                                                                              \
+   } while (0)
+   // second plane of this lane's entry of batch b1 (slots 4..7 exist only behind a full first plane, zh_common.h)
+#define ZH_LP_FETCH_HI()                                                                                           \
+   do {                                                                                                            \
+      h1 = make_uint4(0, 0, 0, 0);                                                                                 \
+      if (q - b1.off < b1.n && (a1.w & 0xffffu) >= ZH_MIN_MATCH) h1 = rows_hi[b1.p0 - (q - b1.off) - prev];        \
+   } while (0)
+
+   // what an entry carries from stage A to stage B, and from stage B to stage C
+   struct zh_lp_a_t {
+      uint32_t e0, e1, mlen0, mlen1, dp0, dp1, lit, lc0, lc1, rg0, rg1, j;
+      uint32_t cv[ZH_LP_KPL];
+      bool act, fresh;
+   };
+   struct zh_lp_b_t {
+      uint32_t e0, e1, mlen0, mlen1, key0, key1, lit, j;
+      bool act, fresh;
+   };
+   zh_lp_a_t ea;
+   zh_lp_b_t eb;
+   ea.e0 = ea.e1 = ea.mlen0 = ea.mlen1 = ea.dp0 = ea.dp1 = ea.lit = ea.lc0 = ea.lc1 = ea.rg0 = ea.rg1 = ea.j = 0;
+#pragma unroll
+   for (uint32_t k = 0; k < ZH_LP_KPL; k++) ea.cv[k] = 0;
+   ea.act = ea.fresh = false;
+   eb.e0 = eb.e1 = eb.mlen0 = eb.mlen1 = eb.lit = eb.j = 0;
+   eb.key0 = eb.key1 = ZH_LP_NOKEY;
+   eb.act = eb.fresh = false;
+
+   // (every ring slot a first piece may take for its end holds a zero)
+   for (uint32_t k = lane; k < (ZH_LP_RING + ZH_LP_MIRROR) * ZH_LP_C / 2u; k += 64) ((uint32_t *)&ws.ring[0][0])[k] = 0;
+   ZH_LP_FETCH(b1, a1, y1);
+   ZH_LP_FETCH(b2, a2, y2);
+   ZH_LP_FETCH_HI();
+   uint32_t drain = 0;   // the pipeline runs two entries behind the stream
+   for (;;) {
+      // ---- batch b1 enters stage A: into LDS, where every lane of the quad finds its slot of every entry ---------------------------
+      old = cur;
+      cur = b1;
+      if (!zh_ballot(cur.n != 0)) {   // (a quad without a batch has none later either: pieces are handed out in order)
+         if (drain) break;
+         drain = 1;   // one more round of empty entries lets the last real ones through stages B and C
+      }
+      *(uint4 *)&ws.stage0[piece][q][0] = a1;
+      *(uint4 *)&ws.stage1[piece][q][0] = h1;
+      ws.stageb[piece][q] = y1;
+      zh_lockstep_sync();
+      b1 = b2;
+      a1 = a2;
+      y1 = y2;
+      ZH_LP_FETCH_HI();
+      ZH_LP_FETCH(b2, a2, y2);
+
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+         // ======== stage A, first half, of entry (cur, j): the reads that need nothing but the entry's place in the stream ========
+         zh_lp_a_t na;
+         na.act = j - cur.off < cur.n;
+         na.fresh = cur.fresh && j == cur.off;
+         na.j = j;
+         const uint32_t apos = na.act ? cur.p0 - (j - cur.off) : wk.start;
+         const uint32_t aroom = sb_end - apos;   // end clamp (blockdeflate.c:283-284); a no-op away from the sub-block end
+         na.e0 = ws.stage0[piece][j][q];
+         na.e1 = ws.stage1[piece][j][q];
+         const uint32_t abyte = ws.stageb[piece][j];
+         {
+            const uint16_t *rk = rq + (slot + 3u + ZH_LP_KPL * q) * ZH_LP_C;
+#pragma unroll
+            for (uint32_t k = 0; k < ZH_LP_KPL; k++) na.cv[k] = rk[k * ZH_LP_C];
+         }
+#ifdef ZH_LP_PROFILE
+         prof_steps++;
+         prof_quads += (uint32_t)zh_popc64(zh_ballot(na.act && q == 0));
+#endif
+
+         // ======== stage C of the entry two before: literal first; a match must be strictly cheaper (:292,:307) =====================
+         {
+            const uint32_t cslot = slot + 2u >= ZH_LP_RING ? slot + 2u - ZH_LP_RING : slot + 2u;
+            const uint32_t bestkey = zh_quad_min(min(eb.key0, eb.key1));
+            if (eb.fresh) c1 = 0;
+            const uint32_t litc = c1 + eb.lit;
+            const uint32_t mc = bestkey >> 9;
+            const bool take = mc < litc;
+            const uint32_t c = eb.act ? (take ? mc : litc) : 0u;   // (an empty step leaves a zero: the end of the piece that may follow)
+            if (q == 0) {
+               rq[cslot * ZH_LP_C] = (uint16_t)c;
+               if (cslot < ZH_LP_MIRROR) rq[(cslot + ZH_LP_RING) * ZH_LP_C] = (uint16_t)c;
+               if (!take) ws.outp[piece][eb.j] = 0;
+            }
+            // the lane whose slot won writes the parse entry
+            if (take && eb.key0 == bestkey) ws.outp[piece][eb.j] = ((eb.e0 & 0xffffu) >= ZH_LEAVE_ALONE ? eb.mlen0 : 39u - (bestkey & 63u)) | (eb.e0 & 0xffff0000u);
+            if (take && eb.key1 == bestkey) ws.outp[piece][eb.j] = ((eb.e1 & 0xffffu) >= ZH_LEAVE_ALONE ? eb.mlen1 : 39u - (bestkey & 63u)) | (eb.e1 & 0xffff0000u);
+            c1 = c;
+            zh_lockstep_sync();
+            if (j == 1 && q - old.off < old.n) best[old.p0 - (q - old.off) - prev] = ws.outp[piece][q];   // the batch before this one is through
+         }
+
+         // ======== stage B of the entry before: prefix minima over the lengths, P(L) = min over 3 <= k <= L of
+         //          (cost[pos + k] + price(k)) << 9 | (39 - k): the lane's own ten, then the minimum of the lanes below it ==========
+         zh_lp_b_t nb;
+         {
+            uint32_t pl[ZH_LP_KPL];
+            uint32_t P = ZH_LP_NOKEY;
+#pragma unroll
+            for (uint32_t k = 0; k < ZH_LP_KPL; k++) {
+               P = min(P, (ea.cv[k] << 9) + kc[k]);
+               pl[k] = P;
+            }
+            uint32_t x = zh_quad_shr1(P);
+            x = q == 0 ? ZH_LP_NOKEY : x;
+            x = min(x, zh_quad_shr1(x));
+            x = min(x, zh_quad_lo2(x));
+            uint32_t *pk = pq + (ZH_LP_KPL * q) * ZH_LP_C;
+#pragma unroll
+            for (uint32_t k = 0; k < ZH_LP_KPL; k++) pk[k * ZH_LP_C] = min(pl[k], x);
+            zh_lockstep_sync();
+            // a slot's best pair (slot, k <= its clamped length) is P(that length) + its distance price; a slot stored with length
+            // >= 40 is tried at its full (clamped) length only (blockdeflate.c:286-297)
+            const uint32_t len0 = ea.e0 & 0xffffu, len1 = ea.e1 & 0xffffu;
+            const bool long0 = len0 >= ZH_LEAVE_ALONE, long1 = len1 >= ZH_LEAVE_ALONE;
+            const bool short0 = len0 >= ZH_MIN_MATCH && !long0 && ea.mlen0 >= ZH_MIN_MATCH, short1 = len1 >= ZH_MIN_MATCH && !long1 && ea.mlen1 >= ZH_MIN_MATCH;
+            const uint32_t pk0 = pq[(short0 ? ea.mlen0 - ZH_MIN_MATCH : 0u) * ZH_LP_C];
+            const uint32_t pk1 = pq[(short1 ? ea.mlen1 - ZH_MIN_MATCH : 0u) * ZH_LP_C];
+            const uint32_t lk0 = long0 ? ((ea.lc0 + ea.rg0 + ea.dp0) << 9) | (q << 6) : ZH_LP_NOKEY;
+            const uint32_t lk1 = long1 ? ((ea.lc1 + ea.rg1 + ea.dp1) << 9) | ((4u + q) << 6) : ZH_LP_NOKEY;
+            nb.key0 = short0 ? pk0 + ((ea.dp0 << 9) | (q << 6)) : lk0;
+            nb.key1 = short1 ? pk1 + ((ea.dp1 << 9) | ((4u + q) << 6)) : lk1;
+            nb.e0 = ea.e0;
+            nb.e1 = ea.e1;
+            nb.mlen0 = ea.mlen0;
+            nb.mlen1 = ea.mlen1;
+            nb.lit = ea.lit;
+            nb.j = ea.j;
+            nb.act = ea.act;
+            nb.fresh = ea.fresh;
+         }
+
+         // ======== stage A, second half: the slots' distance prices, the literal's price; for a slot stored with length >= 40 the
+         //          price of its clamped length and the cost behind it ========================================================================
+         {
+            if (!na.act) na.e0 = na.e1 = 0;
+            const uint32_t len0 = na.e0 & 0xffffu, len1 = na.e1 & 0xffffu;
+            na.mlen0 = min(len0, aroom);
+            na.mlen1 = min(len1, aroom);
+            na.dp0 = ws.distprice[len0 >= ZH_MIN_MATCH ? zh_lp_dist_index((na.e0 >> 16) - 1u) : 0u];   // rows are zero padded: an empty slot ends the row
+            na.dp1 = ws.distprice[len1 >= ZH_MIN_MATCH ? zh_lp_dist_index((na.e1 >> 16) - 1u) : 0u];
+            na.lit = ws.litprice[abyte & 0xffu];
+            const bool long0 = len0 >= ZH_LEAVE_ALONE, long1 = len1 >= ZH_LEAVE_ALONE;
+            na.lc0 = na.lc1 = na.rg0 = na.rg1 = 0;
+            if (zh_ballot(long0)) {
+               // (rows are longest first: a long slot 4..7 sits behind four long slots 0..3)
+               uint32_t enc0 = na.mlen0 - ZH_MIN_MATCH, enc1 = na.mlen1 - ZH_MIN_MATCH;   // wraps below 3, then saturates (:289, :216-219)
+               if (enc0 > 255u) enc0 = 255u;
+               if (enc1 > 255u) enc1 = 255u;
+               // (a length clamped to 1 or 2 ends at the sub-block's end, where the cost is 0: nothing is read for it — the costs of
+               // the two positions before this one are not in the ring yet)
+               uint32_t s0 = slot + (long0 && na.mlen0 >= 3u ? na.mlen0 : 3u), s1 = slot + (long1 && na.mlen1 >= 3u ? na.mlen1 : 3u);
+               s0 -= s0 >= ZH_LP_RING ? ZH_LP_RING : 0u;
+               s1 -= s1 >= ZH_LP_RING ? ZH_LP_RING : 0u;
+               na.lc0 = ws.lencost[long0 ? enc0 : 0u];
+               na.lc1 = ws.lencost[long1 ? enc1 : 0u];
+               const uint32_t r0 = rq[s0 * ZH_LP_C], r1 = rq[s1 * ZH_LP_C];
+               na.rg0 = na.mlen0 >= 3u ? r0 : 0u;
+               na.rg1 = na.mlen1 >= 3u ? r1 : 0u;
+            }
+         }
+         eb = nb;
+         ea = na;
+         slot = slot ? slot - 1u : ZH_LP_RING - 1u;
+      }
+   }
+#undef ZH_LP_FETCH
+#undef ZH_LP_FETCH_HI
+#ifdef ZH_LP_PROFILE
+   ZH_LP_COUNT(0, prof_steps);
+   ZH_LP_COUNT(1, prof_quads);
+   ZH_LP_COUNT(7, prof_hi);
+#endif
+   ZH_LP_COUNT(2, ZH_LP_CLOCK() - tic1);
+   const uint64_t tic2 = ZH_LP_CLOCK();
+
+   // ---- histogram of the group's parse; the per-sub-block sum is taken by zh_sb_build ------------------------------------
+   if (st->is_dynamic) {
+      __threadfence_block();
+      zh_sync();
+      for (uint32_t k = lane; k < ZH_NSYM; k += 64) ws.hist[k] = 0;
+      zh_sync();
+      for (uint32_t idx = lane; idx < npieces; idx += 64) {
+         const uint32_t at = idx < nlongp ? idx : ZH_LP_MAXP - nshortp + (idx - nlongp);
+         uint32_t x = ws.plo[at];
+         const uint32_t hi = ws.phi[at];
+         while (x < hi) {
+            const uint32_t bm = best[x - prev];
+            const uint32_t byte = win[x];
+            const uint32_t len = bm & 0xffffu;
+            if (len >= ZH_MIN_MATCH) {
+               atomicAdd(&ws.hist[257 + zh_len_idx(len)], 1u);
+               atomicAdd(&ws.hist[ZH_NLIT + zh_dist_sym(bm >> 16)], 1u);
+               x += len;
+            }
+            else {
+               atomicAdd(&ws.hist[byte], 1u);
+               x++;
+            }
+         }
+      }
+      zh_sync();
+      bool first = true;
+      for (uint32_t gt = g0; gt < g1; gt++) {
+         if (!((parsed >> (gt - g0)) & 1ull)) continue;
+         uint32_t *hp = hist_part + (uint64_t)gt * ZH_NSYM;
+         for (uint32_t k = lane; k < ZH_NSYM; k += 64) hp[k] = first ? ws.hist[k] : 0u;
+         first = false;
+      }
+   }
+   ZH_LP_COUNT(5, ZH_LP_CLOCK() - tic2);
+}
+
+// ticket == NULL: one workgroup (= one wave) per ZH_LP_TASKS tasks, the grid covers the task list. Otherwise the workgroups are
+// persistent and take task groups from *ticket (see zh_parse_tasks: next to zh_parse_chain the host launches a bounded grid).
+__global__ void __launch_bounds__(64)
+zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
+               const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
+               const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass,
+               uint32_t *ticket) {
+   __shared__ zh_lp_ws_t ws;
+   const uint32_t ntasks = cnt[ZH_CNT_TASKS];
+   for (;;) {
+      uint32_t w = blockIdx.x;
+      if (ticket) {
+         if (zh_lane() == 0) w = atomicAdd(ticket, 1u);
+         w = zh_readfirstlane(w);
+      }
+      const uint32_t g0 = w * ZH_LP_TASKS;
+      if (g0 >= ntasks) return;
+      const uint32_t g1 = min(ntasks, g0 + ZH_LP_TASKS);
+      // the wave's tasks, sub-block by sub-block
+      for (uint32_t g = g0; g < g1;) {
+         const uint32_t sb = taskmap[g].x;
+         uint32_t ge = g + 1;
+         while (ge < g1 && taskmap[ge].x == sb) ge++;
+         zh_lp_group(ws, g, ge, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass);
+         g = ge;
+      }
+      if (!ticket) return;
+   }
+}

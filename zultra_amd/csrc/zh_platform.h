@@ -79,6 +79,15 @@ __device__ __forceinline__ uint32_t zh_row_sum(uint32_t v) {
    v += zh_dpp<ZH_DPP_ROW_MIRROR>(v);
    return v;
 }
+// quads (four neighbouring lanes, DPP quad_perm): minimum over the quad in every lane; lane q <- lane q-1 (lane 0 keeps its own);
+// lanes 2, 3 <- lanes 0, 1 (lanes 0, 1 keep their own)
+__device__ __forceinline__ uint32_t zh_quad_min(uint32_t v) {
+   v = zh_dpp_min<ZH_DPP_QUAD_XOR1>(v);
+   v = zh_dpp_min<ZH_DPP_QUAD_XOR2>(v);
+   return v;
+}
+__device__ __forceinline__ uint32_t zh_quad_shr1(uint32_t v) { return zh_dpp<0x90>(v); }   // quad_perm:[0,0,1,2]
+__device__ __forceinline__ uint32_t zh_quad_lo2(uint32_t v) { return zh_dpp<0x44>(v); }    // quad_perm:[0,1,0,1]
 // whole-wave reductions: row step on the VALU, the 4 row results combined on the scalar unit
 __device__ __forceinline__ uint32_t zh_wave_min(uint32_t v) {
    v = zh_row_min(v);
@@ -170,6 +179,14 @@ __device__ __forceinline__ void zh_wave_sync() {
    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
    __builtin_amdgcn_wave_barrier();
    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Between an LDS store by one lane and a load of it by another lane of the SAME wave: the hardware runs a wave's LDS operations in
+// order, so all it takes is that the compiler keeps them in order too. Unlike zh_wave_sync no counter is drained: global loads
+// and LDS reads issued earlier stay in flight.
+__device__ __forceinline__ void zh_lockstep_sync() {
+   __builtin_amdgcn_wave_barrier();
+   asm volatile("" ::: "memory");
 }
 
 __device__ __forceinline__ uint32_t zh_atomic_add_lds(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
