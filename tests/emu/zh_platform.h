@@ -301,6 +301,7 @@ inline uint32_t atomicOr(uint32_t *p, uint32_t v) {
 inline uint64_t zh_clock() { return 0; }
 inline uint64_t zh_wall_clock() { return 0; }
 inline uint32_t zh_load_agent_u32(const uint32_t *p) { return *p; }
+inline uint32_t zh_load_agent_u16(const uint16_t *p) { return *p; }
 inline void zh_set_wave_priority_high() {}
 inline void zh_set_wave_priority_mid() {}
 inline void zh_set_wave_priority_normal() {}

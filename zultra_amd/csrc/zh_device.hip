@@ -74,6 +74,7 @@ struct zultra_hip_ctx_s {
    uint32_t *d_chunkmax, *d_spanstart, *d_spancnt;   // per chunk of ZH_TOK_CHUNK positions (zh_split.h: barriers and token chain)
    uint32_t chunks_per_block;
    uint32_t *d_best;
+   uint16_t *d_cost;            // zh_parse_lanes: cost of every position from its piece's end (best_stride per max-block)
    zh_work_t *d_work;
    zh_subblock_t *d_results;
    uint8_t *d_payload;
@@ -345,6 +346,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_split_cnt);
    (void)hipFree(c->d_sub_base);
    (void)hipFree(c->d_best);
+   (void)hipFree(c->d_cost);
    (void)hipFree(c->d_work);
    (void)hipFree(c->d_results);
    (void)hipFree(c->d_payload);
@@ -518,7 +520,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
        zh_alloc(c, &c->d_tok_pos, B * c->tok_stride) || zh_alloc(c, &c->d_tok_info, B * c->tok_stride) ||
        zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_chunkmax, B * c->chunks_per_block) || zh_alloc(c, &c->d_spanstart, B * c->chunks_per_block) ||
        zh_alloc(c, &c->d_spancnt, B * c->chunks_per_block) || zh_alloc(c, &c->d_split_tok, B * (ZH_MAX_SPLITS + 1)) || zh_alloc(c, &c->d_split_cnt, B) ||
-       zh_alloc(c, &c->d_sub_base, B) || zh_alloc(c, &c->d_best, B * c->best_stride) || zh_alloc(c, &c->d_work, B * c->max_subs) ||
+       zh_alloc(c, &c->d_sub_base, B) || zh_alloc(c, &c->d_best, B * c->best_stride) || zh_alloc(c, &c->d_cost, B * c->best_stride) || zh_alloc(c, &c->d_work, B * c->max_subs) ||
        zh_alloc(c, &c->d_results, B * c->max_subs) || zh_alloc(c, &c->d_payload, B * c->slot_stride) ||
        zh_alloc(c, &c->d_items, B * c->max_subs) || zh_alloc(c, &c->d_crc, B) || zh_alloc(c, &c->d_adler, 2 * B) || zh_alloc(c, &c->d_crc_tables, 256 + 1024))
       return -1;
@@ -631,7 +633,7 @@ extern "C" size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max
    uint64_t bytes = 0;
    bytes += W + (B - 1) * N + 64;                                    // d_data
    bytes += B * S * sort_stride * (4 + 4 + 8) + B * S * run_stride * 4;   // sort ping-pong, prev records, run tables
-   bytes += B * N * ZH_NMATCH * sizeof(zh_match_t) + B * tok_stride * (4 + 4 + 2 + 4);   // rows, longest, token chain, parse
+   bytes += B * N * ZH_NMATCH * sizeof(zh_match_t) + B * tok_stride * (4 + 4 + 2 + 4 + 2);   // rows, longest, token chain, parse, costs
    bytes += B * (tok_stride / 64) * 8;                               // barrier bitmap
    bytes += B * slot_stride;                                         // payload slots
    bytes += (B * (N + 5 * (N / 65535 + 1) + 8) + 80);                // stitched stream
@@ -764,7 +766,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
       if (c->parse_lanes)
          ZH_LAUNCH(zh_parse_lanes, (task_grid + ZH_LP_TASKS - 1) / ZH_LP_TASKS, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
+                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL);
       else
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
                 (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
@@ -1086,11 +1088,11 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
             const uint32_t lane_grid = (task_grid + ZH_LP_TASKS - 1) / ZH_LP_TASKS;
             if (nchains || seg_wide || c->always_persistent)
                ZH_LAUNCH(zh_parse_lanes, min(lane_grid, c->num_cus * c->lane_waves), 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
+                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass,
                          ntasks + ZH_CNT_TASK_TICKET + pass);
             else
                ZH_LAUNCH(zh_parse_lanes, lane_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
+                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL);
          }
          else if (nchains || seg_wide || c->always_persistent)
             ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,

@@ -6,16 +6,19 @@
 // position and pass, the vector unit saturated). What a position needs is much less once the work is ordered differently.
 //
 // One step for the position p of a piece (a barrier-to-barrier run, zh_parse.h), by the four lanes q = 0..3 of its quad:
-//   * costs live in an LDS ring [slot][piece] of uint16: cost[p + k] sits k slots behind the slot written this step, the same
-//     slot for every piece of the wave (all pieces step together), so the reads are at immediate offsets from a per-lane base.
-//     A piece is at most ZH_COOP_MIN positions and a position costs at most 15 bits: absolute costs from the piece's end fit 16 bits.
+//   * the costs a step looks at — cost[p + 3 .. p + 39] — live in REGISTERS: lane q keeps cost[p + 3 + 9 q .. p + 12 + 9 q] (<< 9, ready
+//     to take a price), and moving to p - 1 shifts the window by one: the new element of lane q is the one that leaves lane q - 1
+//     (one DPP move), lane 0's is the cost decided three steps earlier. No LDS ring: costs farther than 39 positions ahead are
+//     only ever needed by slots stored with length >= 40, and those read them back from a uint16 array in global memory that
+//     every step appends to (fetched with the rows, two batches ahead). A piece is at most ZH_COOP_MIN positions and a position
+//     costs at most 15 bits: absolute costs from the piece's end fit 16 bits.
 //   * prefix minima over the lengths: G(k) = cost[p+k] + price of length k, P(L) = min over k <= L of (G(k), larger k first),
-//     L = 3..39 — none of it depends on the position's matches. Lane q scans the ten lengths 3+10q .. 12+10q, the lanes' totals are
+//     L = 3..39 — none of it depends on the position's matches. Lane q scans the ten lengths 3+9q .. 12+9q, the lanes' totals are
 //     combined with two DPP steps, P goes to an LDS scratch [L][piece].
 //   * the reference tries every pair (slot m, k <= len_m) in the order m ascending, k descending, and takes strict improvements
 //     only: the winner is the minimum of (cost, m, -k). For slot m all of its k's at once: P(min(len_m, room)) + distance price.
 //     So each slot costs one gather from the scratch and one add (lane q takes slots q and 4+q); slots stored with length >= 40
-//     are tried at their clamped length only (blockdeflate.c:286-297): one gather from the ring.
+//     are tried at their clamped length only (blockdeflate.c:286-297): one cost from the array in global memory.
 //   * a quad minimum picks the position's best match; literal first, a match must be strictly cheaper (:292,:307).
 // Keys: cost << 9 | slot << 6 | (39 - k), as in zh_parse.h.
 // (A lane per piece — 64 recurrences per wave — needs 4 x the LDS per wave, leaves one wave per SIMD and, measured, 10 to 20 of
@@ -39,14 +42,16 @@
 #define ZH_LP_TASKS 8u             // tasks per wave
 #endif
 #define ZH_LP_C 16u                // pieces in flight per wave (one per quad)
-#define ZH_LP_RING 258u            // a step reads cost[p+1 .. p+258] and then writes cost[p]
-#define ZH_LP_KPL 10u              // lengths per lane: lane q scans 3 + 10 q .. 12 + 10 q (40 .. 42 do not exist)
-#define ZH_LP_NL (4u * ZH_LP_KPL)  // rows of the prefix scratch
-#define ZH_LP_MIRROR (3u + ZH_LP_NL)   // the first rows of the ring are kept twice: slot + 3 .. slot + 42 never wraps
+#define ZH_LP_KPL 10u              // lengths per lane: lane q scans 3 + 9 q .. 12 + 9 q (neighbours share one: a stride of 9 ring rows
+                                   // puts the four lanes of a quad on different LDS banks, a stride of 10 puts lanes 0 and 2 on the same)
+#define ZH_LP_QSTRIDE 9u
+#define ZH_LP_NL 37u               // rows of the prefix scratch: lengths 3 .. 39 (ZH_LEAVE_ALONE - 1)
 #define ZH_LP_MAXP (ZH_LP_TASKS * 32u) // pieces per group: a task without a run of more than ZH_COOP_MIN positions has fewer than 32
 #define ZH_LP_LONG 192u            // pieces of at least this many positions are handed out first
 #define ZH_LP_NOKEY 0xFFFFFFFFu
-#define ZH_LP_NOPRICE 0x80000000u  // "price" of a length that does not exist: above every real key, and no overflow when a cost is added
+// The prefix scratch [row][column]: row L - 3, and piece i in column i ^ 8 for the rows of lanes 2 and 3 — the four lanes of a quad
+// write rows 9 q + k, whose LDS banks (16 per row) would coincide for lanes 0 / 2 and for lanes 1 / 3
+#define ZH_LP_PCOL(row_, piece_) ((piece_) ^ ((row_) >= 2u * ZH_LP_QSTRIDE ? 8u : 0u))
 
 #ifdef ZH_LP_PROFILE
 // probe builds only (tools/lp_profile.py): 0 steps, 1 quad-steps with a position, 2 cycles of the step loops, 3 groups, 4 cycles of the
@@ -60,13 +65,18 @@ __device__ unsigned long long zh_lp_prof[8];
 #endif
 
 struct alignas(16) zh_lp_ws_t {
-   uint16_t ring[ZH_LP_RING + ZH_LP_MIRROR][ZH_LP_C];   // [slot][piece]: cost of the piece, absolute from the piece's end
-   uint32_t pmin[ZH_LP_NL][ZH_LP_C];      // [L - 3][piece]: prefix minimum P(L) of this step
-   uint32_t stage0[ZH_LP_C][4][4];        // the batch: [piece][entry][slot 0..3] of the entries' rows,
-   uint32_t stage1[ZH_LP_C][4][4];        //            slots 4..7,
-   uint32_t stageb[ZH_LP_C][4];           //            the entries' bytes
-   uint32_t outp[ZH_LP_C][4];             // the batch's parse entries
-   uint32_t hist[ZH_NSYM];                // after the parse: histogram of the group
+   union {
+      struct {
+         uint32_t pmin[ZH_LP_NL][ZH_LP_C];      // [L - 3][piece, see ZH_LP_PCOL]: prefix minimum P(L) of this step
+         uint32_t stage0[ZH_LP_C][4][4];        // the batch: [piece][entry][slot 0..3] of the entries' rows,
+         uint32_t stage1[ZH_LP_C][4][4];        //            slots 4..7,
+         uint16_t stagef[ZH_LP_C][4][8];        //            per slot stored with length >= 40 the cost behind it,
+         uint32_t stageb[ZH_LP_C][4];           //            the entries' bytes
+         uint32_t outp[ZH_LP_C][4];             // the batch's parse entries ...
+         uint32_t outc[ZH_LP_C][4];             // ... and costs
+      };
+      uint32_t hist[ZH_NSYM];                   // after the parse: histogram of the group
+   };
    uint32_t plo[ZH_LP_MAXP], phi[ZH_LP_MAXP];   // the group's pieces: the long ones from the front, the others from the back
    uint32_t bnd[ZH_MAXPIECES + 1];
    uint8_t litprice[ZH_NLIT];             // code lengths with the 9-bit fill (blockdeflate.c:873-876)
@@ -83,7 +93,7 @@ __device__ __forceinline__ uint32_t zh_lp_index_dist(uint32_t idx) { return idx 
 // piece's last position (the recurrence starts there). A piece's first batch has at most three positions, in its LAST entries: the
 // step before a piece is always an empty one, which zeroes its ring slot — cost[piece end] — and nothing interrupts a piece.
 struct zh_lp_batch_t {
-   uint32_t p0, n, off;
+   uint32_t p0, n, off, end;   // end = the piece's end: the cost there is 0
    bool fresh;
 };
 
@@ -91,7 +101,7 @@ struct zh_lp_batch_t {
 __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_t g1, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
                                             const zh_match_t *__restrict__ match, uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride,
                                             const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
-                                            uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass) {
+                                            uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all, uint32_t *hist_part, int pass) {
    const uint2 tm0 = taskmap[g0];
    const zh_work_t wk = work[tm0.x];
    const zh_sbstate_t *st = states + tm0.x;
@@ -104,6 +114,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    const uint4 *rows_hi = rows + ZH_ROW_HI_OFF(match_stride);                        // ... and 4..7, present when slot 3 holds a match
    const uint64_t *bar = bars + (uint64_t)wk.block * bar_stride;
    uint32_t *best = best_all + (uint64_t)wk.block * best_stride;
+   uint16_t *costs = cost_all + (uint64_t)wk.block * best_stride;   // cost of every position from its piece's end, for the slots of length >= 40
    const uint32_t lane = zh_lane(), q = lane & 3u, piece = lane >> 2;
    const uint32_t sb_end = wk.start + wk.size;
    const uint64_t lt_mask = (1ull << lane) - 1ull, lt_quad = (1ull << (lane & ~3u)) - 1ull;
@@ -126,12 +137,12 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
       ws.lencost[e] = (uint8_t)(ws.litprice[257 + idx] + zh_lenidx_xbits(idx));
    }
    zh_sync();
-   // price << 9 | (39 - k) of the lane's ten lengths k = 3 + 10 q + j
+   // price << 9 | (39 - k) of the lane's ten lengths k = 3 + 9 q + j
    uint32_t kc[ZH_LP_KPL];
 #pragma unroll
    for (uint32_t j = 0; j < ZH_LP_KPL; j++) {
-      const uint32_t e = ZH_LP_KPL * q + j;   // k - 3
-      kc[j] = e < ZH_LEAVE_ALONE - ZH_MIN_MATCH ? (((uint32_t)ws.lencost[e] << 9) | (36u - e)) : ZH_LP_NOPRICE;
+      const uint32_t e = ZH_LP_QSTRIDE * q + j;   // k - 3 <= 36
+      kc[j] = ((uint32_t)ws.lencost[e] << 9) | (36u - e);
    }
 
    // ---- the group's pieces ---------------------------------------------------------------------------------------------
@@ -178,17 +189,22 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    // ---- the recurrences ----------------------------------------------------------------------------------------------------
    // The only thing a step needs from the step before it is cost[p + 1], for the literal: everything about the matches of p looks
    // at cost[p + 3] and beyond. So the steps are software-pipelined over three consecutive entries of the wave's stream — while
-   // entry i takes its decision (stage C), entry i+1 scans its prefix minima (stage B) and entry i+2 has its LDS reads in flight
-   // (stage A) — and no LDS round trip is waited for with nothing else to issue.
+   // entry i takes its decision (stage C), entry i+1 scans its prefix minima and has its gathers from the scratch in flight (stage
+   // B) and entry i+2 has its slots digested (stage A) — and no LDS round trip is waited for with nothing else to issue.
    uint32_t next = 0;              // wave-uniform: pieces handed out so far
-   uint32_t slot = ZH_LP_RING - 4u;   // wave-uniform: the ring slot of the entry in stage A; cost[p + k] is at slot + k (mod ring)
-   uint32_t sp = 0, sleft = 0;     // the quad's fetch cursor: the next position to request is sp - 1, sleft are left of its piece
+   uint32_t sp = 0, sleft = 0, send = 0;   // the quad's fetch cursor: the next position to request is sp - 1, sleft are left of its piece, which ends at send
    uint32_t c1 = 0;                // cost[p + 1] of the position deciding next: the literal's continuation
-   zh_lp_batch_t cur = {0, 0, 0, false}, old = {0, 0, 0, false}, b1 = {0, 0, 0, false}, b2 = {0, 0, 0, false};   // the batch entering stage A, the one before it, the next two
+   uint32_t cin1 = 0, cin2 = 0, cin3 = 0;   // cost << 9 decided one, two and three steps ago: the last one is what enters lane 0's window
+   zh_lp_batch_t cur = {0, 0, 0, 0, false}, old = {0, 0, 0, 0, false}, b1 = {0, 0, 0, 0, false}, b2 = {0, 0, 0, 0, false};   // the batch entering stage A, the one before it, the next two
    uint4 a1 = make_uint4(0, 0, 0, 0), a2 = make_uint4(0, 0, 0, 0), h1 = make_uint4(0, 0, 0, 0);   // this lane's entry of batch b1 / b2: first plane; of b1: second plane
    uint32_t y1 = 0, y2 = 0;        // ... and its byte
-   uint16_t *const rq = &ws.ring[0][piece];       // the quad's ring column
-   uint32_t *const pq = &ws.pmin[0][piece];       // ... and its column of the prefix scratch
+   uint32_t f1[4] = {0, 0, 0, 0};  // ... of b1: the costs behind its slots 0..3 where they are stored with length >= 40
+   // the cost window of the entry in stage B, << 9: lane q's ten costs are w[wb .. wb + 9], wb = 3, 2, 1, 0 over the four entries of a
+   // batch, then everything moves up by four
+   uint32_t w[14];
+#pragma unroll
+   for (uint32_t k = 0; k < 14; k++) w[k] = 0;
+   uint32_t *const pw = &ws.pmin[ZH_LP_QSTRIDE * q][ZH_LP_PCOL(ZH_LP_QSTRIDE * q, piece)];   // the rows of the prefix scratch this lane writes
 
    // the quad's next batch: a new piece when the current one is used up; requests its rows and bytes
 #define ZH_LP_FETCH(bt_, a_, y_)                                                                                    \
@@ -199,7 +215,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
          const uint32_t i_ = next + (uint32_t)zh_popc64(idle_ & lt_quad);                                          \
          if (sleft == 0 && i_ < npieces) {                                                                         \
             const uint32_t at_ = i_ < nlongp ? i_ : ZH_LP_MAXP - nshortp + (i_ - nlongp);                          \
-            sp = ws.phi[at_];                                                                                      \
+            sp = send = ws.phi[at_];                                                                               \
             sleft = sp - ws.plo[at_];                                                                              \
             fresh_ = true;                                                                                         \
          }                                                                                                         \
@@ -208,6 +224,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
       bt_.n = min(fresh_ ? 3u : 4u, sleft);                                                                        \
       bt_.off = fresh_ ? 4u - bt_.n : 0u;                                                                          \
       bt_.p0 = sp - 1u;                                                                                            \
+      bt_.end = send;                                                                                              \
       bt_.fresh = fresh_;                                                                                          \
       a_ = make_uint4(0, 0, 0, 0);                                                                                 \
       y_ = 0;                                                                                                      \
@@ -218,17 +235,32 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
       sp -= bt_.n;                                                                                                 \
       sleft -= bt_.n;                                                                                              \
    } while (0)
-   // second plane of this lane's entry of batch b1 (slots 4..7 exist only behind a full first plane, zh_common.h)
+   // the cost behind a slot stored with length >= 40 (len_ | offset << 16) of the position pos_ of a piece that ends at end_: 0 at
+   // the piece's end (and wherever the sub-block's end clamps the length: the last piece ends there), else what the step of that
+   // position left in global memory — at least 40 steps ago; read past this CU's vector cache, which may hold the line from before
+#define ZH_LP_FAR(e_, pos_, end_) ((((e_) & 0xffffu) >= ZH_LEAVE_ALONE && (pos_) + ((e_) & 0xffffu) < (end_)) ? zh_load_agent_u16(costs + ((pos_) + ((e_) & 0xffffu) - prev)) : 0u)
+   // second plane of this lane's entry of batch b1 (slots 4..7 exist only behind a full first plane, zh_common.h), and the far costs
+   // of its first plane
 #define ZH_LP_FETCH_HI()                                                                                           \
    do {                                                                                                            \
       h1 = make_uint4(0, 0, 0, 0);                                                                                 \
-      if (q - b1.off < b1.n && (a1.w & 0xffffu) >= ZH_MIN_MATCH) h1 = rows_hi[b1.p0 - (q - b1.off) - prev];        \
+      f1[0] = f1[1] = f1[2] = f1[3] = 0;                                                                           \
+      const bool on_ = q - b1.off < b1.n;                                                                          \
+      const uint32_t pos_ = b1.p0 - (q - b1.off);                                                                  \
+      if (on_ && (a1.w & 0xffffu) >= ZH_MIN_MATCH) h1 = rows_hi[pos_ - prev];                                      \
+      if (zh_ballot(on_ && (a1.x & 0xffffu) >= ZH_LEAVE_ALONE)) {   /* rows are longest first */                   \
+         if (on_) {                                                                                                \
+            f1[0] = ZH_LP_FAR(a1.x, pos_, b1.end);                                                                 \
+            f1[1] = ZH_LP_FAR(a1.y, pos_, b1.end);                                                                 \
+            f1[2] = ZH_LP_FAR(a1.z, pos_, b1.end);                                                                 \
+            f1[3] = ZH_LP_FAR(a1.w, pos_, b1.end);                                                                 \
+         }                                                                                                         \
+      }                                                                                                            \
    } while (0)
 
    // what an entry carries from stage A to stage B, and from stage B to stage C
    struct zh_lp_a_t {
       uint32_t e0, e1, mlen0, mlen1, dp0, dp1, lit, lc0, lc1, rg0, rg1, j;
-      uint32_t cv[ZH_LP_KPL];
       bool act, fresh;
    };
    struct zh_lp_b_t {
@@ -238,15 +270,11 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    zh_lp_a_t ea;
    zh_lp_b_t eb;
    ea.e0 = ea.e1 = ea.mlen0 = ea.mlen1 = ea.dp0 = ea.dp1 = ea.lit = ea.lc0 = ea.lc1 = ea.rg0 = ea.rg1 = ea.j = 0;
-#pragma unroll
-   for (uint32_t k = 0; k < ZH_LP_KPL; k++) ea.cv[k] = 0;
    ea.act = ea.fresh = false;
    eb.e0 = eb.e1 = eb.mlen0 = eb.mlen1 = eb.lit = eb.j = 0;
    eb.key0 = eb.key1 = ZH_LP_NOKEY;
    eb.act = eb.fresh = false;
 
-   // (every ring slot a first piece may take for its end holds a zero)
-   for (uint32_t k = lane; k < (ZH_LP_RING + ZH_LP_MIRROR) * ZH_LP_C / 2u; k += 64) ((uint32_t *)&ws.ring[0][0])[k] = 0;
    ZH_LP_FETCH(b1, a1, y1);
    ZH_LP_FETCH(b2, a2, y2);
    ZH_LP_FETCH_HI();
@@ -259,9 +287,21 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
          if (drain) break;
          drain = 1;   // one more round of empty entries lets the last real ones through stages B and C
       }
-      *(uint4 *)&ws.stage0[piece][q][0] = a1;
-      *(uint4 *)&ws.stage1[piece][q][0] = h1;
-      ws.stageb[piece][q] = y1;
+      {
+         // (five and more slots of length >= 40 at one position: their costs are fetched here, with nothing to hide the round trip)
+         uint32_t f5 = 0, f6 = 0, f7 = 0, f8 = 0;
+         if (zh_ballot((h1.x & 0xffffu) >= ZH_LEAVE_ALONE)) {
+            const uint32_t pos_ = cur.p0 - (q - cur.off);
+            f5 = ZH_LP_FAR(h1.x, pos_, cur.end);
+            f6 = ZH_LP_FAR(h1.y, pos_, cur.end);
+            f7 = ZH_LP_FAR(h1.z, pos_, cur.end);
+            f8 = ZH_LP_FAR(h1.w, pos_, cur.end);
+         }
+         *(uint4 *)&ws.stage0[piece][q][0] = a1;
+         *(uint4 *)&ws.stage1[piece][q][0] = h1;
+         *(uint4 *)&ws.stagef[piece][q][0] = make_uint4(f1[0] | (f1[1] << 16), f1[2] | (f1[3] << 16), f5 | (f6 << 16), f7 | (f8 << 16));
+         ws.stageb[piece][q] = y1;
+      }
       zh_lockstep_sync();
       b1 = b2;
       a1 = a2;
@@ -271,7 +311,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
 
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {
-         // ======== stage A, first half, of entry (cur, j): the reads that need nothing but the entry's place in the stream ========
+         // ======== stage A, first half, of entry (cur, j): its slots and its byte ==========================================================
          zh_lp_a_t na;
          na.act = j - cur.off < cur.n;
          na.fresh = cur.fresh && j == cur.off;
@@ -281,11 +321,6 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
          na.e0 = ws.stage0[piece][j][q];
          na.e1 = ws.stage1[piece][j][q];
          const uint32_t abyte = ws.stageb[piece][j];
-         {
-            const uint16_t *rk = rq + (slot + 3u + ZH_LP_KPL * q) * ZH_LP_C;
-#pragma unroll
-            for (uint32_t k = 0; k < ZH_LP_KPL; k++) na.cv[k] = rk[k * ZH_LP_C];
-         }
 #ifdef ZH_LP_PROFILE
          prof_steps++;
          prof_quads += (uint32_t)zh_popc64(zh_ballot(na.act && q == 0));
@@ -293,52 +328,61 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
 
          // ======== stage C of the entry two before: literal first; a match must be strictly cheaper (:292,:307) =====================
          {
-            const uint32_t cslot = slot + 2u >= ZH_LP_RING ? slot + 2u - ZH_LP_RING : slot + 2u;
             const uint32_t bestkey = zh_quad_min(min(eb.key0, eb.key1));
             if (eb.fresh) c1 = 0;
             const uint32_t litc = c1 + eb.lit;
             const uint32_t mc = bestkey >> 9;
             const bool take = mc < litc;
             const uint32_t c = eb.act ? (take ? mc : litc) : 0u;   // (an empty step leaves a zero: the end of the piece that may follow)
-            if (q == 0) {
-               rq[cslot * ZH_LP_C] = (uint16_t)c;
-               if (cslot < ZH_LP_MIRROR) rq[(cslot + ZH_LP_RING) * ZH_LP_C] = (uint16_t)c;
-               if (!take) ws.outp[piece][eb.j] = 0;
-            }
-            // the lane whose slot won writes the parse entry
-            if (take && eb.key0 == bestkey) ws.outp[piece][eb.j] = ((eb.e0 & 0xffffu) >= ZH_LEAVE_ALONE ? eb.mlen0 : 39u - (bestkey & 63u)) | (eb.e0 & 0xffff0000u);
-            if (take && eb.key1 == bestkey) ws.outp[piece][eb.j] = ((eb.e1 & 0xffffu) >= ZH_LEAVE_ALONE ? eb.mlen1 : 39u - (bestkey & 63u)) | (eb.e1 & 0xffff0000u);
+            // the lane whose slot won writes the parse entry, lane 0 a literal and the cost
+            const bool own0 = take && eb.key0 == bestkey, own1 = take && eb.key1 == bestkey;
+            const uint32_t we = own1 ? eb.e1 : eb.e0, wm = own1 ? eb.mlen1 : eb.mlen0;
+            const uint32_t pick = take ? ((we & 0xffffu) >= ZH_LEAVE_ALONE ? wm : 39u - (bestkey & 63u)) | (we & 0xffff0000u) : 0u;
+            if (own0 || own1 || (!take && q == 0)) ws.outp[piece][eb.j] = pick;
+            if (q == 0) ws.outc[piece][eb.j] = c;
             c1 = c;
+            cin3 = cin2;
+            cin2 = cin1;
+            cin1 = c << 9;
             zh_lockstep_sync();
-            if (j == 1 && q - old.off < old.n) best[old.p0 - (q - old.off) - prev] = ws.outp[piece][q];   // the batch before this one is through
+            if (j == 1 && q - old.off < old.n) {   // the batch before this one is through
+               best[old.p0 - (q - old.off) - prev] = ws.outp[piece][q];
+               costs[old.p0 - (q - old.off) - prev] = (uint16_t)ws.outc[piece][q];
+            }
          }
 
-         // ======== stage B of the entry before: prefix minima over the lengths, P(L) = min over 3 <= k <= L of
-         //          (cost[pos + k] + price(k)) << 9 | (39 - k): the lane's own ten, then the minimum of the lanes below it ==========
+         // ======== stage B of the entry before: its window, one position down; then the prefix minima over the lengths, P(L) = min over
+         //          3 <= k <= L of (cost[pos + k] + price(k)) << 9 | (39 - k): the lane's own ten, then the minimum of the lanes below it ====
          zh_lp_b_t nb;
          {
+            const uint32_t wb = 3u - j;
+            {
+               const uint32_t up = zh_quad_shr1(w[wb + 9u]);   // (the window before this step's was w[wb + 1 .. wb + 10])
+               w[wb] = q == 0 ? cin3 : up;   // cost[pos + 3]: decided three entries before this one
+            }
             uint32_t pl[ZH_LP_KPL];
             uint32_t P = ZH_LP_NOKEY;
 #pragma unroll
             for (uint32_t k = 0; k < ZH_LP_KPL; k++) {
-               P = min(P, (ea.cv[k] << 9) + kc[k]);
+               P = min(P, w[wb + k] + kc[k]);
                pl[k] = P;
             }
             uint32_t x = zh_quad_shr1(P);
             x = q == 0 ? ZH_LP_NOKEY : x;
             x = min(x, zh_quad_shr1(x));
             x = min(x, zh_quad_lo2(x));
-            uint32_t *pk = pq + (ZH_LP_KPL * q) * ZH_LP_C;
 #pragma unroll
-            for (uint32_t k = 0; k < ZH_LP_KPL; k++) pk[k * ZH_LP_C] = min(pl[k], x);
+            for (uint32_t k = 0; k < ZH_LP_KPL; k++)
+               if (k < ZH_LP_QSTRIDE || q == 3) pw[k * ZH_LP_C] = min(pl[k], x);   // (a lane's tenth length is its neighbour's first)
             zh_lockstep_sync();
             // a slot's best pair (slot, k <= its clamped length) is P(that length) + its distance price; a slot stored with length
             // >= 40 is tried at its full (clamped) length only (blockdeflate.c:286-297)
             const uint32_t len0 = ea.e0 & 0xffffu, len1 = ea.e1 & 0xffffu;
             const bool long0 = len0 >= ZH_LEAVE_ALONE, long1 = len1 >= ZH_LEAVE_ALONE;
             const bool short0 = len0 >= ZH_MIN_MATCH && !long0 && ea.mlen0 >= ZH_MIN_MATCH, short1 = len1 >= ZH_MIN_MATCH && !long1 && ea.mlen1 >= ZH_MIN_MATCH;
-            const uint32_t pk0 = pq[(short0 ? ea.mlen0 - ZH_MIN_MATCH : 0u) * ZH_LP_C];
-            const uint32_t pk1 = pq[(short1 ? ea.mlen1 - ZH_MIN_MATCH : 0u) * ZH_LP_C];
+            const uint32_t r0 = short0 ? ea.mlen0 - ZH_MIN_MATCH : 0u, r1 = short1 ? ea.mlen1 - ZH_MIN_MATCH : 0u;
+            const uint32_t pk0 = ws.pmin[r0][ZH_LP_PCOL(r0, piece)];
+            const uint32_t pk1 = ws.pmin[r1][ZH_LP_PCOL(r1, piece)];
             const uint32_t lk0 = long0 ? ((ea.lc0 + ea.rg0 + ea.dp0) << 9) | (q << 6) : ZH_LP_NOKEY;
             const uint32_t lk1 = long1 ? ((ea.lc1 + ea.rg1 + ea.dp1) << 9) | ((4u + q) << 6) : ZH_LP_NOKEY;
             nb.key0 = short0 ? pk0 + ((ea.dp0 << 9) | (q << 6)) : lk0;
@@ -363,32 +407,29 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
             na.dp0 = ws.distprice[len0 >= ZH_MIN_MATCH ? zh_lp_dist_index((na.e0 >> 16) - 1u) : 0u];   // rows are zero padded: an empty slot ends the row
             na.dp1 = ws.distprice[len1 >= ZH_MIN_MATCH ? zh_lp_dist_index((na.e1 >> 16) - 1u) : 0u];
             na.lit = ws.litprice[abyte & 0xffu];
-            const bool long0 = len0 >= ZH_LEAVE_ALONE, long1 = len1 >= ZH_LEAVE_ALONE;
+            const bool long0 = len0 >= ZH_LEAVE_ALONE;
             na.lc0 = na.lc1 = na.rg0 = na.rg1 = 0;
             if (zh_ballot(long0)) {
                // (rows are longest first: a long slot 4..7 sits behind four long slots 0..3)
                uint32_t enc0 = na.mlen0 - ZH_MIN_MATCH, enc1 = na.mlen1 - ZH_MIN_MATCH;   // wraps below 3, then saturates (:289, :216-219)
                if (enc0 > 255u) enc0 = 255u;
                if (enc1 > 255u) enc1 = 255u;
-               // (a length clamped to 1 or 2 ends at the sub-block's end, where the cost is 0: nothing is read for it — the costs of
-               // the two positions before this one are not in the ring yet)
-               uint32_t s0 = slot + (long0 && na.mlen0 >= 3u ? na.mlen0 : 3u), s1 = slot + (long1 && na.mlen1 >= 3u ? na.mlen1 : 3u);
-               s0 -= s0 >= ZH_LP_RING ? ZH_LP_RING : 0u;
-               s1 -= s1 >= ZH_LP_RING ? ZH_LP_RING : 0u;
-               na.lc0 = ws.lencost[long0 ? enc0 : 0u];
-               na.lc1 = ws.lencost[long1 ? enc1 : 0u];
-               const uint32_t r0 = rq[s0 * ZH_LP_C], r1 = rq[s1 * ZH_LP_C];
-               na.rg0 = na.mlen0 >= 3u ? r0 : 0u;
-               na.rg1 = na.mlen1 >= 3u ? r1 : 0u;
+               na.lc0 = ws.lencost[enc0];
+               na.lc1 = ws.lencost[enc1];
+               na.rg0 = ws.stagef[piece][j][q];
+               na.rg1 = ws.stagef[piece][j][4u + q];
             }
          }
          eb = nb;
          ea = na;
-         slot = slot ? slot - 1u : ZH_LP_RING - 1u;
       }
+      // the window moves up by four: the next batch's four entries find it at w[4 .. 13] again
+#pragma unroll
+      for (uint32_t k = 13; k >= 4; k--) w[k] = w[k - 4];
    }
 #undef ZH_LP_FETCH
 #undef ZH_LP_FETCH_HI
+#undef ZH_LP_FAR
 #ifdef ZH_LP_PROFILE
    ZH_LP_COUNT(0, prof_steps);
    ZH_LP_COUNT(1, prof_quads);
@@ -439,8 +480,8 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
 __global__ void __launch_bounds__(64)
 zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
-               const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass,
-               uint32_t *ticket) {
+               const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all,
+               uint32_t *hist_part, int pass, uint32_t *ticket) {
    __shared__ zh_lp_ws_t ws;
    const uint32_t ntasks = cnt[ZH_CNT_TASKS];
    for (;;) {
@@ -457,7 +498,7 @@ zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          const uint32_t sb = taskmap[g].x;
          uint32_t ge = g + 1;
          while (ge < g1 && taskmap[ge].x == sb) ge++;
-         zh_lp_group(ws, g, ge, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass);
+         zh_lp_group(ws, g, ge, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, cost_all, hist_part, pass);
          g = ge;
       }
       if (!ticket) return;

@@ -146,6 +146,8 @@ __device__ __forceinline__ uint64_t zh_wall_clock() { return (uint64_t)wall_cloc
 // a global word written earlier in this kernel (by this or another workgroup, after its fence): read past the CU's vector cache
 __device__ __forceinline__ uint32_t zh_load_agent_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+__device__ __forceinline__ uint32_t zh_load_agent_u16(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // LDS visibility between the lanes of a workgroup (a single wave for the 64-thread kernels)
 __device__ __forceinline__ void zh_sync() { __syncthreads(); }
 // Workgroup barrier that orders LDS traffic only. __syncthreads() also drains the wave's outstanding GLOBAL loads
