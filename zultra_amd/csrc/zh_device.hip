@@ -444,7 +444,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       const char *pl = getenv("ZULTRA_HIP_PARSE_LANES");
       c->parse_lanes = pl ? atoi(pl) : 1;
       const char *lw = getenv("ZULTRA_HIP_LANE_WAVES");
-      c->lane_waves = lw ? (uint32_t)max(1, min(16, atoi(lw))) : 8u;
+      c->lane_waves = lw ? (uint32_t)max(1, min(16, atoi(lw))) : 12u;
       const char *mfp = getenv("ZULTRA_HIP_MF_CUS");   // share of the CUs the matchfinder's persistent workgroups take, in percent (tuning experiments)
       c->mf_cu_pct = mfp ? (uint32_t)max(1, min(100, atoi(mfp))) : 100u;
       const char *sg = getenv("ZULTRA_HIP_STAGGER");   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group, 3 zh_mf_frontier (default), 4 the splitter

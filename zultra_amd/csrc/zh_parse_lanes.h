@@ -198,7 +198,8 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    zh_lp_batch_t cur = {0, 0, 0, 0, false}, old = {0, 0, 0, 0, false}, b1 = {0, 0, 0, 0, false}, b2 = {0, 0, 0, 0, false};   // the batch entering stage A, the one before it, the next two
    uint4 a1 = make_uint4(0, 0, 0, 0), a2 = make_uint4(0, 0, 0, 0), h1 = make_uint4(0, 0, 0, 0);   // this lane's entry of batch b1 / b2: first plane; of b1: second plane
    uint32_t y1 = 0, y2 = 0;        // ... and its byte
-   uint32_t f1[4] = {0, 0, 0, 0};  // ... of b1: the costs behind its slots 0..3 where they are stored with length >= 40
+   uint32_t f1[4] = {0, 0, 0, 0};  // ... of b1: the words that hold the costs behind its slots 0..3 where they are stored with length >= 40
+   bool b1far = false;             // wave-uniform: batch b1 has such slots
    // the cost window of the entry in stage B, << 9: lane q's ten costs are w[wb .. wb + 9], wb = 3, 2, 1, 0 over the four entries of a
    // batch, then everything moves up by four
    uint32_t w[14];
@@ -235,26 +236,28 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
       sp -= bt_.n;                                                                                                 \
       sleft -= bt_.n;                                                                                              \
    } while (0)
-   // the cost behind a slot stored with length >= 40 (len_ | offset << 16) of the position pos_ of a piece that ends at end_: 0 at
+   // The cost behind a slot stored with length >= 40 (e_ = length | offset << 16) of the position pos_ of a piece that ends at end_: 0 at
    // the piece's end (and wherever the sub-block's end clamps the length: the last piece ends there), else what the step of that
-   // position left in global memory — at least 40 steps ago; read past this CU's vector cache, which may hold the line from before
-#define ZH_LP_FAR(e_, pos_, end_) ((((e_) & 0xffffu) >= ZH_LEAVE_ALONE && (pos_) + ((e_) & 0xffffu) < (end_)) ? zh_load_agent_u16(costs + ((pos_) + ((e_) & 0xffffu) - prev)) : 0u)
+   // position left in global memory — at least 40 steps ago; read past this CU's vector cache, which may hold the line from before.
+   // The load is of the aligned word (nothing has to look at its result before it is used, a batch later), ZH_LP_FAR_PICK takes the half.
+#define ZH_LP_FAR_ON(e_, pos_, end_) (((e_) & 0xffffu) >= ZH_LEAVE_ALONE && (pos_) + ((e_) & 0xffffu) < (end_))
+#define ZH_LP_FAR_AT(e_, pos_, end_) (ZH_LP_FAR_ON(e_, pos_, end_) ? (pos_) + ((e_) & 0xffffu) - prev : (pos_) - prev)
+#define ZH_LP_FAR_PICK(word_, e_, pos_, end_) (ZH_LP_FAR_ON(e_, pos_, end_) ? ((word_) >> (16u * (((pos_) + ((e_) & 0xffffu) - prev) & 1u))) & 0xffffu : 0u)
+   const uint32_t *const costs32 = (const uint32_t *)costs;
    // second plane of this lane's entry of batch b1 (slots 4..7 exist only behind a full first plane, zh_common.h), and the far costs
    // of its first plane
 #define ZH_LP_FETCH_HI()                                                                                           \
    do {                                                                                                            \
       h1 = make_uint4(0, 0, 0, 0);                                                                                 \
-      f1[0] = f1[1] = f1[2] = f1[3] = 0;                                                                           \
       const bool on_ = q - b1.off < b1.n;                                                                          \
-      const uint32_t pos_ = b1.p0 - (q - b1.off);                                                                  \
+      const uint32_t pos_ = on_ ? b1.p0 - (q - b1.off) : wk.start;                                                 \
       if (on_ && (a1.w & 0xffffu) >= ZH_MIN_MATCH) h1 = rows_hi[pos_ - prev];                                      \
-      if (zh_ballot(on_ && (a1.x & 0xffffu) >= ZH_LEAVE_ALONE)) {   /* rows are longest first */                   \
-         if (on_) {                                                                                                \
-            f1[0] = ZH_LP_FAR(a1.x, pos_, b1.end);                                                                 \
-            f1[1] = ZH_LP_FAR(a1.y, pos_, b1.end);                                                                 \
-            f1[2] = ZH_LP_FAR(a1.z, pos_, b1.end);                                                                 \
-            f1[3] = ZH_LP_FAR(a1.w, pos_, b1.end);                                                                 \
-         }                                                                                                         \
+      b1far = zh_ballot(on_ && (a1.x & 0xffffu) >= ZH_LEAVE_ALONE) != 0;   /* rows are longest first */             \
+      if (b1far) {                                                                                                 \
+         f1[0] = zh_load_agent_u32(costs32 + (ZH_LP_FAR_AT(a1.x, pos_, b1.end) >> 1));                             \
+         f1[1] = zh_load_agent_u32(costs32 + (ZH_LP_FAR_AT(a1.y, pos_, b1.end) >> 1));                             \
+         f1[2] = zh_load_agent_u32(costs32 + (ZH_LP_FAR_AT(a1.z, pos_, b1.end) >> 1));                             \
+         f1[3] = zh_load_agent_u32(costs32 + (ZH_LP_FAR_AT(a1.w, pos_, b1.end) >> 1));                             \
       }                                                                                                            \
    } while (0)
 
@@ -279,6 +282,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    ZH_LP_FETCH(b2, a2, y2);
    ZH_LP_FETCH_HI();
    uint32_t drain = 0;   // the pipeline runs two entries behind the stream
+   bool cur_hi = false, old_hi = false;   // wave-uniform: some entry of the batch cur / old has a second plane
    for (;;) {
       // ---- batch b1 enters stage A: into LDS, where every lane of the quad finds its slot of every entry ---------------------------
       old = cur;
@@ -288,18 +292,24 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
          drain = 1;   // one more round of empty entries lets the last real ones through stages B and C
       }
       {
-         // (five and more slots of length >= 40 at one position: their costs are fetched here, with nothing to hide the round trip)
-         uint32_t f5 = 0, f6 = 0, f7 = 0, f8 = 0;
-         if (zh_ballot((h1.x & 0xffffu) >= ZH_LEAVE_ALONE)) {
-            const uint32_t pos_ = cur.p0 - (q - cur.off);
-            f5 = ZH_LP_FAR(h1.x, pos_, cur.end);
-            f6 = ZH_LP_FAR(h1.y, pos_, cur.end);
-            f7 = ZH_LP_FAR(h1.z, pos_, cur.end);
-            f8 = ZH_LP_FAR(h1.w, pos_, cur.end);
+         const uint32_t pos_ = q - cur.off < cur.n ? cur.p0 - (q - cur.off) : wk.start;
+         uint4 fv = make_uint4(0, 0, 0, 0);
+         if (b1far) {
+            fv.x = ZH_LP_FAR_PICK(f1[0], a1.x, pos_, cur.end) | (ZH_LP_FAR_PICK(f1[1], a1.y, pos_, cur.end) << 16);
+            fv.y = ZH_LP_FAR_PICK(f1[2], a1.z, pos_, cur.end) | (ZH_LP_FAR_PICK(f1[3], a1.w, pos_, cur.end) << 16);
+            // (five and more slots of length >= 40 at one position: their costs are fetched here, with nothing to hide the round trip)
+            if (zh_ballot((h1.x & 0xffffu) >= ZH_LEAVE_ALONE)) {
+               const uint32_t g0 = zh_load_agent_u32(costs32 + (ZH_LP_FAR_AT(h1.x, pos_, cur.end) >> 1)), g1 = zh_load_agent_u32(costs32 + (ZH_LP_FAR_AT(h1.y, pos_, cur.end) >> 1));
+               const uint32_t g2 = zh_load_agent_u32(costs32 + (ZH_LP_FAR_AT(h1.z, pos_, cur.end) >> 1)), g3 = zh_load_agent_u32(costs32 + (ZH_LP_FAR_AT(h1.w, pos_, cur.end) >> 1));
+               fv.z = ZH_LP_FAR_PICK(g0, h1.x, pos_, cur.end) | (ZH_LP_FAR_PICK(g1, h1.y, pos_, cur.end) << 16);
+               fv.w = ZH_LP_FAR_PICK(g2, h1.z, pos_, cur.end) | (ZH_LP_FAR_PICK(g3, h1.w, pos_, cur.end) << 16);
+            }
+            *(uint4 *)&ws.stagef[piece][q][0] = fv;
          }
+         old_hi = cur_hi;
+         cur_hi = zh_ballot((h1.x & 0xffffu) >= ZH_MIN_MATCH) != 0;
          *(uint4 *)&ws.stage0[piece][q][0] = a1;
-         *(uint4 *)&ws.stage1[piece][q][0] = h1;
-         *(uint4 *)&ws.stagef[piece][q][0] = make_uint4(f1[0] | (f1[1] << 16), f1[2] | (f1[3] << 16), f5 | (f6 << 16), f7 | (f8 << 16));
+         if (cur_hi) *(uint4 *)&ws.stage1[piece][q][0] = h1;
          ws.stageb[piece][q] = y1;
       }
       zh_lockstep_sync();
@@ -319,7 +329,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
          const uint32_t apos = na.act ? cur.p0 - (j - cur.off) : wk.start;
          const uint32_t aroom = sb_end - apos;   // end clamp (blockdeflate.c:283-284); a no-op away from the sub-block end
          na.e0 = ws.stage0[piece][j][q];
-         na.e1 = ws.stage1[piece][j][q];
+         na.e1 = cur_hi ? ws.stage1[piece][j][q] : 0u;
          const uint32_t abyte = ws.stageb[piece][j];
 #ifdef ZH_LP_PROFILE
          prof_steps++;
@@ -338,8 +348,10 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
             const bool own0 = take && eb.key0 == bestkey, own1 = take && eb.key1 == bestkey;
             const uint32_t we = own1 ? eb.e1 : eb.e0, wm = own1 ? eb.mlen1 : eb.mlen0;
             const uint32_t pick = take ? ((we & 0xffffu) >= ZH_LEAVE_ALONE ? wm : 39u - (bestkey & 63u)) | (we & 0xffff0000u) : 0u;
-            if (own0 || own1 || (!take && q == 0)) ws.outp[piece][eb.j] = pick;
-            if (q == 0) ws.outc[piece][eb.j] = c;
+            if (own0 || own1 || (!take && q == 0)) {
+               ws.outp[piece][eb.j] = pick;
+               ws.outc[piece][eb.j] = c;
+            }
             c1 = c;
             cin3 = cin2;
             cin2 = cin1;
@@ -382,11 +394,14 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
             const bool short0 = len0 >= ZH_MIN_MATCH && !long0 && ea.mlen0 >= ZH_MIN_MATCH, short1 = len1 >= ZH_MIN_MATCH && !long1 && ea.mlen1 >= ZH_MIN_MATCH;
             const uint32_t r0 = short0 ? ea.mlen0 - ZH_MIN_MATCH : 0u, r1 = short1 ? ea.mlen1 - ZH_MIN_MATCH : 0u;
             const uint32_t pk0 = ws.pmin[r0][ZH_LP_PCOL(r0, piece)];
-            const uint32_t pk1 = ws.pmin[r1][ZH_LP_PCOL(r1, piece)];
             const uint32_t lk0 = long0 ? ((ea.lc0 + ea.rg0 + ea.dp0) << 9) | (q << 6) : ZH_LP_NOKEY;
-            const uint32_t lk1 = long1 ? ((ea.lc1 + ea.rg1 + ea.dp1) << 9) | ((4u + q) << 6) : ZH_LP_NOKEY;
             nb.key0 = short0 ? pk0 + ((ea.dp0 << 9) | (q << 6)) : lk0;
-            nb.key1 = short1 ? pk1 + ((ea.dp1 << 9) | ((4u + q) << 6)) : lk1;
+            nb.key1 = ZH_LP_NOKEY;
+            if (j == 0 ? old_hi : cur_hi) {   // (the entry in this stage is the last one of the batch before when j is 0)
+               const uint32_t pk1 = ws.pmin[r1][ZH_LP_PCOL(r1, piece)];
+               const uint32_t lk1 = long1 ? ((ea.lc1 + ea.rg1 + ea.dp1) << 9) | ((4u + q) << 6) : ZH_LP_NOKEY;
+               nb.key1 = short1 ? pk1 + ((ea.dp1 << 9) | ((4u + q) << 6)) : lk1;
+            }
             nb.e0 = ea.e0;
             nb.e1 = ea.e1;
             nb.mlen0 = ea.mlen0;
@@ -405,7 +420,8 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
             na.mlen0 = min(len0, aroom);
             na.mlen1 = min(len1, aroom);
             na.dp0 = ws.distprice[len0 >= ZH_MIN_MATCH ? zh_lp_dist_index((na.e0 >> 16) - 1u) : 0u];   // rows are zero padded: an empty slot ends the row
-            na.dp1 = ws.distprice[len1 >= ZH_MIN_MATCH ? zh_lp_dist_index((na.e1 >> 16) - 1u) : 0u];
+            na.dp1 = 0;
+            if (cur_hi) na.dp1 = ws.distprice[len1 >= ZH_MIN_MATCH ? zh_lp_dist_index((na.e1 >> 16) - 1u) : 0u];
             na.lit = ws.litprice[abyte & 0xffu];
             const bool long0 = len0 >= ZH_LEAVE_ALONE;
             na.lc0 = na.lc1 = na.rg0 = na.rg1 = 0;
@@ -429,7 +445,9 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    }
 #undef ZH_LP_FETCH
 #undef ZH_LP_FETCH_HI
-#undef ZH_LP_FAR
+#undef ZH_LP_FAR_ON
+#undef ZH_LP_FAR_AT
+#undef ZH_LP_FAR_PICK
 #ifdef ZH_LP_PROFILE
    ZH_LP_COUNT(0, prof_steps);
    ZH_LP_COUNT(1, prof_quads);
@@ -444,24 +462,10 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
       zh_sync();
       for (uint32_t k = lane; k < ZH_NSYM; k += 64) ws.hist[k] = 0;
       zh_sync();
-      for (uint32_t idx = lane; idx < npieces; idx += 64) {
-         const uint32_t at = idx < nlongp ? idx : ZH_LP_MAXP - nshortp + (idx - nlongp);
-         uint32_t x = ws.plo[at];
-         const uint32_t hi = ws.phi[at];
-         while (x < hi) {
-            const uint32_t bm = best[x - prev];
-            const uint32_t byte = win[x];
-            const uint32_t len = bm & 0xffffu;
-            if (len >= ZH_MIN_MATCH) {
-               atomicAdd(&ws.hist[257 + zh_len_idx(len)], 1u);
-               atomicAdd(&ws.hist[ZH_NLIT + zh_dist_sym(bm >> 16)], 1u);
-               x += len;
-            }
-            else {
-               atomicAdd(&ws.hist[byte], 1u);
-               x++;
-            }
-         }
+      for (uint32_t gt = g0; gt < g1; gt++) {
+         if (!((parsed >> (gt - g0)) & 1ull)) continue;
+         const uint32_t jt = taskmap[gt].y;
+         zh_walk_histogram_wave(ws.hist, win, prev, zh_task_boundary(bar, prev, wk.start, sb_end, jt, wk.ntasks), zh_task_boundary(bar, prev, wk.start, sb_end, jt + 1, wk.ntasks), best);
       }
       zh_sync();
       bool first = true;

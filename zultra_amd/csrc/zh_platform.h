@@ -86,8 +86,9 @@ __device__ __forceinline__ uint32_t zh_quad_min(uint32_t v) {
    v = zh_dpp_min<ZH_DPP_QUAD_XOR2>(v);
    return v;
 }
-__device__ __forceinline__ uint32_t zh_quad_shr1(uint32_t v) { return zh_dpp<0x90>(v); }   // quad_perm:[0,0,1,2]
-__device__ __forceinline__ uint32_t zh_quad_lo2(uint32_t v) { return zh_dpp<0x44>(v); }    // quad_perm:[0,1,0,1]
+// (every lane reads a lane of its quad: no "old" value is needed, which saves the copy that keeps it)
+__device__ __forceinline__ uint32_t zh_quad_shr1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x90, 0xF, 0xF, true); }   // quad_perm:[0,0,1,2]
+__device__ __forceinline__ uint32_t zh_quad_lo2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x44, 0xF, 0xF, true); }    // quad_perm:[0,1,0,1]
 // whole-wave reductions: row step on the VALU, the 4 row results combined on the scalar unit
 __device__ __forceinline__ uint32_t zh_wave_min(uint32_t v) {
    v = zh_row_min(v);
