@@ -69,6 +69,29 @@ def test_chain_segments_are_both_accepted_and_redone(emu, oracle, monkeypatch, w
         assert 0 < st["cut_redone"] < 4 * cuts, st
 
 
+@pytest.mark.parametrize("block", [65536, 32768])
+def test_chain_lists_of_the_three_length_classes_do_not_run_into_each_other(emu, oracle, block):
+    """zh_list_huge files whole chain tasks in three length classes. Records of 1800 zeros + 8 random bytes make most task
+    slots of the run short chains (barrier-free runs of ~1800, periodic: never cut into segments) and one record of 7000 zeros
+    a long one: with the classes packed into one list of `cap` entries the long and the short class overlapped once more than
+    half the slots were listed — a task was then parsed twice and another never (round 2: 65 546 stored bytes instead of 476, and
+    at 32 KiB a stream that inflated to other bytes)."""
+    rng = np.random.default_rng(7)
+    recs = []
+    n = 0
+    k = 0
+    while n < 65536:
+        z = 7000 if k == 9 else 1800
+        recs += [np.zeros(z, dtype=np.uint8), rng.integers(1, 256, 8, dtype=np.uint8)]
+        n += z + 8
+        k += 1
+    d = np.concatenate(recs)[:65536]
+    got = emu.memory_compress(d, 2, block)
+    want = oracle.memory_compress(d, 2, block)
+    assert got is not None and zlib.decompress(got, 31) == d.tobytes()
+    assert got == want, "%d bytes, oracle %d" % (len(got), len(want))
+
+
 @pytest.mark.parametrize("name", ["tiny_100", "one_byte", "two_bytes", "json_4k", "json_4k_b"])
 def test_golden_streams(emu, name):
     c = G.stream_case(name)

@@ -447,8 +447,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->lane_waves = lw ? (uint32_t)max(1, min(16, atoi(lw))) : 12u;
       const char *mfp = getenv("ZULTRA_HIP_MF_CUS");   // share of the CUs the matchfinder's persistent workgroups take, in percent (tuning experiments)
       c->mf_cu_pct = mfp ? (uint32_t)max(1, min(100, atoi(mfp))) : 100u;
-      const char *sg = getenv("ZULTRA_HIP_STAGGER");   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group, 3 zh_mf_frontier (default), 4 the splitter
-      c->stagger_ev = sg ? atoi(sg) : 2;   // measured, 2 instead of 3: 100 MB of real text 51.9 -> 49.8 ms, configuration 3 31.6 -> 30.5, configuration 4 972 -> 910
+      const char *sg = getenv("ZULTRA_HIP_STAGGER");   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group (default), 3 zh_mf_frontier, 4 the splitter
+      c->stagger_ev = sg ? atoi(sg) : 2;   // (default 2)   // measured, 2 instead of 3: 100 MB of real text 51.9 -> 49.8 ms, configuration 3 31.6 -> 30.5, configuration 4 972 -> 910
       if (c->stagger_ev != 0 && (c->stagger_ev < 2 || c->stagger_ev > 4)) c->stagger_ev = 3;
       const char *fr = getenv("ZULTRA_HIP_FIRST_RUN");   // share of the first run, in percent of an equal share (tuning experiments)
       c->first_run_pct = fr ? (uint32_t)atoi(fr) : 100u;
@@ -510,7 +510,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_WARM + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;   // a task of len positions has at most len / ZH_CUT_LEN + ZH_CUT_ROWS segments
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
-       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, c->max_tasks) ||
+       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, 3 * c->max_tasks) ||
        zh_alloc(c, &c->d_segtasks, B * c->seg_tasks_per_block) || zh_alloc(c, &c->d_segwaves, B * c->seg_items_per_block) || zh_alloc(c, &c->d_segitems, B * c->seg_items_per_block) ||
        zh_alloc(c, &c->d_vecs, B * c->seg_items_per_block * 2 * ZH_VEC) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
@@ -638,7 +638,7 @@ extern "C" size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max
    bytes += B * slot_stride;                                         // payload slots
    bytes += (B * (N + 5 * (N / 65535 + 1) + 8) + 80);                // stitched stream
    bytes += subs * (sizeof(zh_sbstate_t) + sizeof(zh_work_t) + 2 * sizeof(zh_subblock_t) + sizeof(zh_stitch_item_t));
-   bytes += tasks * (sizeof(uint2) + 4 + 4 + ZH_NSYM * 4);           // task map, chain list, bit counts, histograms
+   bytes += tasks * (sizeof(uint2) + 3 * 4 + 4 + ZH_NSYM * 4);       // task map, chain lists, bit counts, histograms
    bytes += B * (S * (sizeof(zh_seg_t) + 8) + sizeof(zh_block_t) + cpb * 12 + (ZH_MAX_SPLITS + 1) * 4 + 6 * 4) + 8192;
    {
       // payload of the matchfinder's refining passes: per run (ZULTRA_HIP_STREAMS) and persistent workgroup (one per CU)
@@ -732,7 +732,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    zh_work_t *work = c->d_work + b0;
    zh_sbstate_t *states = c->d_states + b0;
    uint2 *taskmap = c->d_taskmap + t0;
-   uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM, *hugelist = c->d_hugelist + t0, *task_bits = c->d_task_bits + t0;
+   uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM, *hugelist = c->d_hugelist + 3 * t0, *task_bits = c->d_task_bits + t0;
    uint8_t *payload = c->d_payload + (uint64_t)b0 * c->slot_stride;
    uint32_t *best = c->d_best + (uint64_t)b0 * c->best_stride;
    const uint64_t *bars = c->d_bars + (uint64_t)b0 * c->bar_stride;
@@ -917,9 +917,11 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    auto run_lo = [&](int k) -> uint32_t {
       if (k <= 0) return 0u;
       if (k >= lanes) return nblocks;
-      const uint64_t first = (uint64_t)nblocks * c->first_run_pct / (100ull * (uint64_t)lanes);
+      // (a run is never empty: with ZULTRA_HIP_FIRST_RUN / _LAST_RUN below 25 and four max-blocks per run the shares rounded to 0, and a
+      // zero-sized grid fails the batch)
+      const uint64_t first = max((uint64_t)1, (uint64_t)nblocks * c->first_run_pct / (100ull * (uint64_t)lanes));
       if (lanes < 3) return (uint32_t)(first + ((uint64_t)nblocks - first) * (uint64_t)(k - 1) / (uint64_t)(lanes - 1));
-      const uint64_t last = (uint64_t)nblocks * c->last_run_pct / (100ull * (uint64_t)lanes);   // likewise the last run: its passes are the tail of the batch
+      const uint64_t last = max((uint64_t)1, (uint64_t)nblocks * c->last_run_pct / (100ull * (uint64_t)lanes));   // likewise the last run: its passes are the tail of the batch
       const uint64_t mid = (uint64_t)nblocks - first - last;
       if (k == lanes - 1) return (uint32_t)(nblocks - last);
       return (uint32_t)(first + mid * (uint64_t)(k - 1) / (uint64_t)(lanes - 2));
@@ -1032,7 +1034,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       int16_t *vecs = c->d_vecs + (uint64_t)b0 * c->seg_items_per_block * 2 * ZH_VEC;
       uint32_t *h_cnt = c->h_ntasks + ZH_NCNT + (size_t)k * ZH_CNT_STRIDE;   // read back before the passes are launched
       uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM;
-      uint32_t *hugelist = c->d_hugelist + t0;
+      uint32_t *hugelist = c->d_hugelist + 3 * t0;   // three lists of task_grid entries each (zh_list_huge)
       uint32_t *task_bits = c->d_task_bits + t0;
       uint8_t *payload = c->d_payload + (uint64_t)b0 * c->slot_stride;
       uint32_t *best = c->d_best + b0 * c->best_stride;

@@ -469,14 +469,15 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
    }
    if (lane == 0) {
       // three classes by length, handed out longest class first (zh_chain_ticket): what the pass will wait for are its longest
-      // chains, so they get the first tickets of zh_parse_chain. The very long ones fill the list from the front, the long ones
-      // from its middle, the rest from the back.
+      // chains, so they get the first tickets of zh_parse_chain. Each class has a list of `cap` entries of its own (any of them may
+      // hold every task of the run: with one shared list the long and the other tasks ran into each other when more than half of
+      // a run's task slots were listed).
       if (len > ZH_CHAIN_VLONG_TASK)
          hugelist[atomicAdd(&cnt[ZH_CNT_VLONG], 1u)] = gt;
       else if (len > ZH_CHAIN_LONG_TASK)
-         hugelist[cap / 2u + atomicAdd(&cnt[ZH_CNT_LONG], 1u)] = gt;
+         hugelist[cap + atomicAdd(&cnt[ZH_CNT_LONG], 1u)] = gt;
       else
-         hugelist[cap - 1u - atomicAdd(&cnt[ZH_CNT_SHORT], 1u)] = gt;
+         hugelist[2u * cap + atomicAdd(&cnt[ZH_CNT_SHORT], 1u)] = gt;
       atomicAdd(&cnt[ZH_CNT_HUGE_POS], len);
    }
 }
@@ -611,7 +612,7 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          slot = stask.z + k;
       }
       else
-         gt = item < nvlong ? hugelist[item] : (item < nvlong + nlong ? hugelist[cap / 2u + (item - nvlong)] : hugelist[cap - 1u - (item - nvlong - nlong - nseg)]);
+         gt = item < nvlong ? hugelist[item] : (item < nvlong + nlong ? hugelist[cap + (item - nvlong)] : hugelist[2u * cap + (item - nvlong - nlong - nseg)]);
       const zh_chain_task_t T = zh_chain_task(gt, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, pass);
       if (T.skip) continue;
       zh_chain_prices(ws, T.st);
