@@ -919,9 +919,9 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       if (k >= lanes) return nblocks;
       // (a run is never empty: with ZULTRA_HIP_FIRST_RUN / _LAST_RUN below 25 and four max-blocks per run the shares rounded to 0, and a
       // zero-sized grid fails the batch)
-      const uint64_t first = max((uint64_t)1, (uint64_t)nblocks * c->first_run_pct / (100ull * (uint64_t)lanes));
+      const uint64_t first = max((uint64_t)1, (uint64_t)((uint64_t)nblocks * c->first_run_pct / (100ull * (uint64_t)lanes)));
       if (lanes < 3) return (uint32_t)(first + ((uint64_t)nblocks - first) * (uint64_t)(k - 1) / (uint64_t)(lanes - 1));
-      const uint64_t last = max((uint64_t)1, (uint64_t)nblocks * c->last_run_pct / (100ull * (uint64_t)lanes));   // likewise the last run: its passes are the tail of the batch
+      const uint64_t last = max((uint64_t)1, (uint64_t)((uint64_t)nblocks * c->last_run_pct / (100ull * (uint64_t)lanes)));   // likewise the last run: its passes are the tail of the batch
       const uint64_t mid = (uint64_t)nblocks - first - last;
       if (k == lanes - 1) return (uint32_t)(nblocks - last);
       return (uint32_t)(first + mid * (uint64_t)(k - 1) / (uint64_t)(lanes - 2));
