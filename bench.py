@@ -60,26 +60,61 @@ def _free_port():
     return p
 
 
+def count_gpus():
+    """GPUs of this node from sysfs — no HIP / torch call, so the process that spawns the ranks never touches a GPU: KFD topology nodes
+    with SIMDs (CPUs have simd_count 0), else the DRM render nodes."""
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(f):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    if n == 0:
+        n = len(glob.glob("/dev/dri/renderD*"))
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    if vis:
+        n = min(n, len([v for v in vis.split(",") if v.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args, argv):
-    """--gpus N without a launcher: start N rank processes (fork + exec from a process that has not touched a GPU)."""
-    import torch
-    have = torch.cuda.device_count()   # counts devices without initialising the GPU (on this image)
+    """--gpus N without a launcher: start N rank processes (from a process that has not touched a GPU) and watch them: when one
+    fails the others would wait in the rendezvous or in a collective forever, so they are stopped and the failure is reported."""
+    have = count_gpus()
     if have < args.gpus:
         sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible — refusing to report a smaller job as N=%d\n" % (args.gpus, have, args.gpus))
         return 2
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    out0 = os.path.join(os.environ.get("TMPDIR", "/tmp"), "zultra_bench_rank0.%d.out" % os.getpid())
+    with open(out0, "wb") as f0:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=f0 if r == 0 else subprocess.DEVNULL))
+        bad = []
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(rcs) if c not in (None, 0)]
+            if bad or all(c is not None for c in rcs):
+                break
+            time.sleep(0.2)
+        if bad:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    sys.stdout.write(open(out0).read())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    os.unlink(out0)
     if bad:
-        sys.stderr.write("bench.py: rank(s) failed: %s\n" % bad)
+        sys.stderr.write("bench.py: rank(s) failed: %s (the other ranks were stopped)\n" % bad)
         return 1
     return 0
 
@@ -172,7 +207,18 @@ def text_corpus(world, size):
     return CyclicCorpus("real_text", base), "real text: the image's Python sources, sorted by path, cycled to size (enwik8 absent)"
 
 
+def find_file(env, names, size):
+    """A named corpus file when it is on the box: $env, ./data/<name>, /data/<name>, ~/<name> — of exactly `size` bytes."""
+    for p in [os.environ.get(env)] + [os.path.join(d, n) for n in names for d in (os.path.join(ROOT, "data"), "/data", os.path.expanduser("~"))]:
+        if p and os.path.isfile(p) and os.path.getsize(p) == size:
+            return p
+    return None
+
+
 def binary_corpus(world, size):
+    p = find_file("ZULTRA_MOZILLA", ["mozilla", "silesia/mozilla"], 51_220_480)
+    if p:
+        return CyclicCorpus("real_mozilla", np.fromfile(p, dtype=np.uint8)), "silesia/mozilla (real file)"
     base = _files_corpus(["/usr/lib/x86_64-linux-gnu/*.so*", "/usr/bin/*"], world * size)
     return CyclicCorpus("real_binary", base), "real binaries: shared libraries and executables of the image, sorted by path (silesia/mozilla absent)"
 
@@ -268,16 +314,21 @@ def inflate_check(flags, framed, first_shard, total_in):
 
 
 def committed_traffic(kernel, config):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json, written by
-    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command), or None."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this configuration (profiles/*_traffic_c<N>.json,
+    or an older *_traffic.json that names the configuration; written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this same command), or None."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_c%s.json" % config)))
+    if not files:
+        files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))) if json.load(open(f)).get("config") == config]
     if not files:
         return None, None
     with open(files[-1]) as f:
         t = json.load(f)
-    if t.get("config") != config:   # the counters were collected on another workload: no figure for this one
-        return None, None
-    k = t.get("kernels", {}).get(kernel) or t.get("kernels", {}).get(kernel.split("+")[0])   # a timed group is priced by its main kernel
+    ks = t.get("kernels", {})
+    k = ks.get(kernel) or ks.get(kernel.split("+")[0]) or ks.get(kernel.split("+")[-1])   # a timed group is priced by its main kernel
+    if kernel.startswith("zh_parse") and "zh_parse_lanes" in ks:   # the parse group: its kernels run side by side
+        tot = sum(ks[n]["hbm_bytes_per_launch"] * ks[n]["launches"] for n in ("zh_parse_lanes", "zh_parse_chain", "zh_parse_segments", "zh_parse_tasks") if n in ks)
+        return int(tot / max(1, ks["zh_parse_lanes"]["launches"])), os.path.basename(files[-1])
     if not k:
         return None, os.path.basename(files[-1])
     return int(k["hbm_bytes_per_launch"]), os.path.basename(files[-1])
@@ -377,13 +428,13 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
         avg = {k: float(np.mean([t[k] for t in timings])) for k in timings[0]}
         kernels = {"zh_mf_group": avg["group_ms"], "zh_mf_frontier": avg["frontier_ms"],
                    "zh_barriers+zh_tokenize_spans+zh_split": avg["tokenize_split_ms"], "zh_plan_subblocks+zh_sb_init": avg["init_ms"],
-                   "zh_parse_tasks+zh_parse_chain": avg["parse_ms"], "zh_sb_build": avg["build_ms"], "zh_post_tasks": avg["post_ms"],
+                   "zh_parse_lanes+zh_parse_chain": avg["parse_ms"], "zh_sb_build": avg["build_ms"], "zh_post_tasks": avg["post_ms"],
                    "zh_emit_tasks": avg["emit_ms"], "zh_stitch": avg["stitch_ms"]}
         # the library runs a batch as staggered runs of max-blocks on separate streams (ZULTRA_HIP_STREAMS): every kernel is launched
         # once per run (the parse / code-rebuild pair once per pass and run) over 1/runs of the batch
         runs = max(1, int(res["stats"]["runs"]))
         launches = {k: runs for k in kernels}
-        launches["zh_parse_tasks+zh_parse_chain"] = launches["zh_sb_build"] = 4 * runs
+        launches["zh_parse_lanes+zh_parse_chain"] = launches["zh_sb_build"] = 4 * runs
         launches["zh_stitch"] = 1
         dom = max(kernels, key=lambda k: kernels[k])
         out_bytes = len(body) / world
@@ -477,12 +528,16 @@ def run_stream_config(args, env, prep):
     if rank == 0 and world == 1:
         # whole-input ratio against zlib-9 (README.md:16-46 quotes sizes against zlib/zopfli)
         t0 = time.perf_counter()
-        z9 = len(zlib.compress(shard.tobytes(), 9))
-        line["size_vs_zlib9"] = round(len(framed) / (z9 + (12 if flags == 2 else 0)), 5)
-        line["zlib9_MBps_1core"] = round(len(shard) / (time.perf_counter() - t0) / 1e6, 1)
+        zs = shard if len(shard) <= (128 << 20) else shard[: 64 << 20]   # (zlib-9 runs at ~20 MB/s: a GiB shard is priced on its first 64 MiB)
+        z9 = len(zlib.compress(zs.tobytes(), 9))
+        ours = len(framed) if zs is shard else len(L.memory_compress(zs, flags, bs))
+        line["size_vs_zlib9"] = round(ours / (z9 + (12 if flags == 2 else 0)), 5)
+        if zs is not shard:
+            line["size_vs_zlib9_sample_bytes"] = len(zs)
+        line["zlib9_MBps_1core"] = round(len(zs) / (time.perf_counter() - t0) / 1e6, 1)
         # the drop-in entry on a host buffer: H2D, kernels, stitch, D2H, frame (PCIe-inclusive; never `value`)
         best, out = None, None
-        for _ in range(2):
+        for _ in range(1 if args.leg else 2):
             t0 = time.perf_counter()
             out = L.memory_compress(shard, flags, bs)
             dtm = time.perf_counter() - t0
@@ -491,12 +546,18 @@ def run_stream_config(args, env, prep):
         same = out == framed
         line["memory_compress_equals_sharded_pipeline"] = bool(same)
         failed |= not same
+        # a named corpus is on the box: the size the reference's README quotes for it (README.md:16,25; lzbench, framing and block size
+        # not stated: compared as raw deflate at the default block size, reported, not asserted)
+        readme = {"enwik8": 35029585, "real_mozilla": 18280189}.get(corp.name)
+        if readme and len(shard) == len(corp.base):
+            raw = L.memory_compress(shard, 0, 0)
+            line["readme_size_check"] = {"readme_bytes": readme, "raw_deflate_default_block_bytes": len(raw), "equal": bool(len(raw) == readme)}
         if cb is not None:
             line["cpu_baseline"] = cb
             gpu_out = L.memory_compress(sample, flags, bs)
             line["bit_exact_vs_cpu_on_sample"] = bool(gpu_out == ref_out)
             failed |= gpu_out != ref_out
-        if cfg == 2 and not args.no_synthetic:
+        if cfg == 2 and not args.no_synthetic and not args.leg:
             # round 1's headline corpus, for continuity: Zipf words without repeated phrases (never splits, never hits the chain parse)
             slead, sshard = SyntheticText().shard(0, size)
             syn = run_stream_leg(dict(env, config=None), slead, sshard, flags, bs, args.steps, args.warmup)
@@ -513,6 +574,9 @@ def run_stream_config(args, env, prep):
 def prepare_config1(args, rank, world):
     import corpus
     data = corpus.bootstrap_js()
+    p = find_file("ZULTRA_BOOTSTRAP", ["bootstrap.min.js"], 48944)   # the README's file (README.md:43: 12 599 B): reported beside the stand-in's known answer
+    if p:
+        args.readme_bootstrap = np.fromfile(p, dtype=np.uint8)
     cb, ref_out = cpu_baseline_stream(data, 0, 0, "bootstrap.min.js v3.4.1")
     return dict(data=data, cb=cb, ref_out=ref_out)
 
@@ -550,6 +614,9 @@ def run_config1(args, env, prep):
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 5), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 8),
                          "traffic": None, "launch_ms": round(kern[dom] / nl, 3), "launches_per_step": nl},
             "cpu_baseline": cb}
+    if getattr(args, "readme_bootstrap", None) is not None:
+        rb = L.memory_compress(args.readme_bootstrap, 0, 0)
+        line["readme_size_check"] = {"readme_bytes": 12599, "raw_deflate_default_block_bytes": len(rb), "equal": bool(len(rb) == 12599)}
     return line, not ok
 
 
@@ -637,8 +704,8 @@ def run_config5(args, env, prep):
                 "rccl_ranks_seen": env["ranks_seen"], "input_MBps": round(world * nfiles * size / (dt / args.steps) / 1e6, 2),
                 "ratio": round(out_bytes / (nfiles * size), 4), "graph_ms_per_batch": round(avg_graph, 3), "stitch_ms_per_batch": round(avg_stitch, 3),
                 "gzip_roundtrip_ok_first_files": bool(ok),
-                "roofline": {"bound": "hbm", "kernel": "hipGraph of stages 1-3 (dominant: zh_parse_tasks)", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "roofline": {"bound": "hbm", "kernel": "hipGraph of stages 1-3 (one replay per batch)", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": committed_traffic("graph", 5)[0], "traffic_source": committed_traffic("graph", 5)[1],
                              "algorithmic_bytes_per_launch": int(in_b + out_b), "launch_ms": round(avg_graph, 3), "launches_per_step": nb}}
         if args.profile_run:
             L.traffic_probe(256 << 20)
@@ -648,6 +715,39 @@ def run_config5(args, env, prep):
             failed |= h.hexdigest() != digest
     ctx.close()
     return line, failed
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_other_configs(args):
+    """The default run (configuration 2 on one GPU) also measures configurations 3, 4 and 5, bounded so that the whole command stays
+    within a few minutes: each as a child process of its own (started before this process touches the GPU), its JSON line condensed."""
+    legs = {3: ["--cpu-sample", str(8 << 20)], 4: ["--cpu-sample", str(4 << 20)], 5: ["--files", "262144", "--cpu-files", "2048"]}
+    out = {}
+    for cfg, extra in legs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--gpus", "1", "--steps", "2", "--warmup", "1", "--leg"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            lines = [x for x in r.stdout.decode().strip().splitlines() if x.startswith("{")]
+            d = json.loads(lines[-1]) if lines else None
+            rc = r.returncode
+        except (subprocess.TimeoutExpired, ValueError) as e:
+            d, rc = None, "%s" % type(e).__name__
+        if d is None:
+            out[str(cfg)] = {"error": "no line (rc %s)" % rc, "wall_s": round(time.perf_counter() - t0, 1)}
+            continue
+        keep = ("metric", "value", "unit", "ms_per_step", "kernel_ms", "graph_ms_per_batch", "input_MBps", "ratio", "size_vs_zlib9", "size_vs_zlib9_sample_bytes",
+                "inflate_roundtrip_ok", "gzip_roundtrip_ok_first_files", "bit_exact_vs_cpu_on_sample", "memory_compress_equals_sharded_pipeline", "end_to_end_MBps",
+                "compressed_bytes_total", "sub_blocks_per_block", "parse_huge_share_of_positions", "chain_cut", "readme_size_check")
+        o = {k: d[k] for k in keep if k in d}
+        o["workload"] = d["config"]["workload"]
+        o["roofline"] = d["roofline"]
+        if "cpu_baseline" in d:
+            o["cpu_baseline"] = {k: d["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "all_cores_value") if k in d["cpu_baseline"]}
+        o["rc"] = rc
+        o["wall_s"] = round(time.perf_counter() - t0, 1)
+        out[str(cfg)] = o
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -665,6 +765,8 @@ def main():
     ap.add_argument("--cpu-files", type=int, default=4096, help="config 5: files the CPU reference is timed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-synthetic", action="store_true", help="config 2: skip the synthetic-text leg")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run (config 2, one GPU): skip the legs of configurations 3, 4 and 5")
+    ap.add_argument("--leg", action="store_true", help="(internal) this process is one of those legs: bounded extras")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3 passes: only the steps (no round-trip / ratio / CPU extras that would add dispatches), then the PMC calibration probe")
     args = ap.parse_args()
@@ -681,6 +783,11 @@ def main():
     if args.config == 1 and world > 1:
         sys.stderr.write("bench.py: configuration 1 is a single 39 680-byte input: there is nothing to shard\n")
         sys.exit(2)
+
+    # ---- the other configurations' legs, as child processes, before this process touches a GPU ---------------------------------------
+    other = None
+    if args.config == 2 and world == 1 and not have_launcher and not args.profile_run and not args.leg and not args.no_other_configs:
+        other = run_other_configs(args)
 
     # ---- CPU side first: corpus generation and the CPU reference timing (config 5 forks worker processes) -------------------
     prep = {1: prepare_config1, 5: prepare_config5}.get(args.config, prepare_stream_config)(args, rank, world)
@@ -713,6 +820,9 @@ def main():
 
     line, failed = {1: run_config1, 5: run_config5}.get(args.config, run_stream_config)(args, env, prep)
     if rank == 0:
+        if other is not None:
+            line["other_configs"] = other
+            failed |= any(o.get("rc", 1) != 0 for o in other.values())
         print(json.dumps(line), flush=True)
     if world > 1:
         flag = torch.tensor([1 if failed else 0], dtype=torch.int64, device=device)

@@ -37,6 +37,9 @@
 
 #define ZH_MF_THREADS 1024
 #define ZH_MF_WAVES (ZH_MF_THREADS / 64)
+#ifndef ZH_MF_UNROLL
+#define ZH_MF_UNROLL 4u              // 64-element steps of a sort pass whose loads are issued together
+#endif
 #define ZH_MF_HEAD 0x80000000u       // sorted entry: first position of its 6-gram class
 #define ZH_MF_POS_MASK 0x7fffffffu
 #define ZH_MF_SENTINEL 0xffffffffu   // "no entry": marked, and farther than any legal distance
@@ -134,17 +137,17 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
    } while (0)
 
    // per-wave digit histogram of the wave's contiguous slice; four independent fetches in flight per lane
-   for (uint32_t base = lo; base < hi && !HAVE; base += 256) {
-      uint32_t e[4], d[4];
+   for (uint32_t base = lo; base < hi && !HAVE; base += 64 * ZH_MF_UNROLL) {
+      uint32_t e[ZH_MF_UNROLL], d[ZH_MF_UNROLL];
 #pragma unroll
-      for (uint32_t u = 0; u < 4; u++) {
+      for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {
          const uint32_t idx = base + u * 64 + lane;
          e[u] = 0;
          d[u] = 0xffffffffu;
          if (idx < hi) ZH_MF_FETCH(idx, e[u], d[u]);
       }
 #pragma unroll
-      for (uint32_t u = 0; u < 4; u++)
+      for (uint32_t u = 0; u < ZH_MF_UNROLL; u++)
          if (d[u] != 0xffffffffu) atomicAdd(&hist[wave * 256 + d[u]], 1u);
    }
    __syncthreads();
@@ -172,10 +175,11 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
    __syncthreads();
 
    // stable scatter: each wave walks its slice in order, 64 elements per step; the fetches of four steps are issued together
-   for (uint32_t base4 = lo; base4 < hi; base4 += 256) {
-      uint32_t e4[4], d4[4], p4[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0};
+   for (uint32_t base4 = lo; base4 < hi; base4 += 64 * ZH_MF_UNROLL) {
+      uint32_t e4[ZH_MF_UNROLL], d4[ZH_MF_UNROLL], p4[ZH_MF_UNROLL], q4[ZH_MF_UNROLL];
 #pragma unroll
-      for (uint32_t u = 0; u < 4; u++) {
+      for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {
+         p4[u] = q4[u] = 0;
          const uint32_t idx = base4 + u * 64 + lane;
          e4[u] = 0;
          d4[u] = 0xffffffffu;
@@ -186,7 +190,7 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
          }
       }
 #pragma unroll
-      for (uint32_t u = 0; u < 4; u++) {
+      for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {
          const uint32_t idx = base4 + u * 64 + lane;
          const uint32_t e = e4[u], d = d4[u];
          const bool valid = idx < hi && d != 0xffffffffu;
