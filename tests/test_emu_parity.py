@@ -69,7 +69,7 @@ def test_chain_segments_are_both_accepted_and_redone(emu, oracle, monkeypatch, w
         assert 0 < st["cut_redone"] < 4 * cuts, st
 
 
-@pytest.mark.parametrize("block", [65536, 32768])
+@pytest.mark.parametrize("block", [65536])
 def test_chain_lists_of_the_three_length_classes_do_not_run_into_each_other(emu, oracle, block):
     """zh_list_huge files whole chain tasks in three length classes. Records of 1800 zeros + 8 random bytes make most task
     slots of the run short chains (barrier-free runs of ~1800, periodic: never cut into segments) and one record of 7000 zeros
@@ -90,6 +90,18 @@ def test_chain_lists_of_the_three_length_classes_do_not_run_into_each_other(emu,
     want = oracle.memory_compress(d, 2, block)
     assert got is not None and zlib.decompress(got, 31) == d.tobytes()
     assert got == want, "%d bytes, oracle %d" % (len(got), len(want))
+
+
+def test_memory_compress_over_two_device_lanes(emu, oracle, monkeypatch):
+    """ZULTRA_HIP_DEVICES=0,0: zultra_memory_compress cuts the input into two shards of max-blocks, a host thread and a device
+    context each (here: on the emulator's one device, the kernels taking turns), and stitches the shards in stream order at the
+    bit phase the stream has reached — a stored sub-block sits right behind the cut. Same bytes as the one-stream path."""
+    d = corpus.text_like(4 * 32768 + 5000, 9)
+    d[2 * 32768:2 * 32768 + 12000] = corpus.noise(12000, 4)
+    want = oracle.memory_compress(d, 2, 32768)
+    monkeypatch.setenv("ZULTRA_HIP_DEVICES", "0,0")
+    got = emu.memory_compress(d, 2, 32768)
+    assert got == want
 
 
 @pytest.mark.parametrize("name", ["tiny_100", "one_byte", "two_bytes", "json_4k", "json_4k_b"])
@@ -215,3 +227,38 @@ def test_edge_sizes_and_tiny_alphabets_vs_oracle(emu, oracle):
     hist = np.concatenate(files)[-3000:]
     for f in files[60::9]:
         check_window(emu, oracle, np.concatenate([hist, f, f]), len(hist), 2 * len(f), tag="edge_tail_%d" % len(f))
+
+
+def test_stream_memory_comes_from_the_callers_allocator(emu, oracle):
+    """libzultra.h:88-90 / libzultra.c:59-71,94-147: a stream's own memory goes through the caller's zalloc / zfree — the
+    compressor state and its per-max-block arrays; the device context (device memory, pinned staging) belongs to the backend.
+    A counting allocator sees every one of these allocations freed by zultra_stream_end, and none after it."""
+    import ctypes as C
+    from zultra_amd._ffi import ZALLOC_T, ZFREE_T
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    live, log = {}, []
+
+    def za(opaque, items, size):
+        p = libc.malloc(items * size)
+        live[p] = items * size
+        log.append(items * size)
+        return p
+
+    def zf(opaque, p):
+        assert p in live, "zfree of memory zalloc never returned"
+        del live[p]
+        libc.free(p)
+
+    zalloc, zfree = ZALLOC_T(za), ZFREE_T(zf)
+    d = corpus.text_like(50000, 6)
+    s = emu.stream(2, 32768, zalloc, zfree)
+    assert len(log) >= 5 and len(live) == len(log)      # the state and four per-max-block arrays
+    n_init = len(log)
+    st, out = s.compress(d, True)
+    assert st == 1 and out == oracle.memory_compress(d, 2, 32768)
+    assert len(log) == n_init                           # compressing allocates nothing more on the host side of the stream
+    s.end()
+    assert not live

@@ -467,3 +467,160 @@ def test_cached_contexts_are_released_on_request(gpu):
         assert 0.95 * info[3].value <= est <= 1.10 * info[3].value, (est, info[3].value)   # the estimate follows the real layout
     finally:
         ctx.close()
+
+
+def test_api_state_machine_on_the_device(gpu, oracle):
+    """The stream API's corner conventions, on the GPU build (the emulator suite checks the same): ZULTRA_STREAM_END once, any
+    further call -5 (libzultra.c:204-205,504-507); zultra_stream_set_dictionary only before the first compress (libzultra.c:180);
+    zultra_memory_bound equal to the reference's formula (libzultra.c:576-587)."""
+    t = corpus.text_like(5000, 2)
+    s = gpu.stream(2, 0)
+    st, out = s.compress(t, True)
+    assert st == 1 and out == oracle.memory_compress(t, 2, 0)          # ZULTRA_STREAM_END with the whole stream delivered
+    st2, out2 = s.compress(t[:0], True)
+    assert st2 == -5 and out2 == b""                                    # ZULTRA_ERROR_COMPRESSION from then on
+    s.end()
+    s = gpu.stream(0, 0)
+    s.compress(t, False)
+    assert s.set_dictionary(t) == -5
+    s.end()
+    for n in (0, 1, 65535, 65536, 10 ** 6, (1 << 31) + 5):
+        for flags in (0, 1, 2):
+            for bs in (0, 32768, 65536, 1 << 22):
+                assert gpu.memory_bound(n, flags, bs) == oracle.memory_bound(n, flags, bs)
+
+
+@pytest.mark.parametrize("how", ["env_0_0", "api_0_0_0", "default_two_lanes_large_input"])
+def test_memory_compress_over_device_lanes(gpu, oracle, monkeypatch, how):
+    """zultra_memory_compress over several device contexts (libzultra.cpp: lanes; ZULTRA_HIP_DEVICES / zultra_set_devices): shards of
+    max-blocks compressed side by side by one host thread and one context each — here all on device 0 — and stitched in stream
+    order at the bit phase the stream has reached, with a stored sub-block right behind every cut. The bytes are those of the
+    one-stream path (and of the oracle)."""
+    import ctypes as C
+    bs = 65536
+    if how == "default_two_lanes_large_input":
+        d = corpus.real_text(56 << 20)
+        d[28 << 20:(28 << 20) + 40000] = corpus.noise(40000, 11)
+        monkeypatch.setenv("ZULTRA_HIP_MEMORY_LANES", "1")
+        want = gpu.memory_compress(d, 2, bs)
+        monkeypatch.delenv("ZULTRA_HIP_MEMORY_LANES")
+        got = gpu.memory_compress(d, 2, bs)                             # 48 MiB and more: two contexts on the device by itself
+        assert got == want and zlib.decompress(got, 31) == d.tobytes()
+        return
+    d = corpus.text_like_fast(24 * bs + 1234, 77)
+    lanes = 2 if how == "env_0_0" else 3
+    for k in range(1, lanes):
+        cut = ((24 * k + lanes - 1) // lanes) * bs if lanes == 3 else 12 * bs
+        d[cut:cut + 30000] = corpus.noise(30000, cut)
+    want = oracle.memory_compress(d, 1, bs)
+    if how == "env_0_0":
+        monkeypatch.setenv("ZULTRA_HIP_DEVICES", "0,0")
+        got = gpu.memory_compress(d, 1, bs)
+    else:
+        f = gpu.L.zultra_set_devices
+        f.argtypes = [C.POINTER(C.c_int), C.c_int]
+        f.restype = C.c_int
+        assert f((C.c_int * 1)(gpu.device_count()), 1) == -1            # not a visible device
+        assert f((C.c_int * 3)(0, 0, 0), 3) == 3
+        try:
+            got = gpu.memory_compress(d, 1, bs)
+        finally:
+            assert f(None, 0) == 0
+    assert got == want
+    assert zlib.decompress(got, 15) == d.tobytes()
+
+
+def test_sharded_assembly_at_world_two_with_the_real_kernels(tmp_path):
+    """zultra_amd.sharded.assemble — the N > 1 path of bench.py — with the REAL kernels: two rank processes, both on GPU 0, the
+    collectives over gloo (RCCL refuses two ranks on one device). A stored sub-block sits right behind the cut; rank 0's stream
+    equals the oracle's single stream."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    worker = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+import corpus, zlibs, zultra_amd
+from zultra_amd import sharded
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+L = zultra_amd.lib()
+bs = 65536
+data = corpus.text_like_fast(16 * bs + 7000, 5)
+data[8 * bs:8 * bs + 30000] = corpus.noise(30000, 8)          # stored sub-block right behind the cut between the ranks
+n = len(data)
+nb = (n + bs - 1) // bs
+lo, hi = sharded.shard_range(nb, rank, world)
+first = lo * bs - (32768 if lo else 0)
+blocks = [(b * bs - (32768 if b else 0) - first, 32768 if b else 0, min(bs, n - b * bs)) for b in range(lo, hi)]
+ctx = L.context(bs, hi - lo, device=0)
+ctx.compress_blocks(data[first:min(n, hi * bs)], blocks)
+stream, info = sharded.assemble(L, ctx, bs, dist, torch, torch.device("cpu"), (nb - 1 - lo) if hi == nb else -1)
+if rank == 0:
+    want = zlibs.Oracle().memory_compress(data, 0, bs)
+    assert stream.tobytes() == want, (len(stream), len(want))
+    print("SHARDED_GPU_OK", len(want), info["start_phase"])
+dist.destroy_process_group()
+'''
+    script = tmp_path / "worker.py"
+    script.write_text(worker % {"root": root, "here": here})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "SHARDED_GPU_OK" in outs[0], outs[0]
+
+
+def test_many_sub_blocks_in_one_max_block(gpu, oracle):
+    """The splitter's cap (blockdeflate.c:643-647: 63 interior splits, depth 6, 8192 bytes): a 2 MiB max-block of 64 stretches of
+    32 KiB, each over 16 byte values of its own that fall into one bin of the splitter's 18-bin statistics (blockdeflate.c:684-703:
+    literal bin = ((b >> 4) & 0xc) | (b & 3)), neighbours in different bins — the splitter cuts it into 41 sub-blocks; splits,
+    costs, parse and bits equal the oracle's."""
+    parts = []
+    for k in range(64):
+        r = corpus.noise(32768, 500 + k)
+        parts.append(((((k >> 2) & 3) << 6) | ((r & 15) << 2) | (k & 3)).astype(np.uint8))
+    d = np.concatenate(parts)
+    st = {}
+    check_window(gpu, oracle, d, 0, len(d), max_block=2 << 20, tag="many_splits", stats_out=st)
+    assert st["subblocks"] >= 32, st
+
+
+def test_stream_memory_comes_from_the_callers_allocator(gpu, oracle):
+    """libzultra.h:88-90 / libzultra.c:59-71,94-147: a stream's own memory goes through the caller's zalloc / zfree — the
+    compressor state and its per-max-block arrays; the device context (device memory, pinned staging) belongs to the backend.
+    A counting allocator sees every one of these allocations freed by zultra_stream_end, and none after it."""
+    import ctypes as C
+    from zultra_amd._ffi import ZALLOC_T, ZFREE_T
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    live, log = {}, []
+
+    def za(opaque, items, size):
+        p = libc.malloc(items * size)
+        live[p] = items * size
+        log.append(items * size)
+        return p
+
+    def zf(opaque, p):
+        assert p in live, "zfree of memory zalloc never returned"
+        del live[p]
+        libc.free(p)
+
+    zalloc, zfree = ZALLOC_T(za), ZFREE_T(zf)
+    d = corpus.text_like(50000, 6)
+    s = gpu.stream(2, 32768, zalloc, zfree)
+    assert len(log) >= 5 and len(live) == len(log)      # the state and four per-max-block arrays
+    n_init = len(log)
+    st, out = s.compress(d, True)
+    assert st == 1 and out == oracle.memory_compress(d, 2, 32768)
+    assert len(log) == n_init                           # compressing allocates nothing more on the host side of the stream
+    s.end()
+    assert not live

@@ -194,7 +194,10 @@ class Lib:
         f.restype = C.c_uint32
         return f(crc, a.ctypes.data, n.ctypes.data, len(a))
 
-    def stream(self, flags, max_block=0):
+    def stream(self, flags, max_block=0, zalloc=None, zfree=None):
+        return Stream(self, flags, max_block, zalloc, zfree)
+
+    def _stream_default(self, flags, max_block=0):
         return Stream(self, flags, max_block)
 
     def context(self, max_block, max_blocks, device=0):
@@ -204,12 +207,21 @@ class Lib:
         return HipContext(self, device, max_file_size, max_files, files=True)
 
 
+ZALLOC_T = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint, C.c_uint)
+ZFREE_T = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
 class Stream:
     """zultra_stream_t driven the way tool/zultra.c:151-186 drives it."""
 
-    def __init__(self, lib, flags, max_block=0):
+    def __init__(self, lib, flags, max_block=0, zalloc=None, zfree=None):
+        """zalloc / zfree: ctypes callbacks (ZALLOC_T / ZFREE_T) for the stream's own memory, as libzultra.h:88-90; default malloc / free."""
         self.lib = lib
         self.s = _Stream()
+        self._alloc = (zalloc, zfree)
+        if zalloc is not None:
+            self.s.zalloc = C.cast(zalloc, C.c_void_p)
+            self.s.zfree = C.cast(zfree, C.c_void_p)
         rc = lib.L.zultra_stream_init(C.byref(self.s), flags, max_block)
         if rc != ZULTRA_OK:
             raise ZultraError("zultra_stream_init failed: %d (no HIP device? the library has no CPU path)" % rc)

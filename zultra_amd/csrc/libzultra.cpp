@@ -9,8 +9,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "../../include/libzultra.h"
@@ -420,6 +422,42 @@ static int zh_pick_device() {
 
 extern "C" void zultra_set_device(int nDevice) { g_device = nDevice; }
 
+// The devices zultra_memory_compress spreads an input over: zultra_set_devices, else ZULTRA_HIP_DEVICES="0,1,2,..." (a device may be
+// named more than once: "0,0" = two contexts on device 0, the kernels of one batch next to the transfers of another), else none.
+static std::vector<int> g_devices;
+extern "C" int zultra_set_devices(const int *pDevices, int nDevices) {
+   std::lock_guard<std::mutex> lk(g_ctx_mutex);
+   g_devices.clear();
+   const int have = zultra_hip_device_count();
+   for (int i = 0; i < nDevices; i++) {
+      if (pDevices[i] < 0 || pDevices[i] >= have) {
+         g_devices.clear();
+         return -1;
+      }
+      g_devices.push_back(pDevices[i]);
+   }
+   return nDevices;
+}
+static std::vector<int> zh_pick_devices() {
+   {
+      std::lock_guard<std::mutex> lk(g_ctx_mutex);
+      if (!g_devices.empty()) return g_devices;
+   }
+   std::vector<int> v;
+   const char *e = getenv("ZULTRA_HIP_DEVICES");
+   if (e) {
+      const int have = zultra_hip_device_count();
+      for (const char *p = e; *p;) {
+         char *end = NULL;
+         const long d = strtol(p, &end, 10);
+         if (end == p) break;
+         if (d >= 0 && d < have) v.push_back((int)d);
+         p = (*end == ',') ? end + 1 : end;
+      }
+   }
+   return v;
+}
+
 static uint32_t clamp_block(uint32_t n) {
    if (!n) n = ZULTRA_DEFAULT_MAX_BLOCK_SIZE;
    if (n < 32768) n = 32768;
@@ -427,8 +465,7 @@ static uint32_t clamp_block(uint32_t n) {
    return n;
 }
 
-static zultra_hip_ctx_t *ctx_acquire(uint32_t bs, uint32_t want_blocks) {
-   const int dev = zh_pick_device();
+static zultra_hip_ctx_t *ctx_acquire_on(int dev, uint32_t bs, uint32_t want_blocks) {
    std::lock_guard<std::mutex> lk(g_ctx_mutex);
    for (size_t i = 0; i < g_ctx_pool.size(); i++) {
       if (g_ctx_pool[i].device == dev && g_ctx_pool[i].max_block == bs && g_ctx_pool[i].max_blocks >= want_blocks) {
@@ -448,6 +485,7 @@ static zultra_hip_ctx_t *ctx_acquire(uint32_t bs, uint32_t want_blocks) {
    }
    return zultra_hip_create(dev, bs, want_blocks);
 }
+static zultra_hip_ctx_t *ctx_acquire(uint32_t bs, uint32_t want_blocks) { return ctx_acquire_on(zh_pick_device(), bs, want_blocks); }
 
 // A finished stream's context goes back under what the CONTEXT says it is (device, block size, capacity) — not under what the
 // stream asked for or what zultra_set_device says now.
@@ -462,9 +500,15 @@ static void ctx_release(zultra_hip_ctx_t *c) {
    cc.ctx = c;
    zultra_hip_ctx_info(c, &cc.device, &cc.max_block, &cc.max_blocks, NULL);
    std::lock_guard<std::mutex> lk(g_ctx_mutex);
-   if (g_ctx_pool.size() >= 2) {
-      zultra_hip_destroy(g_ctx_pool[0].ctx);
-      g_ctx_pool.erase(g_ctx_pool.begin());
+   size_t same = 0, first_same = 0;   // at most two kept per device
+   for (size_t i = g_ctx_pool.size(); i-- > 0;)
+      if (g_ctx_pool[i].device == cc.device) {
+         same++;
+         first_same = i;
+      }
+   if (same >= 2) {
+      zultra_hip_destroy(g_ctx_pool[first_same].ctx);
+      g_ctx_pool.erase(g_ctx_pool.begin() + (long)first_same);
    }
    g_ctx_pool.push_back(cc);
 }
@@ -498,10 +542,12 @@ struct _zultra_compressor_s {
    unsigned char frame[16];
    size_t frame_pos, frame_pending;
 
-   std::vector<zultra_hip_block_t> blocks;
-   std::vector<uint64_t> raw_off;
-   std::vector<uint32_t> crc;
-   std::vector<uint32_t> adler_parts;
+   // per max-block of a batch, batch_blocks entries each, from the caller's allocator (libzultra.c:94-147: every buffer of a stream
+   // comes from zalloc; what does not here is the device context — device memory and pinned staging — which belongs to the backend)
+   zultra_hip_block_t *blocks;
+   uint64_t *raw_off;
+   uint32_t *crc;
+   uint32_t *adler_parts;       // two per max-block
    bool host_stitch;            // ZULTRA_HIP_HOST_STITCH=1: stitch on the host (A/B checking)
 };
 
@@ -530,6 +576,10 @@ static zultra_status_t stream_init_sized(zultra_stream_t *s, unsigned flags, uns
    c->out_pos = c->out_pending = 0;
    c->frame_pos = c->frame_pending = 0;
    c->in = c->out = NULL;
+   c->hip = NULL;
+   c->blocks = NULL;
+   c->raw_off = NULL;
+   c->crc = c->adler_parts = NULL;
    {
       const char *e = getenv("ZULTRA_HIP_HOST_STITCH");
       c->host_stitch = e && atoi(e) != 0;
@@ -544,6 +594,14 @@ static zultra_status_t stream_init_sized(zultra_stream_t *s, unsigned flags, uns
    const uint64_t budget = 24ull << 30;
    while (batch_blocks > 1 && (uint64_t)zultra_hip_context_bytes(bs, batch_blocks) > budget) batch_blocks = batch_blocks - (batch_blocks + 7) / 8;
    c->batch_blocks = batch_blocks;
+   c->blocks = (zultra_hip_block_t *)s->zalloc(s->opaque, batch_blocks, (unsigned)sizeof(zultra_hip_block_t));
+   c->raw_off = (uint64_t *)s->zalloc(s->opaque, batch_blocks, (unsigned)sizeof(uint64_t));
+   c->crc = (uint32_t *)s->zalloc(s->opaque, batch_blocks, (unsigned)sizeof(uint32_t));
+   c->adler_parts = (uint32_t *)s->zalloc(s->opaque, 2 * batch_blocks, (unsigned)sizeof(uint32_t));
+   if (!c->blocks || !c->raw_off || !c->crc || !c->adler_parts) {
+      zultra_stream_end(s);
+      return ZULTRA_ERROR_MEMORY;
+   }
 
    c->hip = ctx_acquire(bs, batch_blocks);
    if (!c->hip) {
@@ -583,6 +641,10 @@ extern "C" void zultra_stream_end(zultra_stream_t *s) {
       zultra_compressor_t *c = s->state;
       ctx_release(c->hip);
       /* c->in / c->out belong to the device context */
+      if (c->blocks) s->zfree(s->opaque, c->blocks);
+      if (c->raw_off) s->zfree(s->opaque, c->raw_off);
+      if (c->crc) s->zfree(s->opaque, c->crc);
+      if (c->adler_parts) s->zfree(s->opaque, c->adler_parts);
       c->~zultra_compressor_t();
       s->zfree(s->opaque, c);
       s->state = NULL;
@@ -604,8 +666,7 @@ static void drain_frame(zultra_stream_t *s, zultra_compressor_t *c) {
 // Compress `count` max-blocks staged at c->in + HISTORY (the last one `last_n` bytes long).
 static zultra_status_t compress_staged(zultra_stream_t *s, zultra_compressor_t *c, uint32_t count, uint32_t last_n, bool final_last) {
    const uint32_t bs = c->max_block;
-   c->blocks.resize(count);
-   c->raw_off.resize(count);
+   if (count > c->batch_blocks) return ZULTRA_ERROR_COMPRESSION;
    const uint64_t base = (uint64_t)HISTORY_SIZE - (uint64_t)c->prev;   // window of block 0 starts here
    size_t consumed = 0;
    for (uint32_t b = 0; b < count; b++) {
@@ -618,18 +679,16 @@ static zultra_status_t compress_staged(zultra_stream_t *s, zultra_compressor_t *
       consumed += n;
    }
    const size_t data_size = (size_t)c->prev + consumed;
-   int nsubs = zultra_hip_compress_blocks(c->hip, c->in + base, data_size, 0, c->blocks.data(), count);
+   int nsubs = zultra_hip_compress_blocks(c->hip, c->in + base, data_size, 0, c->blocks, count);
    if (nsubs <= 0) return ZULTRA_ERROR_COMPRESSION;
 
    // checksum once per max-block over its bytes (libzultra.c:279): both kinds come from the device, folded here
    if (c->flags & ZULTRA_FLAG_GZIP_FRAMING) {
-      c->crc.resize(count);
-      if (zultra_hip_block_crc32(c->hip, c->crc.data()) != (int)count) return ZULTRA_ERROR_COMPRESSION;
+      if (zultra_hip_block_crc32(c->hip, c->crc) != (int)count) return ZULTRA_ERROR_COMPRESSION;
       for (uint32_t b = 0; b < count; b++) s->adler = zultra_crc32_append(s->adler, c->crc[b], c->blocks[b].n);
    }
    else if (c->flags & ZULTRA_FLAG_ZLIB_FRAMING) {
-      c->adler_parts.resize(2 * (size_t)count);
-      if (zultra_hip_block_adler32(c->hip, c->adler_parts.data()) != (int)count) return ZULTRA_ERROR_COMPRESSION;
+      if (zultra_hip_block_adler32(c->hip, c->adler_parts) != (int)count) return ZULTRA_ERROR_COMPRESSION;
       for (uint32_t b = 0; b < count; b++) s->adler = zultra_adler32_append(s->adler, c->adler_parts[2 * b], c->adler_parts[2 * b + 1], c->blocks[b].n);
    }
 
@@ -661,7 +720,7 @@ static zultra_status_t compress_staged(zultra_stream_t *s, zultra_compressor_t *
       const zultra_hip_subblock_t *subs = zultra_hip_subblocks(c->hip, &cnt);
       size_t psize = 0;
       const uint8_t *payload = zultra_hip_payload(c->hip, &psize);
-      w = zultra_hip_stitch(&c->bitstate, subs, cnt, payload, c->in + HISTORY_SIZE, c->raw_off.data(), bs,
+      w = zultra_hip_stitch(&c->bitstate, subs, cnt, payload, c->in + HISTORY_SIZE, c->raw_off, bs,
                             final_last ? (int)count - 1 : -1, c->out, c->out_cap);
       if (w == (size_t)-1) return ZULTRA_ERROR_DST;
       if (final_last) {
@@ -795,11 +854,224 @@ extern "C" size_t zultra_memory_bound(size_t nInputSize, const unsigned int nFla
           (size_t)zultra_frame_get_footer_size(nFlags);
 }
 
+// ---- in-memory compression over several device contexts ("lanes") ---------------------------------------------------------------
+// The reference's zultra_memory_compress (libzultra.c:601-619) is one stream; here the whole input is at hand, and max-blocks only
+// need the 32 KiB in front of them: the input is cut into contiguous *jobs* of max-blocks, job j goes to lane j % lanes — a lane = a
+// device context on one of the devices of ZULTRA_HIP_DEVICES / zultra_set_devices, with a host thread of its own that stages the job's
+// bytes into the context's pinned memory and runs the batch (upload + kernels). What depends on the bit phase the stream has reached —
+// BFINAL / BTYPE bits, stored fallback, bit carry (libzultra.c:327-398,414-436) — is the stitch, and that is done by the calling
+// thread job by job in stream order, on the job's own device, as soon as the job's batch is done; the stitched bytes go to pOut
+// while the lanes are at their next jobs. Same bytes as the one-stream path: both cut max-blocks at multiples of the block size.
+namespace {
+struct MemJob {
+   size_t block0, nblocks;   // max-blocks [block0, block0 + nblocks) of the input
+   int state;                // 0 waiting, 1 batch done, -1 failed, 2 stitched (the lane's context is free again)
+};
+struct MemLanes {
+   const unsigned char *in;
+   size_t n_in;
+   uint32_t bs;
+   size_t total_blocks;
+   const void *dict;
+   int dict_size;
+   std::vector<MemJob> jobs;
+   std::vector<zultra_hip_ctx_t *> ctx;
+   std::mutex m;
+   std::condition_variable cv;
+   bool abort;
+};
+
+// input bytes -> pinned staging: the copy is what a lane's first job waits for, so large ones are split over a few threads
+static void staged_copy(uint8_t *dst, const uint8_t *src, size_t n) {
+   const size_t piece = 16u << 20;
+   if (n < 2 * piece) {
+      memcpy(dst, src, n);
+      return;
+   }
+   const size_t nt = n / piece < 4 ? n / piece : 4;
+   std::vector<std::thread> th;
+   for (size_t t = 1; t < nt; t++) th.emplace_back([=] { memcpy(dst + n * t / nt, src + n * t / nt, n * (t + 1) / nt - n * t / nt); });
+   memcpy(dst, src, n / nt);
+   for (auto &t : th) t.join();
+}
+
+static void mem_lane_thread(MemLanes *M, size_t lane) {
+   zultra_hip_ctx_t *c = M->ctx[lane];
+   std::vector<zultra_hip_block_t> blocks;
+   for (size_t j = lane; j < M->jobs.size(); j += M->ctx.size()) {
+      MemJob &J = M->jobs[j];
+      if (j >= M->ctx.size()) {   // the lane's previous job must have left the context (stitched and read out)
+         std::unique_lock<std::mutex> lk(M->m);
+         M->cv.wait(lk, [&] { return M->abort || M->jobs[j - M->ctx.size()].state == 2; });
+      }
+      {
+         std::lock_guard<std::mutex> lk(M->m);
+         if (M->abort) return;
+      }
+      const size_t first = J.block0 * M->bs, last = first + J.nblocks * M->bs < M->n_in ? first + J.nblocks * M->bs : M->n_in;
+      // history of the job's first max-block: the 32 KiB of input in front of it, or the preset dictionary (libzultra.c:250-253)
+      size_t hist = first < (size_t)HISTORY_SIZE ? first : (size_t)HISTORY_SIZE;
+      const uint8_t *hsrc = M->in + first - hist;
+      if (J.block0 == 0 && M->dict && M->dict_size > 0) {
+         hist = M->dict_size > HISTORY_SIZE ? (size_t)HISTORY_SIZE : (size_t)M->dict_size;
+         hsrc = (const uint8_t *)M->dict + (M->dict_size - (int)hist);
+      }
+      uint8_t *stage = (uint8_t *)zultra_hip_staging(c, 0, (size_t)HISTORY_SIZE + J.nblocks * M->bs);
+      int ok = stage != NULL;
+      if (ok) {
+         memcpy(stage, hsrc, hist);
+         staged_copy(stage + hist, M->in + first, last - first);
+         blocks.resize(J.nblocks);
+         for (size_t b = 0; b < J.nblocks; b++) {
+            const uint32_t prev = b == 0 ? (uint32_t)hist : (uint32_t)HISTORY_SIZE;
+            const size_t at = first + b * M->bs;
+            blocks[b].win_off = hist + b * M->bs - prev;
+            blocks[b].prev = prev;
+            blocks[b].n = (uint32_t)(at + M->bs <= M->n_in ? M->bs : M->n_in - at);
+         }
+         ok = zultra_hip_compress_blocks(c, stage, hist + (last - first), 0, blocks.data(), (uint32_t)J.nblocks) > 0;
+      }
+      {
+         std::lock_guard<std::mutex> lk(M->m);
+         J.state = ok ? 1 : -1;
+         if (!ok) M->abort = true;
+      }
+      M->cv.notify_all();
+      if (!ok) return;
+   }
+}
+}   // namespace
+
+static size_t memory_compress_lanes(const unsigned char *pIn, size_t nIn, unsigned char *pOut, size_t nOutCap, const unsigned int nFlags, uint32_t bs,
+                                    const void *pDict, int nDictSize, const std::vector<int> &devices) {
+   MemLanes M;
+   M.in = pIn;
+   M.n_in = nIn;
+   M.bs = bs;
+   M.total_blocks = (nIn + bs - 1) / bs;
+   M.dict = pDict;
+   M.dict_size = nDictSize;
+   M.abort = false;
+   // jobs: as few as there are lanes when the input fits that way, else batches of the size a one-stream call would use
+   size_t per = (M.total_blocks + devices.size() - 1) / devices.size();
+   const uint64_t budget = 24ull << 30;
+   if (per > 8192) per = 8192;
+   while (per > 1 && (uint64_t)zultra_hip_context_bytes(bs, (uint32_t)per) > budget) per -= (per + 7) / 8;
+   for (size_t b = 0; b < M.total_blocks; b += per) M.jobs.push_back(MemJob{b, M.total_blocks - b < per ? M.total_blocks - b : per, 0});
+   const size_t lanes = M.jobs.size() < devices.size() ? M.jobs.size() : devices.size();
+   for (size_t l = 0; l < lanes; l++) {
+      zultra_hip_ctx_t *c = ctx_acquire_on(devices[l], bs, (uint32_t)per);
+      if (!c) {
+         for (auto *k : M.ctx) ctx_release(k);
+         return (size_t)-1;
+      }
+      M.ctx.push_back(c);
+   }
+   std::vector<std::thread> threads;
+   for (size_t l = 0; l < lanes; l++) threads.emplace_back(mem_lane_thread, &M, l);
+
+   size_t w = 0;
+   bool fail = false;
+   {
+      unsigned char hdr[16];
+      const int h = zultra_frame_encode_header(hdr, 16, nFlags, pDict, nDictSize);
+      if (h < 0 || (size_t)h > nOutCap)
+         fail = true;
+      else {
+         memcpy(pOut, hdr, (size_t)h);
+         w = (size_t)h;
+      }
+   }
+   zultra_frame_checksum_t sum = zultra_frame_init_checksum(nFlags);
+   zultra_hip_bitstate_t bit;
+   bit.acc = bit.nacc = 0;
+   std::vector<uint32_t> parts;
+   for (size_t j = 0; j < M.jobs.size(); j++) {
+      MemJob &J = M.jobs[j];
+      {
+         std::unique_lock<std::mutex> lk(M.m);
+         M.cv.wait(lk, [&] { return J.state != 0 || M.abort; });
+         if (J.state != 1) fail = true;
+      }
+      zultra_hip_ctx_t *c = M.ctx[j % lanes];
+      if (!fail) {
+         // checksum once per max-block over its bytes (libzultra.c:279): computed on the device next to the compression, folded here
+         const size_t first = J.block0 * bs;
+         if (nFlags & ZULTRA_FLAG_GZIP_FRAMING) {
+            parts.resize(J.nblocks);
+            fail = zultra_hip_block_crc32(c, parts.data()) != (int)J.nblocks;
+            for (size_t b = 0; b < J.nblocks && !fail; b++) {
+               const size_t at = first + b * bs;
+               sum = zultra_crc32_append(sum, parts[b], at + bs <= nIn ? bs : nIn - at);
+            }
+         }
+         else if (nFlags & ZULTRA_FLAG_ZLIB_FRAMING) {
+            parts.resize(2 * J.nblocks);
+            fail = zultra_hip_block_adler32(c, parts.data()) != (int)J.nblocks;
+            for (size_t b = 0; b < J.nblocks && !fail; b++) {
+               const size_t at = first + b * bs;
+               sum = zultra_adler32_append(sum, parts[2 * b], parts[2 * b + 1], at + bs <= nIn ? bs : nIn - at);
+            }
+         }
+      }
+      if (!fail) {
+         const bool last = j + 1 == M.jobs.size();
+         uint64_t end_bit = 0;
+         const uint32_t phase = bit.nacc;
+         const uint32_t pending = bit.acc & ((1u << phase) - 1);
+         const int rc = zultra_hip_stitch_device(c, &bit, last ? (int)J.nblocks - 1 : -1, &end_bit);
+         const size_t total = (size_t)((end_bit + 7) >> 3);
+         uint8_t *stage = rc == 0 ? (uint8_t *)zultra_hip_staging(c, 1, total + 16) : NULL;
+         if (rc != 0 || !stage || zultra_hip_stream_read(c, stage, 0, total) != 0)
+            fail = true;
+         else {
+            stage[0] |= (uint8_t)pending;
+            // whole bytes go out; a trailing partial byte stays pending for the next job (the last job's is zero padded, libzultra.c:414-417)
+            const size_t whole = last ? total : (size_t)(end_bit >> 3);
+            if (w + whole > nOutCap)
+               fail = true;
+            else {
+               memcpy(pOut + w, stage, whole);
+               w += whole;
+               bit.acc = (!last && (end_bit & 7)) ? stage[whole] : 0;
+               if (last) bit.nacc = 0;
+            }
+         }
+      }
+      {
+         std::lock_guard<std::mutex> lk(M.m);
+         J.state = 2;
+         if (fail) M.abort = true;
+      }
+      M.cv.notify_all();
+      if (fail) break;
+   }
+   for (auto &t : threads) t.join();
+   for (auto *k : M.ctx) ctx_release(k);
+   if (fail) return (size_t)-1;
+   unsigned char ftr[16];
+   const int f = zultra_frame_encode_footer(ftr, 16, sum, (long long)nIn, nFlags);
+   if (f < 0 || w + (size_t)f > nOutCap) return (size_t)-1;
+   memcpy(pOut + w, ftr, (size_t)f);
+   return w + (size_t)f;
+}
+
 extern "C" size_t zultra_memory_compress_dict(const unsigned char *pIn, size_t nIn, unsigned char *pOut, size_t nOutCap,
                                               const unsigned int nFlags, unsigned int nMaxBlockSize, const void *pDict, int nDictSize) {
    zultra_stream_t strm;
    memset(&strm, 0, sizeof(strm));
    const uint32_t bs = clamp_block(nMaxBlockSize);
+   // several devices asked for (or two contexts on one: ZULTRA_HIP_DEVICES=0,0), and at least two max-blocks per lane to give them
+   {
+      std::vector<int> devs = zh_pick_devices();
+      if (devs.empty() && nIn >= (size_t)(48u << 20)) {
+         // one device, a large input: two contexts on it, so that one half's staging, upload and read-back run next to the other half's kernels
+         const char *e = getenv("ZULTRA_HIP_MEMORY_LANES");
+         const int lanes = e ? atoi(e) : 2;
+         for (int l = 0; l < lanes && lanes > 1; l++) devs.push_back(zh_pick_device());
+      }
+      if (devs.size() > 1 && pIn && nIn && (nIn + bs - 1) / bs >= 2 * devs.size()) return memory_compress_lanes(pIn, nIn, pOut, nOutCap, nFlags, bs, pDict, nDictSize, devs);
+   }
    // the whole input is at hand: size the device batch to it
    uint64_t want = (nIn + bs - 1) / bs;
    if (want < 1) want = 1;

@@ -35,6 +35,16 @@
 #include "zh_split.h"
 #include "zh_stitch.h"
 
+#ifdef ZH_EMU
+#include <mutex>
+// the lock-step emulator (tests/emu) runs one kernel at a time on one OS thread's fibers: host threads that drive contexts of their
+// own (libzultra.cpp: lanes of zultra_memory_compress) take turns here. The product build has no such lock.
+static std::recursive_mutex g_emu_mutex;
+#define ZH_EMU_SERIALIZE() std::lock_guard<std::recursive_mutex> emu_lock_(g_emu_mutex)
+#else
+#define ZH_EMU_SERIALIZE()
+#endif
+
 #define ZH_MAX_RUNS 8           // staggered runs of a batch (ZULTRA_HIP_STREAMS)
 #define ZH_NCNT ((uint32_t)ZH_MAX_RUNS * ZH_CNT_STRIDE)   // device counters: one block of ZH_CNT_* words per run
 
@@ -877,6 +887,7 @@ static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
 
 extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data, size_t data_size, int data_on_device,
                                           const zultra_hip_block_t *blocks, uint32_t nblocks) {
+   ZH_EMU_SERIALIZE();
    if (!c || !data || !blocks || nblocks == 0 || nblocks > c->max_blocks) {
       if (c) snprintf(c->err, sizeof(c->err), "bad arguments");
       return -1;
@@ -1200,6 +1211,7 @@ extern "C" int zultra_hip_block_crc32(const zultra_hip_ctx_t *c, uint32_t *out) 
 // bits after it and *end_bit = total bits from the start of the byte that held the pending bits. The stream buffer
 // holds ceil(end_bit / 8) bytes; its first byte carries only this batch's bits (OR the caller's pending bits in).
 extern "C" int zultra_hip_stitch_device(zultra_hip_ctx_t *c, zultra_hip_bitstate_t *state, int final_block, uint64_t *end_bit) {
+   ZH_EMU_SERIALIZE();
    if (!c || !state || !end_bit || c->nsubs == 0) return -1;
    c->items.resize(c->nsubs);
    uint64_t eb = 0;

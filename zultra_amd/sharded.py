@@ -16,6 +16,7 @@ ranks after the compute:
 `dist` is torch.distributed (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -42,8 +43,10 @@ def _stream_tensor(ctx, torch, device, nbytes):
     ptr = ctx.stream_ptr()
     if device.type == "cuda":
         return torch.as_tensor(_DevBuf(ptr, nbytes), device=device)
-    buf = (C.c_uint8 * nbytes).from_address(ptr)   # CPU emulator build: the "device" buffer is host memory
-    return torch.from_numpy(np.ctypeslib.as_array(buf))
+    if "emu" in os.path.basename(ctx.lib.path):
+        buf = (C.c_uint8 * nbytes).from_address(ptr)   # CPU emulator build: the "device" buffer is host memory
+        return torch.from_numpy(np.ctypeslib.as_array(buf))
+    return torch.from_numpy(ctx.stream_read(nbytes).copy())   # real device, collectives on CPU tensors (gloo tests): through the host
 
 
 def phase_table(lib, ctx, max_block):
