@@ -67,7 +67,7 @@ class BitState(C.Structure):
 EXPORTS = [
     # include/libzultra.h
     "zultra_stream_init", "zultra_stream_set_dictionary", "zultra_stream_compress", "zultra_stream_end",
-    "zultra_memory_bound", "zultra_memory_compress", "zultra_memory_compress_dict", "zultra_set_device",
+    "zultra_memory_bound", "zultra_memory_compress", "zultra_memory_compress_dict", "zultra_set_device", "zultra_set_devices",
     "zultra_frame_get_header_size", "zultra_frame_encode_header", "zultra_frame_init_checksum",
     "zultra_frame_update_checksum", "zultra_frame_get_footer_size", "zultra_frame_encode_footer",
     "zultra_dictionary_load", "zultra_dictionary_free",
