@@ -118,8 +118,8 @@ void zultra_set_device(int nDevice);
 /* Devices zultra_memory_compress spreads an input over (default: env ZULTRA_HIP_DEVICES="0,1,...", else the one device above). The
  * max-blocks of the input are cut into contiguous shards, one host thread and one device context per entry compress them side by
  * side, and the shards' bit strings are stitched in stream order on their own devices: the output bytes do not depend on the list.
- * An entry may repeat a device ("0,0": two contexts on device 0 — transfers of one shard next to the kernels of the other; that is
- * also what a call with 48 MiB of input or more does on a single device, ZULTRA_HIP_MEMORY_LANES=1 turns it off).
+ * An entry may repeat a device ("0,0": two contexts on device 0, the transfers of one shard next to the kernels of the other;
+ * without a list ZULTRA_HIP_MEMORY_LANES=n does the same on the one device, default 1, and 0 sends the call through the stream API).
  * Returns nDevices, or -1 when an entry is not a visible device (the list is then left empty). nDevices = 0 clears the list. */
 int zultra_set_devices(const int *pDevices, int nDevices);
 /* zultra_stream_end frees everything the stream owns through zfree, like the reference (libzultra.c:521-565) — except that the

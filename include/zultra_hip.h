@@ -96,9 +96,11 @@ void *zultra_hip_staging(zultra_hip_ctx_t *ctx, int which, size_t size);
 /* Bytes of input the context can hold per batch (max_blocks * max_block_size + 32768 of leading history). */
 size_t zultra_hip_data_capacity(const zultra_hip_ctx_t *ctx);
 
-/* Run stages 1-3 for a batch. `data` holds every window of the batch (host memory if data_on_device == 0, else a
- * device pointer valid on the context's device; it is then read in place, nothing is copied). Returns the number of
- * sub-blocks (>0) or a negative error. Results stay in the context until the next batch. */
+/* Run stages 1-3 for a batch. `data` holds every window of the batch: host memory if data_on_device == 0 (uploaded in one piece:
+ * best from pinned memory, e.g. zultra_hip_staging), a device pointer valid on the context's device if 1 (read in place, nothing
+ * is copied), pageable host memory if 2 (staged through the context's pinned buffer and uploaded run by run, each run's bytes
+ * under the kernels of the run before it). Returns the number of sub-blocks (>0) or a negative error. Results stay in the context
+ * until the next batch. */
 int zultra_hip_compress_blocks(zultra_hip_ctx_t *ctx, const void *data, size_t data_size, int data_on_device,
                                const zultra_hip_block_t *blocks, uint32_t nblocks);
 

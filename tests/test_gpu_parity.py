@@ -490,7 +490,7 @@ def test_api_state_machine_on_the_device(gpu, oracle):
                 assert gpu.memory_bound(n, flags, bs) == oracle.memory_bound(n, flags, bs)
 
 
-@pytest.mark.parametrize("how", ["env_0_0", "api_0_0_0", "default_two_lanes_large_input"])
+@pytest.mark.parametrize("how", ["env_0_0", "api_0_0_0", "one_lane_two_lanes_stream_api_large_input"])
 def test_memory_compress_over_device_lanes(gpu, oracle, monkeypatch, how):
     """zultra_memory_compress over several device contexts (libzultra.cpp: lanes; ZULTRA_HIP_DEVICES / zultra_set_devices): shards of
     max-blocks compressed side by side by one host thread and one context each — here all on device 0 — and stitched in stream
@@ -498,14 +498,16 @@ def test_memory_compress_over_device_lanes(gpu, oracle, monkeypatch, how):
     one-stream path (and of the oracle)."""
     import ctypes as C
     bs = 65536
-    if how == "default_two_lanes_large_input":
+    if how == "one_lane_two_lanes_stream_api_large_input":
         d = corpus.real_text(56 << 20)
         d[28 << 20:(28 << 20) + 40000] = corpus.noise(40000, 11)
-        monkeypatch.setenv("ZULTRA_HIP_MEMORY_LANES", "1")
+        monkeypatch.setenv("ZULTRA_HIP_MEMORY_LANES", "0")              # through the stream API, as the reference does
         want = gpu.memory_compress(d, 2, bs)
+        monkeypatch.setenv("ZULTRA_HIP_MEMORY_LANES", "2")              # two contexts on the device
+        got2 = gpu.memory_compress(d, 2, bs)
         monkeypatch.delenv("ZULTRA_HIP_MEMORY_LANES")
-        got = gpu.memory_compress(d, 2, bs)                             # 48 MiB and more: two contexts on the device by itself
-        assert got == want and zlib.decompress(got, 31) == d.tobytes()
+        got = gpu.memory_compress(d, 2, bs)                             # default: one lane, staged and uploaded run by run
+        assert got == want and got2 == want and zlib.decompress(got, 31) == d.tobytes()
         return
     d = corpus.text_like_fast(24 * bs + 1234, 77)
     lanes = 2 if how == "env_0_0" else 3

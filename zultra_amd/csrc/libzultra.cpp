@@ -916,11 +916,16 @@ static void mem_lane_thread(MemLanes *M, size_t lane) {
          hist = M->dict_size > HISTORY_SIZE ? (size_t)HISTORY_SIZE : (size_t)M->dict_size;
          hsrc = (const uint8_t *)M->dict + (M->dict_size - (int)hist);
       }
-      uint8_t *stage = (uint8_t *)zultra_hip_staging(c, 0, (size_t)HISTORY_SIZE + J.nblocks * M->bs);
+      // The job's windows are contiguous in the caller's buffer — unless its history is the preset dictionary — and are handed over
+      // as they are: the device layer stages and uploads them run by run (zultra_hip_compress_blocks, data_on_device == 2).
+      const bool in_place = hsrc + hist == M->in + first;
+      uint8_t *stage = in_place ? (uint8_t *)(M->in + first - hist) : (uint8_t *)zultra_hip_staging(c, 0, (size_t)HISTORY_SIZE + J.nblocks * M->bs);
       int ok = stage != NULL;
       if (ok) {
-         memcpy(stage, hsrc, hist);
-         staged_copy(stage + hist, M->in + first, last - first);
+         if (!in_place) {
+            memcpy(stage, hsrc, hist);
+            staged_copy(stage + hist, M->in + first, last - first);
+         }
          blocks.resize(J.nblocks);
          for (size_t b = 0; b < J.nblocks; b++) {
             const uint32_t prev = b == 0 ? (uint32_t)hist : (uint32_t)HISTORY_SIZE;
@@ -929,7 +934,7 @@ static void mem_lane_thread(MemLanes *M, size_t lane) {
             blocks[b].prev = prev;
             blocks[b].n = (uint32_t)(at + M->bs <= M->n_in ? M->bs : M->n_in - at);
          }
-         ok = zultra_hip_compress_blocks(c, stage, hist + (last - first), 0, blocks.data(), (uint32_t)J.nblocks) > 0;
+         ok = zultra_hip_compress_blocks(c, stage, hist + (last - first), in_place ? 2 : 0, blocks.data(), (uint32_t)J.nblocks) > 0;
       }
       {
          std::lock_guard<std::mutex> lk(M->m);
@@ -1061,16 +1066,17 @@ extern "C" size_t zultra_memory_compress_dict(const unsigned char *pIn, size_t n
    zultra_stream_t strm;
    memset(&strm, 0, sizeof(strm));
    const uint32_t bs = clamp_block(nMaxBlockSize);
-   // several devices asked for (or two contexts on one: ZULTRA_HIP_DEVICES=0,0), and at least two max-blocks per lane to give them
+   // The whole input is at hand: shards of max-blocks over the devices asked for (ZULTRA_HIP_DEVICES / zultra_set_devices; "0,0" = two
+   // contexts on device 0), at least two max-blocks per lane — or one lane on the one device, its batch staged and uploaded run by run.
+   // (ZULTRA_HIP_MEMORY_LANES=0: through the stream API instead, as the reference does, libzultra.c:601-619.)
    {
       std::vector<int> devs = zh_pick_devices();
-      if (devs.empty() && nIn >= (size_t)(48u << 20)) {
-         // one device, a large input: two contexts on it, so that one half's staging, upload and read-back run next to the other half's kernels
-         const char *e = getenv("ZULTRA_HIP_MEMORY_LANES");
-         const int lanes = e ? atoi(e) : 2;
-         for (int l = 0; l < lanes && lanes > 1; l++) devs.push_back(zh_pick_device());
-      }
-      if (devs.size() > 1 && pIn && nIn && (nIn + bs - 1) / bs >= 2 * devs.size()) return memory_compress_lanes(pIn, nIn, pOut, nOutCap, nFlags, bs, pDict, nDictSize, devs);
+      const char *e = getenv("ZULTRA_HIP_MEMORY_LANES");
+      const int lanes = e ? atoi(e) : 1;
+      if (devs.empty())
+         for (int l = 0; l < lanes; l++) devs.push_back(zh_pick_device());
+      while (devs.size() > 1 && (nIn + bs - 1) / bs < 2 * devs.size()) devs.pop_back();
+      if (!devs.empty() && pIn && nIn) return memory_compress_lanes(pIn, nIn, pOut, nOutCap, nFlags, bs, pDict, nDictSize, devs);
    }
    // the whole input is at hand: size the device batch to it
    uint64_t want = (nIn + bs - 1) / bs;

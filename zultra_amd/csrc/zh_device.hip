@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "../../include/zultra_hip.h"
@@ -899,7 +900,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          return -1;
       }
    }
-   if (!data_on_device && data_size > c->data_cap) {
+   if (data_on_device != 1 && data_size > c->data_cap) {
       snprintf(c->err, sizeof(c->err), "batch of %zu bytes exceeds the context's staging capacity %zu", data_size, c->data_cap);
       return -1;
    }
@@ -941,10 +942,22 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    hipStream_t st0 = c->lane_stream[0];
 
    ZH_CHECK(c, hipEventRecord(c->lane_ev[0][0], st0));
-   if (data_on_device)
+   // data_on_device == 2: pageable host memory, and the batch runs as staggered runs of max-blocks — every run's bytes are staged
+   // (host copy into the context's pinned buffer) and uploaded on the run's own stream just before its kernels are launched, so the
+   // copies of run k+1 go on under the kernels of run k: only the first run's are waited for. (Files mode runs from a captured graph:
+   // its input goes up in one piece like mode 0.)
+   uint8_t *per_run_stage = NULL;
+   if (data_on_device == 2 && !c->files_mode) {
+      per_run_stage = (uint8_t *)zultra_hip_staging(c, 0, data_size);
+      if (!per_run_stage) {
+         snprintf(c->err, sizeof(c->err), "no pinned staging for %zu bytes", data_size);
+         return -1;
+      }
+   }
+   if (data_on_device == 1)
       c->cur_data = (const uint8_t *)data;
    else {
-      ZH_CHECK(c, hipMemcpyAsync(c->d_data, data, data_size, hipMemcpyHostToDevice, st0));
+      if (!per_run_stage) ZH_CHECK(c, hipMemcpyAsync(c->d_data, data, data_size, hipMemcpyHostToDevice, st0));
       c->cur_data = c->d_data;
    }
    ZH_CHECK(c, hipMemcpyAsync(c->d_blocks, blocks, nblocks * sizeof(zh_block_t), hipMemcpyHostToDevice, st0));
@@ -964,6 +977,24 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          // stagger the runs by one stage: this run's wide matchfinder kernels start when the previous run reaches its
          // narrow ones (token chain, splitter), so narrow and wide kernels of different runs share the chip
          if (c->stagger_ev) ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k - 1][c->stagger_ev], 0));
+      }
+      if (per_run_stage) {
+         // this run's windows: from the first block's history to the last block's end (the 32 KiB in front of the run go up twice,
+         // with the run before it: the same bytes)
+         const uint64_t lo = blocks[b0].win_off, hi = blocks[b1 - 1].win_off + blocks[b1 - 1].prev + blocks[b1 - 1].n;
+         const uint8_t *src = (const uint8_t *)data + lo;
+         uint8_t *dst = per_run_stage + lo;
+         const size_t len = (size_t)(hi - lo), piece = 8u << 20;
+         if (len >= 2 * piece) {   // (a run of tens of MB: the host copy is split over a few threads)
+            const size_t nt = len / piece < 4 ? len / piece : 4;
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < nt; t++) th.emplace_back([=] { memcpy(dst + len * t / nt, src + len * t / nt, len * (t + 1) / nt - len * t / nt); });
+            memcpy(dst, src, len / nt);
+            for (auto &t : th) t.join();
+         }
+         else
+            memcpy(dst, src, len);
+         ZH_CHECK(c, hipMemcpyAsync(c->d_data + lo, dst, len, hipMemcpyHostToDevice, st));
       }
       ZH_CHECK(c, hipEventRecord(ev[1], st));
       const uint32_t sg0 = c->seg_base[b0], nsg = c->seg_base[b1] - sg0;   // this run's matchfinder segments
