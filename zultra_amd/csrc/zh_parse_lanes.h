@@ -481,6 +481,8 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
 
 // ticket == NULL: one workgroup (= one wave) per ZH_LP_TASKS tasks, the grid covers the task list. Otherwise the workgroups are
 // persistent and take task groups from *ticket (see zh_parse_tasks: next to zh_parse_chain the host launches a bounded grid).
+// (118 registers. Capped at 96 — a wave would then fit on a SIMD next to the four 104-register waves of another run's matchfinder
+// workgroup — the compiler spills 17 of them and the kernel takes 1.5 times as long: measured, not kept.)
 __global__ void __launch_bounds__(64)
 zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
