@@ -1,10 +1,26 @@
-mkdir -p gpurun_out/r4p; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q > gpurun_out/r4p/pytest.log 2>&1; echo "rc=$?" >> gpurun_out/r4p/pytest.log
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r4p/smoke.log 2>&1
-for c in 2 3 4 5 1; do python bench.py --config $c > gpurun_out/r4p/bench_c$c.json 2> gpurun_out/r4p/bench_c$c.err; echo "rc=$?" >> gpurun_out/r4p/bench_c$c.err; done
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r4p/bench_driver.json 2> gpurun_out/r4p/bench_driver.err
-rocprofv3 --kernel-trace --stats -d gpurun_out/r4p/kt -o kt --output-format csv -- python3 bench.py --config 2 --profile-run --no-synthetic --steps 2 --warmup 1 > gpurun_out/r4p/kt_bench.json 2> gpurun_out/r4p/kt_bench.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/r4p/fetch -o f -- python3 bench.py --config 2 --profile-run --no-synthetic --steps 1 --warmup 1 > gpurun_out/r4p/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/r4p/write -o w -- python3 bench.py --config 2 --profile-run --no-synthetic --steps 1 --warmup 1 > gpurun_out/r4p/write.log 2>&1
-for k in json pysrc mixed; do python tools/profile_encode.py 50000000 $k > gpurun_out/r4p/pe_$k.log 2>&1; done
-ls -R gpurun_out/r4p | head -50
+# Round-3 measurement run on the GPU box (gpurun -- 'bash tools/final_run.sh [quick]'): tests, bench lines, rocprofv3 kernel trace, PMC traffic per
+# configuration, SQ counters. Everything lands in gpurun_out/r03/; what is kept goes to profiles/ by hand.
+O=gpurun_out/r03; mkdir -p $O; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+if [ "$1" != "quick" ]; then
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; echo "rc=$?" >> $O/bench_driver.err
+python bench.py --config 1 > $O/bench_c1.json 2> $O/bench_c1.err
+fi
+prof() {  # config, extra bench args
+  c=$1; shift
+  rocprofv3 --kernel-trace --stats -d $O/kt_c$c -o kt --output-format csv -- python3 bench.py --config $c --profile-run --no-synthetic --steps 2 --warmup 1 "$@" > $O/kt_c$c.json 2> $O/kt_c$c.err
+  cp $(find $O/kt_c$c -name "*kernel_stats.csv" | head -1) $O/r03_kernel_stats_c$c.csv 2>/dev/null
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_c$c -o f -- python3 bench.py --config $c --profile-run --no-synthetic --steps 1 --warmup 1 "$@" > $O/fetch_c$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_c$c -o w -- python3 bench.py --config $c --profile-run --no-synthetic --steps 1 --warmup 1 "$@" > $O/write_c$c.log 2>&1
+  python tools/pmc_traffic.py $(find $O/fetch_c$c -name "*results.db" | head -1) $(find $O/write_c$c -name "*results.db" | head -1) 268435456 $O/r03_traffic_c$c.json $c "python3 bench.py --config $c --profile-run --no-synthetic --steps 1 --warmup 1 $*" > $O/traffic_c$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d $O/sq_c$c -o s -- python3 bench.py --config $c --profile-run --no-synthetic --steps 1 --warmup 1 "$@" > $O/sq_c$c.log 2>&1
+  python tools/rocpd_summary.py $(find $O/sq_c$c -name "*results.db" | head -1) $O/r03_sq_c$c > $O/sq_summary_c$c.log 2>&1
+  rm -rf $O/fetch_c$c $O/write_c$c $O/sq_c$c $O/kt_c$c
+}
+prof 2
+prof 3
+prof 5 --files 262144
+prof 4
+for k in json pysrc mixed; do python tools/profile_encode.py 50000000 $k > $O/pe_$k.log 2>&1; done
+ls -la $O | head -60

@@ -93,6 +93,7 @@ struct zultra_hip_ctx_s {
    uint64_t bar_stride, max_tasks;
    zh_sbstate_t *d_states;
    uint2 *d_taskmap;
+   uint2 *d_taskinfo;           // per task: its range and whether zh_list_huge listed it (zh_parse_chain.h)
    uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: per run [0..3] tasks, [40..43] / [4..7] / [12..15] very long / long / other tasks listed for zh_parse_chain, [8..11] their positions,
                                                      // [16 + 4 run + pass] its tickets, [32 + 4 run + pass] tickets of a persistent zh_parse_tasks
    uint32_t *h_ntasks;          // pinned mirror, read after the batch (zultra_hip_last_stats)
@@ -364,6 +365,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_bars);
    (void)hipFree(c->d_states);
    (void)hipFree(c->d_taskmap);
+   (void)hipFree(c->d_taskinfo);
    (void)hipFree(c->d_ntasks);
    (void)hipFree(c->d_hugelist);
    (void)hipFree(c->d_segtasks);
@@ -519,7 +521,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    // a cut task has at least 2 * ZH_CUT_WARM positions (the floor of ZULTRA_HIP_CUT_MIN) and lies inside one max-block
    c->seg_tasks_per_block = c->files_mode ? 1 : N / (2u * ZH_CUT_WARM) + 1;
    c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_WARM + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;   // a task of len positions has at most len / ZH_CUT_LEN + ZH_CUT_ROWS segments
-   if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) ||
+   if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) || zh_alloc(c, &c->d_taskinfo, c->max_tasks) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
        zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, 3 * c->max_tasks) ||
        zh_alloc(c, &c->d_segtasks, B * c->seg_tasks_per_block) || zh_alloc(c, &c->d_segwaves, B * c->seg_items_per_block) || zh_alloc(c, &c->d_segitems, B * c->seg_items_per_block) ||
@@ -649,7 +651,7 @@ extern "C" size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max
    bytes += B * slot_stride;                                         // payload slots
    bytes += (B * (N + 5 * (N / 65535 + 1) + 8) + 80);                // stitched stream
    bytes += subs * (sizeof(zh_sbstate_t) + sizeof(zh_work_t) + 2 * sizeof(zh_subblock_t) + sizeof(zh_stitch_item_t));
-   bytes += tasks * (sizeof(uint2) + 3 * 4 + 4 + ZH_NSYM * 4);       // task map, chain lists, bit counts, histograms
+   bytes += tasks * (2 * sizeof(uint2) + 3 * 4 + 4 + ZH_NSYM * 4);   // task map and ranges, chain lists, bit counts, histograms
    bytes += B * (S * (sizeof(zh_seg_t) + 8) + sizeof(zh_block_t) + cpb * 12 + (ZH_MAX_SPLITS + 1) * 4 + 6 * 4) + 8192;
    {
       // payload of the matchfinder's refining passes: per run (ZULTRA_HIP_STREAMS) and persistent workgroup (one per CU)
@@ -766,7 +768,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    // (inputs of a files batch are never cut into speculative segments: seg_min = all ones)
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
              (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu,
-             (uint32_t)ZH_CUT_LEN, cnt);
+             (uint32_t)ZH_CUT_LEN, cnt, c->d_taskinfo + t0);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
@@ -777,7 +779,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
       if (c->parse_lanes)
          ZH_LAUNCH(zh_parse_lanes, (task_grid + ZH_LP_TASKS - 1) / ZH_LP_TASKS, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL);
+                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0));
       else
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
                 (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
@@ -1091,7 +1093,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
       ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
       ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, c->cut_len, ntasks);
+                (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, c->cut_len, ntasks, c->d_taskinfo + t0);
       // Does this run have chains at all? With none (text without long repeats) zh_parse_tasks gets the whole chip; with chains it
       // runs as a bounded number of persistent waves per CU, so that the chain workgroups find room the moment they are launched.
       ZH_CHECK(c, hipMemcpyAsync(h_cnt, ntasks, ZH_CNT_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1133,10 +1135,10 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
             if (nchains || seg_wide || c->always_persistent)
                ZH_LAUNCH(zh_parse_lanes, min(lane_grid, c->num_cus * c->lane_waves), 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                          (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass,
-                         ntasks + ZH_CNT_TASK_TICKET + pass);
+                         ntasks + ZH_CNT_TASK_TICKET + pass, (const uint2 *)(c->d_taskinfo + t0));
             else
                ZH_LAUNCH(zh_parse_lanes, lane_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL);
+                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0));
          }
          else if (nchains || seg_wide || c->always_persistent)
             ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,

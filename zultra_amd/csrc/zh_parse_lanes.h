@@ -101,7 +101,7 @@ struct zh_lp_batch_t {
 __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_t g1, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
                                             const zh_match_t *__restrict__ match, uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride,
                                             const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
-                                            uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all, uint32_t *hist_part, int pass) {
+                                            uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all, uint32_t *hist_part, int pass, const uint2 *__restrict__ taskinfo) {
    const uint2 tm0 = taskmap[g0];
    const zh_work_t wk = work[tm0.x];
    const zh_sbstate_t *st = states + tm0.x;
@@ -149,14 +149,14 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    uint32_t nlongp = 0, nshortp = 0;
    uint64_t parsed = 0;   // bit j: task g0 + j is parsed here
    for (uint32_t gt = g0; gt < g1; gt++) {
-      const uint32_t j = taskmap[gt].y;
-      const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, j, wk.ntasks);
-      const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, j + 1, wk.ntasks);
+      // the task's range, and whether it has a barrier-free run of more than ZH_COOP_MIN positions: zh_list_huge has listed such a
+      // task for zh_parse_chain / zh_parse_segments — and left both here
+      const uint2 ti = taskinfo[gt];
+      if (ti.y >> 31) continue;
+      const uint32_t t0 = ti.x, t1 = ti.y;
       const uint32_t np = zh_task_pieces(ws.bnd, bar, prev, t0, t1, lane);
       zh_sync();
-      // a barrier-free run of more than ZH_COOP_MIN positions: zh_list_huge has listed the task for zh_parse_chain / zh_parse_segments
-      const bool huge = zh_task_is_huge(ws.bnd, np, lane);
-      if (!huge && nlongp + nshortp + np <= ZH_LP_MAXP) {
+      if (nlongp + nshortp + np <= ZH_LP_MAXP) {
          const uint32_t lo = lane < np ? ws.bnd[lane] : 0u, hi = lane < np ? ws.bnd[lane + 1] : 0u;
          const bool is_l = hi - lo >= ZH_LP_LONG, is_s = hi > lo && !is_l;   // (empty pieces are dropped)
          const uint64_t ml = zh_ballot(is_l), ms = zh_ballot(is_s);
@@ -464,8 +464,8 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
       zh_sync();
       for (uint32_t gt = g0; gt < g1; gt++) {
          if (!((parsed >> (gt - g0)) & 1ull)) continue;
-         const uint32_t jt = taskmap[gt].y;
-         zh_walk_histogram_wave(ws.hist, win, prev, zh_task_boundary(bar, prev, wk.start, sb_end, jt, wk.ntasks), zh_task_boundary(bar, prev, wk.start, sb_end, jt + 1, wk.ntasks), best);
+         const uint2 ti = taskinfo[gt];
+         zh_walk_histogram_wave(ws.hist, win, prev, ti.x, ti.y, best);
       }
       zh_sync();
       bool first = true;
@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(64)
 zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
                const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all,
-               uint32_t *hist_part, int pass, uint32_t *ticket) {
+               uint32_t *hist_part, int pass, uint32_t *ticket, const uint2 *__restrict__ taskinfo) {
    __shared__ zh_lp_ws_t ws;
    const uint32_t ntasks = cnt[ZH_CNT_TASKS];
    for (;;) {
@@ -504,7 +504,7 @@ zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          const uint32_t sb = taskmap[g].x;
          uint32_t ge = g + 1;
          while (ge < g1 && taskmap[ge].x == sb) ge++;
-         zh_lp_group(ws, g, ge, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, cost_all, hist_part, pass);
+         zh_lp_group(ws, g, ge, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, cost_all, hist_part, pass, taskinfo);
          g = ge;
       }
       if (!ticket) return;
