@@ -787,9 +787,9 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
       ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass);
    }
    ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt,
-             (const zh_sbstate_t *)states, best, c->best_stride, task_bits);
+             (const zh_sbstate_t *)states, best, c->best_stride, task_bits, (const uint2 *)(c->d_taskinfo + t0));
    ZH_LAUNCH(zh_emit_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt,
-             (const zh_sbstate_t *)states, (const uint32_t *)best, c->best_stride, (const uint32_t *)task_bits, payload, c->d_results + b0);
+             (const zh_sbstate_t *)states, (const uint32_t *)best, c->best_stride, (const uint32_t *)task_bits, payload, c->d_results + b0, (const uint2 *)(c->d_taskinfo + t0));
    ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
    return 0;
 }
@@ -1154,11 +1154,11 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));
       }
       ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, task_bits);
+                (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, task_bits, (const uint2 *)(c->d_taskinfo + t0));
       ZH_CHECK(c, hipEventRecord(ev[14], st));
       ZH_LAUNCH(zh_emit_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
                 (const uint32_t *)ntasks, (const zh_sbstate_t *)states, (const uint32_t *)best, c->best_stride, (const uint32_t *)task_bits, payload,
-                c->d_results + s0);
+                c->d_results + s0, (const uint2 *)(c->d_taskinfo + t0));
       ZH_CHECK(c, hipEventRecord(ev[15], st));
       // per-max-block CRC-32 (linear part) for the gzip footer
       ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);

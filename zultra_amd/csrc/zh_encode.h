@@ -333,7 +333,7 @@ struct zh_task_ws_t {
 __global__ void __launch_bounds__(64)
 zh_post_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride,
               const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total,
-              const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *task_bits) {
+              const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *task_bits, const uint2 *__restrict__ taskinfo) {
    __shared__ zh_task_ws_t ws;
    const uint32_t gt = blockIdx.x;
    if (gt >= *ntasks_total) return;
@@ -347,9 +347,8 @@ zh_post_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ b
    const uint64_t *bar = bars + (uint64_t)wk.block * bar_stride;
    uint32_t *best = best_all + (uint64_t)wk.block * best_stride;
    const uint32_t lane = zh_lane();
-   const uint32_t sb_end = wk.start + wk.size;
-   const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y, wk.ntasks);
-   const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
+   const uint32_t t0 = taskinfo[gt].x, t1 = taskinfo[gt].y & 0x7fffffffu;   // the task's range (zh_list_huge)
+   (void)bar;
    const bool dynamic = st->is_dynamic != 0;
 
    for (uint32_t s = lane; s < ZH_NLIT; s += 64) {
@@ -476,7 +475,7 @@ __global__ void __launch_bounds__(64)
 zh_emit_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride,
               const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total,
               const zh_sbstate_t *__restrict__ states, const uint32_t *__restrict__ best_all, uint64_t best_stride,
-              const uint32_t *__restrict__ task_bits, uint8_t *payload, zh_subblock_t *results) {
+              const uint32_t *__restrict__ task_bits, uint8_t *payload, zh_subblock_t *results, const uint2 *__restrict__ taskinfo) {
    __shared__ zh_task_ws_t ws;
    const uint32_t gt = blockIdx.x;
    if (gt >= *ntasks_total) return;
@@ -496,9 +495,8 @@ zh_emit_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ b
       const uint32_t *best = best_all + (uint64_t)wk.block * best_stride;
       uint32_t *out = (uint32_t *)(payload + wk.out_off);
       const uint32_t cap_bits = wk.out_cap * 8;
-      const uint32_t sb_end = wk.start + wk.size;
-      const uint32_t t0 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y, wk.ntasks);
-      const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
+      const uint32_t t0 = taskinfo[gt].x, t1 = taskinfo[gt].y & 0x7fffffffu;   // the task's range (zh_list_huge)
+      (void)bar;
 
       for (uint32_t s = lane; s < ZH_NLIT; s += 64) {
          ws.lit_len[s] = st->lit_len[s];
