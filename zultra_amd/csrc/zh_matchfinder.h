@@ -35,7 +35,9 @@
 #include <zh_platform.h>
 #include "zh_common.h"
 
+#ifndef ZH_MF_THREADS
 #define ZH_MF_THREADS 1024
+#endif
 #define ZH_MF_WAVES (ZH_MF_THREADS / 64)
 #ifndef ZH_MF_UNROLL
 #define ZH_MF_UNROLL 4u              // 64-element steps of a sort pass whose loads are issued together
