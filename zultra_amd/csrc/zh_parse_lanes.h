@@ -72,8 +72,8 @@ struct alignas(16) zh_lp_ws_t {
          uint32_t stage1[ZH_LP_C][4][4];        //            slots 4..7,
          uint16_t stagef[ZH_LP_C][4][8];        //            per slot stored with length >= 40 the cost behind it,
          uint32_t stageb[ZH_LP_C][4];           //            the entries' bytes
-         uint32_t outp[ZH_LP_C][4];             // the batch's parse entries ...
-         uint32_t outc[ZH_LP_C][4];             // ... and costs
+         uint32_t outp[2][ZH_LP_C][4];          // the parse entries of two batches (by batch parity) ...
+         uint32_t outc[2][ZH_LP_C][4];          // ... and their costs
       };
       uint32_t hist[ZH_NSYM];                   // after the parse: histogram of the group
    };
@@ -263,7 +263,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
 
    // what an entry carries from stage A to stage B, and from stage B to stage C
    struct zh_lp_a_t {
-      uint32_t e0, e1, mlen0, mlen1, dp0, dp1, lit, lc0, lc1, rg0, rg1, j;
+      uint32_t e0, e1, mlen0, mlen1, dp0, dp1, lit, lc0, lc1, rg0, rg1, j;   // (j: entry | batch parity << 2)
       bool act, fresh;
    };
    struct zh_lp_b_t {
@@ -282,6 +282,8 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    ZH_LP_FETCH(b2, a2, y2);
    ZH_LP_FETCH_HI();
    uint32_t drain = 0;   // the pipeline runs two entries behind the stream
+   uint32_t it = 0;      // batches so far; the parse entries of a batch are buffered under its parity
+   zh_lp_batch_t pend = {0, 0, 0, 0, false};   // the batch whose entries wait for the next one's: two batches' stores go out back to back
    bool cur_hi = false, old_hi = false;   // wave-uniform: some entry of the batch cur / old has a second plane
    for (;;) {
       // ---- batch b1 enters stage A: into LDS, where every lane of the quad finds its slot of every entry ---------------------------
@@ -325,7 +327,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
          zh_lp_a_t na;
          na.act = j - cur.off < cur.n;
          na.fresh = cur.fresh && j == cur.off;
-         na.j = j;
+         na.j = j | ((it & 1u) << 2);
          const uint32_t apos = na.act ? cur.p0 - (j - cur.off) : wk.start;
          const uint32_t aroom = sb_end - apos;   // end clamp (blockdeflate.c:283-284); a no-op away from the sub-block end
          na.e0 = ws.stage0[piece][j][q];
@@ -349,17 +351,30 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
             const uint32_t we = own1 ? eb.e1 : eb.e0, wm = own1 ? eb.mlen1 : eb.mlen0;
             const uint32_t pick = take ? ((we & 0xffffu) >= ZH_LEAVE_ALONE ? wm : 39u - (bestkey & 63u)) | (we & 0xffff0000u) : 0u;
             if (own0 || own1 || (!take && q == 0)) {
-               ws.outp[piece][eb.j] = pick;
-               ws.outc[piece][eb.j] = c;
+               ws.outp[eb.j >> 2][piece][eb.j & 3u] = pick;
+               ws.outc[eb.j >> 2][piece][eb.j & 3u] = c;
             }
             c1 = c;
             cin3 = cin2;
             cin2 = cin1;
             cin1 = c << 9;
             zh_lockstep_sync();
-            if (j == 1 && q - old.off < old.n) {   // the batch before this one is through
-               best[old.p0 - (q - old.off) - prev] = ws.outp[piece][q];
-               costs[old.p0 - (q - old.off) - prev] = (uint16_t)ws.outc[piece][q];
+            if (j == 1) {
+               // The batch before this one is through. Its four parse entries are 16 bytes, its costs 8: stored batch by batch they left
+               // the L2 as half-written 32-byte sectors, 19 bytes of HBM writes per position where 6 are stored (rocprofv3 WRITE_SIZE).
+               // Every second batch, the entries of two batches go out back to back instead: neighbours in memory, merged in the L2.
+               if (it & 1u) {
+                  if (q - pend.off < pend.n) {
+                     best[pend.p0 - (q - pend.off) - prev] = ws.outp[1][piece][q];
+                     costs[pend.p0 - (q - pend.off) - prev] = (uint16_t)ws.outc[1][piece][q];
+                  }
+                  if (q - old.off < old.n) {
+                     best[old.p0 - (q - old.off) - prev] = ws.outp[0][piece][q];
+                     costs[old.p0 - (q - old.off) - prev] = (uint16_t)ws.outc[0][piece][q];
+                  }
+               }
+               else
+                  pend = old;
             }
          }
 
@@ -442,6 +457,14 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
       // the window moves up by four: the next batch's four entries find it at w[4 .. 13] again
 #pragma unroll
       for (uint32_t k = 13; k >= 4; k--) w[k] = w[k - 4];
+      it++;
+   }
+   if (it & 1u) {   // (the last round was an even one: its `old` batch is still waiting)
+      zh_lockstep_sync();
+      if (q - pend.off < pend.n) {
+         best[pend.p0 - (q - pend.off) - prev] = ws.outp[1][piece][q];
+         costs[pend.p0 - (q - pend.off) - prev] = (uint16_t)ws.outc[1][piece][q];
+      }
    }
 #undef ZH_LP_FETCH
 #undef ZH_LP_FETCH_HI
