@@ -92,11 +92,20 @@ __device__ __forceinline__ uint32_t zh_mf_slice(uint32_t M) { return (((M + ZH_M
 // MODE 8/9: the elements are indices into the run table (aux_rs = run starts, aux_rl = run lengths): digit = the byte that follows the
 // run (0 where the run reaches the window end) / the run's byte. MODE 8 with src == nullptr reads the identity permutation.
 // PAY: the elements carry a payload through the pass — 1: one word (psrc -> pdst), 2: two words (psrc, qsrc -> the pairs pdst2).
-template <int MODE, bool HAVE = false, int NEXT = -1, int PAY = 0>
+// PREV = K (3, 4, 5): the pass also takes, for every element of its INPUT order — the K-gram order, classes contiguous and ascending in
+// position — the distance to the nearest earlier position sharing K bytes: the element before it, when that one is in the same
+// class. Recorded as distance - 1 in 16 bits (0xffff: none within ZH_MAX_DIST) and sent along as payload: K = 3: d3 | none << 16 ->
+// pdst; K = 4: d3 (read from psrc) | d4 << 16 -> pdst; K = 5: (psrc value, d5) -> pdst2. So the three distances of a position arrive
+// next to its entry of the 6-gram order, where zh_mf_frontier reads them with the entries, coalesced. (Round 1 scattered them into
+// a table indexed by position: 8.1 GB of HBM writes per 50 MB. Round 2 took them in a pass of their own over each order, zh_mf_prev_level:
+// one more read of the order and one more write of the payload per level — 0.7 of this kernel's 4 ms per 50 MB and a quarter of its
+// HBM traffic.) The last five window positions drop out of the orders before they reach the 6-gram order: theirs go to tail[pos]
+// (the frontier's position-indexed table: entries from W - 5 on are free, the 6-gram order has at most W - 5 entries).
+template <int MODE, bool HAVE = false, int NEXT = -1, int PAY = 0, int PREV = 0>
 __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, uint32_t M, const uint32_t *src, uint32_t *dst, uint32_t *hist,
                                        uint32_t *wave_tot, uint32_t W = 0, uint32_t *hist_next = nullptr, uint32_t M_next = 0,
                                        const uint32_t *aux_rs = nullptr, const uint32_t *aux_rl = nullptr, const uint32_t *psrc = nullptr,
-                                       uint32_t *pdst = nullptr, const uint32_t *qsrc = nullptr, uint2 *pdst2 = nullptr) {
+                                       uint32_t *pdst = nullptr, const uint32_t *qsrc = nullptr, uint2 *pdst2 = nullptr, uint2 *tail = nullptr) {
    const uint32_t tid = threadIdx.x;
    const uint32_t lane = tid & 63, wave = tid >> 6;
    const uint32_t seg = zh_mf_slice(M);
@@ -177,6 +186,8 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
    __syncthreads();
 
    // stable scatter: each wave walks its slice in order, 64 elements per step; the fetches of four steps are issued together
+   uint32_t e_before = ZH_MF_NONE;   // (PREV) wave-uniform: the element before this step's first one
+   if (PREV && lo > 0 && lo < hi) e_before = src[lo - 1];
    for (uint32_t base4 = lo; base4 < hi; base4 += 64 * ZH_MF_UNROLL) {
       uint32_t e4[ZH_MF_UNROLL], d4[ZH_MF_UNROLL], p4[ZH_MF_UNROLL], q4[ZH_MF_UNROLL];
 #pragma unroll
@@ -187,8 +198,39 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
          d4[u] = 0xffffffffu;
          if (idx < hi) {
             ZH_MF_FETCH(idx, e4[u], d4[u]);
-            if (PAY >= 1) p4[u] = psrc[idx];
-            if (PAY >= 2) q4[u] = qsrc[idx];
+            if (PAY >= 1 && PREV != 3) p4[u] = psrc[idx];
+            if (PAY >= 2 && !PREV) q4[u] = qsrc[idx];
+         }
+      }
+      if (PREV) {
+#pragma unroll
+         for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {
+            const uint32_t idx = base4 + u * 64 + lane;
+            const uint32_t pos = e4[u];
+            const uint32_t q = zh_wave_shr1(pos, e_before);   // the element before this one in the order
+            e_before = zh_readlane(pos, 63);
+            if (idx < hi) {
+               bool same = q != ZH_MF_NONE;
+               if (same) {
+                  if (PREV == 3)
+                     same = zh_ld24(gwin + q) == zh_ld24(gwin + pos);
+                  else
+                     same = zh_ld32(gwin + q) == zh_ld32(gwin + pos) && (PREV == 4 || gwin[q + 4] == gwin[pos + 4]);
+               }
+               const uint32_t dist = pos - q;
+               const uint32_t dd = (same && dist <= ZH_MAX_DIST) ? dist - 1u : 0xffffu;
+               if (PREV == 3) p4[u] = dd | 0xffff0000u;
+               if (PREV == 4) p4[u] = (p4[u] & 0xffffu) | (dd << 16);
+               if (PREV == 5) q4[u] = dd;
+               if (pos + 5u >= W) {
+                  if (PREV == 3)
+                     tail[pos] = make_uint2(p4[u], 0xffffu);
+                  else if (PREV == 4)
+                     tail[pos].x = p4[u];
+                  else
+                     tail[pos].y = dd;
+               }
+            }
          }
       }
 #pragma unroll
@@ -367,7 +409,7 @@ __device__ inline void zh_mf_prev_level(const uint32_t *__restrict__ X, uint32_t
 // `win` is read linearly (global memory); `gwin` is the copy used for scattered reads (LDS when the window fits)
 __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin, uint32_t W, uint32_t Qn, uint32_t first_needed, uint32_t *A, uint32_t *B,
                                         uint2 *prev, uint32_t *pay, uint64_t pay_stride, uint32_t *runs, uint32_t *hist, uint32_t *wave_tot, int stop) {
-   uint32_t *Pa = pay, *Pb = pay + pay_stride, *Pq = pay + 2 * pay_stride;   // payload ping, pong, and the 5-gram distances
+   uint32_t *Pa = pay, *Pb = pay + pay_stride;   // payload ping, pong
    const uint32_t tid = threadIdx.x;
    // W = window bytes, Qn = positions that are candidates or get rows (the rest of the window is look-ahead)
    const uint32_t M3 = min(Qn, W >= 3 ? W - 2 : 0u);   // positions that start a trigram
@@ -381,20 +423,17 @@ __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin,
    zh_mf_sort_pass<1, true, 2>(win, gwin, M3, A, B, hist2, wave_tot, W, hist, M3);
    zh_mf_sort_pass<2, true, 5>(win, gwin, M3, B, A, hist, wave_tot, W, hist2, M3);
    if (stop == 3) return;
-   zh_mf_prev_level<3>(A, M3, gwin, W, Pa, prev);
    if (stop == 4) return;
 
    // ---- 4-, 5- and 6-gram classes: one more stable pass each over the previous order ------------------------------
    // prev4 / prev5 (nearest earlier position sharing 4 / 5 bytes) give the records of length 4 and 5 directly; only
    // matches of 6 and more are found by walking a class, and 6-gram classes are several times smaller than 4-gram
-   // classes (on text the walk shrinks 2.3x, on source code 1.5x).
+   // classes (on text the walk shrinks 2.3x, on source code 1.5x). Each pass takes the distances of its input order as it reads it.
    const uint32_t M5 = min(Qn, W >= 5 ? W - 4 : 0u), M6 = min(Qn, W >= 6 ? W - 5 : 0u);
-   zh_mf_sort_pass<5, true, 6, 1>(win, gwin, M3, A, B, hist2, wave_tot, W, hist, M4, nullptr, nullptr, Pa, Pb);   // B: 4-gram order, M4 entries
-   zh_mf_prev_level<4>(B, M4, gwin, W, Pb, prev);
-   zh_mf_sort_pass<6, true, 7, 1>(win, gwin, M4, B, A, hist, wave_tot, W, hist2, M5, nullptr, nullptr, Pb, Pa);   // A: 5-gram order, M5 entries
-   zh_mf_prev_level<5>(A, M5, gwin, W, Pq, prev);
+   zh_mf_sort_pass<5, true, 6, 1, 3>(win, gwin, M3, A, B, hist2, wave_tot, W, hist, M4, nullptr, nullptr, nullptr, Pb, nullptr, nullptr, prev);   // B: 4-gram order, M4 entries; Pb: d3
+   zh_mf_sort_pass<6, true, 7, 1, 4>(win, gwin, M4, B, A, hist, wave_tot, W, hist2, M5, nullptr, nullptr, Pb, Pa, nullptr, nullptr, prev);      // A: 5-gram order, M5 entries; Pa: d3 | d4 << 16
    // B: 6-gram order, M6 entries; prev[idx] = the distances of the position at B[idx]
-   zh_mf_sort_pass<7, true, -1, 2>(win, gwin, M5, A, B, hist2, wave_tot, W, nullptr, 0, nullptr, nullptr, Pa, nullptr, Pq, prev);
+   zh_mf_sort_pass<7, true, -1, 2, 5>(win, gwin, M5, A, B, hist2, wave_tot, W, nullptr, 0, nullptr, nullptr, Pa, nullptr, nullptr, prev, prev);
    if (stop == 5) return;
    {
       const uint32_t *__restrict__ Br = B;
