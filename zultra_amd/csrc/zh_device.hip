@@ -78,7 +78,7 @@ struct zultra_hip_ctx_s {
    std::vector<uint32_t> seg_base;
    zh_match_t *d_match;
    uint32_t *d_pay;             // zh_mf_group: 3 x sort_stride words per persistent workgroup (payload of the refining sort passes)
-   uint32_t *d_longest;         // per block position: slot 0 of its match row (tok_stride per max-block)
+   uint32_t *d_longest;         // (round 2: a copy of slot 0 of every match row; no longer written — its readers take the rows)
    uint32_t *d_tok_pos;
    uint16_t *d_tok_info;
    uint32_t *d_ntok, *d_split_tok, *d_split_cnt, *d_sub_base;
@@ -555,7 +555,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
        zh_alloc(c, &c->d_vecs, B * c->seg_items_per_block * 2 * ZH_VEC) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
-       zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) || zh_alloc(c, &c->d_longest, B * c->tok_stride) ||
+       zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) || zh_alloc(c, &c->d_longest, 64) ||
        zh_alloc(c, &c->d_pay, (size_t)c->nlanes * min((uint64_t)c->total_cus, B * c->segs_per_block) * 3 * c->sort_stride) ||   // (the runs' kernels may overlap)
        zh_alloc(c, &c->d_tok_pos, B * c->tok_stride) || zh_alloc(c, &c->d_tok_info, B * c->tok_stride) ||
        zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_chunkmax, B * c->chunks_per_block) || zh_alloc(c, &c->d_spanstart, B * c->chunks_per_block) ||
@@ -673,7 +673,7 @@ extern "C" size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max
    uint64_t bytes = 0;
    bytes += W + (B - 1) * N + 64;                                    // d_data
    bytes += B * S * sort_stride * (4 + 4 + 8) + B * S * run_stride * 4;   // sort ping-pong, prev records, run tables
-   bytes += B * N * ZH_NMATCH * sizeof(zh_match_t) + B * tok_stride * (4 + 4 + 2 + 4 + 2);   // rows, longest, token chain, parse, costs
+   bytes += B * N * ZH_NMATCH * sizeof(zh_match_t) + B * tok_stride * (4 + 2 + 4 + 2);   // rows, token chain, parse, costs
    bytes += B * (tok_stride / 64) * 8;                               // barrier bitmap
    bytes += B * slot_stride;                                         // payload slots
    bytes += (B * (N + 5 * (N / 65535 + 1) + 8) + 80);                // stitched stream
@@ -733,14 +733,14 @@ static int zh_build_segments(zultra_hip_ctx_t *c, const zultra_hip_block_t *bloc
 // barrier bitmap and greedy token chain of `nb` max-blocks starting at batch block b0, in chunks (zh_split.h)
 static int zh_enqueue_tokenize(zultra_hip_ctx_t *c, hipStream_t st, const zh_block_t *blk, uint32_t b0, uint32_t nb) {
    const uint32_t cpb = c->chunks_per_block;
-   const uint32_t *match = c->d_longest + (uint64_t)b0 * c->tok_stride;
+   const uint32_t *match = (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride);   // slot 0 of a position's row = its longest match
    uint64_t *bars = c->d_bars + (uint64_t)b0 * c->bar_stride;
    uint32_t *tp = c->d_tok_pos + (uint64_t)b0 * c->tok_stride;
    uint16_t *ti = c->d_tok_info + (uint64_t)b0 * c->tok_stride;
    uint32_t *cmax = c->d_chunkmax + (uint64_t)b0 * cpb, *sstart = c->d_spanstart + (uint64_t)b0 * cpb, *scnt = c->d_spancnt + (uint64_t)b0 * cpb;
-   ZH_LAUNCH(zh_barriers, nb * cpb, 64, st, blk, match, c->tok_stride, bars, c->bar_stride, cmax, cpb);
+   ZH_LAUNCH(zh_barriers, nb * cpb, 64, st, blk, match, c->match_stride, bars, c->bar_stride, cmax, cpb);
    if (cpb > 1) ZH_LAUNCH(zh_barriers_fix, (nb + 63) / 64, 64, st, blk, nb, bars, c->bar_stride, (const uint32_t *)cmax, cpb);
-   ZH_LAUNCH(zh_tokenize_spans, nb * cpb, 64, st, c->cur_data, blk, match, c->tok_stride, tp, ti, c->tok_stride, (const uint64_t *)bars, c->bar_stride, sstart, scnt,
+   ZH_LAUNCH(zh_tokenize_spans, nb * cpb, 64, st, c->cur_data, blk, match, c->match_stride, tp, ti, c->tok_stride, (const uint64_t *)bars, c->bar_stride, sstart, scnt,
              cpb);
    ZH_LAUNCH(zh_tokens_compact, nb, ZH_COMPACT_THREADS, st, blk, tp, ti, c->tok_stride, (const uint32_t *)sstart, (const uint32_t *)scnt, cpb, c->d_ntok + b0);
    return 0;
@@ -794,7 +794,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
    // (inputs of a files batch are never cut into speculative segments: seg_min = all ones)
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-             (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu,
+             (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu,
              (uint32_t)ZH_CUT_LEN, cnt, c->d_taskinfo + t0);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
@@ -1120,7 +1120,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
       ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
       ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)(c->d_longest + (uint64_t)b0 * c->tok_stride), c->tok_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, c->cut_len, ntasks, c->d_taskinfo + t0);
+                (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, c->cut_len, ntasks, c->d_taskinfo + t0);
       // Does this run have chains at all? With none (text without long repeats) zh_parse_tasks gets the whole chip; with chains it
       // runs as a bounded number of persistent waves per CU, so that the chain workgroups find room the moment they are launched.
       ZH_CHECK(c, hipMemcpyAsync(h_cnt, ntasks, ZH_CNT_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

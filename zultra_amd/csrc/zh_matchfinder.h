@@ -641,11 +641,13 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
    const uint32_t *S = sorted + (uint64_t)seg_id * sort_stride;
    const uint2 *prevs = prev_all + (uint64_t)seg_id * sort_stride;   // per entry of the 6-gram order: x = distance - 1 to the previous occurrence of the trigram | of the 4-gram << 16, y = of the 5-gram (0xffff: none)
    const uint32_t *runs = runs_all + (uint64_t)seg_id * run_stride;
-   // row r = segment position prev + r: slots 0..3 in rows_lo[r], slots 4..7 in rows_hi[r] (zh_common.h); its longest match again in
-   // longest[r], for the kernels that only follow the greedy chain (zh_split.h)
+   // row r = segment position prev + r: slots 0..3 in rows_lo[r], slots 4..7 in rows_hi[r] (zh_common.h). (Round 2 stored the longest
+   // match once more in a 4-byte array for the kernels that only follow the greedy chain; a scattered 4-byte store leaves the L2 as a
+   // 64-byte sector, 16 x the bytes: those kernels now read slot 0 of the rows, zh_split.h)
    uint4 *rows_lo = (uint4 *)(match + (uint64_t)blk.block * match_stride) + blk.row_off;
    uint4 *rows_hi = rows_lo + ZH_ROW_HI_OFF(match_stride);
-   uint32_t *longest = longest_all + (uint64_t)blk.block * longest_stride + blk.row_off;
+   (void)longest_all;
+   (void)longest_stride;
    const uint8_t *win = gwin;
 
    if (LDS_WIN) {
@@ -686,7 +688,6 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
          a.z = n > 2 ? m[n - 3] : 0u;
          a.w = 0;
          rows_lo[i - prev] = a;
-         longest[i - prev] = a.x;
       }
    }
 
@@ -1004,7 +1005,6 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
          b2.x = m[4]; b2.y = m[5]; b2.z = m[6]; b2.w = m[7];
          rows_lo[i - prev] = a;
          if (nm >= 4) rows_hi[i - prev] = b2;   // readers fetch it whenever slot 3 holds a match
-         longest[i - prev] = a.x;
       }
       ZH_MF_LAP(4);
    }

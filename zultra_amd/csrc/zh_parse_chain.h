@@ -445,7 +445,7 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
       // periodic? (a 258-byte match at most positions: the costs 258 apart copy each other, a speculative start never converges)
       const uint32_t *lg = longest + (uint64_t)wk.block * longest_stride;
       uint32_t full = 0;
-      for (uint32_t p = t0 + lane; p < t1; p += 64) full += (lg[p - prev] & 0xffffu) >= ZH_MAX_MATCH ? 1u : 0u;
+      for (uint32_t p = t0 + lane; p < t1; p += 64) full += (lg[4u * (p - prev)] & 0xffffu) >= ZH_MAX_MATCH ? 1u : 0u;   // (slot 0 of the position's row)
       full = zh_wave_sum(full);
       if (2u * full <= len) {
          // K segments of S positions, segment 0 the short one: as many as fill whole waves of zh_parse_segments (ZH_CUT_ROWS each)

@@ -84,7 +84,7 @@ zh_barriers(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ 
    const uint32_t n = blk.n, lo = c * ZH_TOK_CHUNK;
    if (lo >= n) return;
    const uint32_t hi = min(n, lo + ZH_TOK_CHUNK);
-   const uint32_t *rows = longest + (uint64_t)b * longest_stride;   // per position: its longest match (slot 0 of its row, matchfinder.c:221)
+   const uint32_t *rows = longest + (uint64_t)b * longest_stride;   // per position r its longest match: slot 0 of its row, rows[4 r] (matchfinder.c:221; first plane, zh_common.h)
    uint64_t *bar = bars + (uint64_t)b * bar_stride;
    const uint32_t lane = zh_lane();
    uint32_t reach_before = 0;   // running maximum over the chunk's earlier tiles
@@ -92,7 +92,7 @@ zh_barriers(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ 
 #pragma unroll
    for (uint32_t u = 0; u < 4; u++) {
       const uint32_t r = lo + u * 64 + lane;
-      pm[u] = r < hi ? rows[r] : 0u;
+      pm[u] = r < hi ? rows[4u * r] : 0u;
    }
    for (uint32_t base4 = lo; base4 < hi; base4 += 256) {
 #pragma unroll
@@ -101,7 +101,7 @@ zh_barriers(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ 
          if (base >= hi) break;
          const uint32_t r = base + lane;
          const uint32_t len = pm[u] & 0xffffu;
-         pm[u] = r + 256 < hi ? rows[r + 256] : 0u;
+         pm[u] = r + 256 < hi ? rows[4u * (r + 256)] : 0u;
          const uint32_t incl = zh_wave_incl_max(r < hi ? r + max(len, 1u) : 0u);
          const uint32_t up = zh_shfl(incl, (int)((lane - 1) & 63));
          const uint32_t excl = lane ? max(reach_before, up) : reach_before;
@@ -161,7 +161,7 @@ zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict
       pm[u] = 0;
       pb[u] = 0;
       if (r < s1) {
-         pm[u] = rows[r];
+         pm[u] = rows[4u * r];
          pb[u] = win[blk.prev + r];
       }
    }
@@ -176,7 +176,7 @@ zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict
          pm[u] = 0;
          pb[u] = 0;
          if (r + 256 < s1) {
-            pm[u] = rows[r + 256];
+            pm[u] = rows[4u * (r + 256)];
             pb[u] = win[blk.prev + r + 256];
          }
          const uint32_t len = m0 & 0xffffu;
