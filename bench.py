@@ -536,12 +536,17 @@ def run_stream_config(args, env, prep):
             line["size_vs_zlib9_sample_bytes"] = len(zs)
         line["zlib9_MBps_1core"] = round(len(zs) / (time.perf_counter() - t0) / 1e6, 1)
         # the drop-in entry on a host buffer: H2D, kernels, stitch, D2H, frame (PCIe-inclusive; never `value`)
-        best, out = None, None
-        for _ in range(1 if args.leg else 2):
+        # (into a buffer the caller owns and has touched, as lzbench and tool/zultra.c -cbench do: the call itself, not Python's allocation
+        # and copy of the result)
+        obuf = np.zeros(L.memory_bound(len(shard), flags, bs), dtype=np.uint8)
+        best, nout = None, None
+        for _ in range(2 if args.leg else 3):
             t0 = time.perf_counter()
-            out = L.memory_compress(shard, flags, bs)
+            nout = L.memory_compress_into(shard, flags, bs, obuf)
             dtm = time.perf_counter() - t0
             best = dtm if best is None else min(best, dtm)
+        out = obuf[:nout].tobytes() if nout is not None else None
+        del obuf
         line["end_to_end_MBps"] = round(len(shard) / best / 1e6, 1)
         same = out == framed
         line["memory_compress_equals_sharded_pipeline"] = bool(same)

@@ -175,6 +175,12 @@ class Lib:
             return None
         return out[:r].tobytes()
 
+    def memory_compress_into(self, data, flags, max_block, out):
+        """zultra_memory_compress into a caller-owned uint8 array (no allocation, no copy of the result): the number of bytes, or None."""
+        data = _as_u8(data)
+        r = self.L.zultra_memory_compress(data.ctypes.data, len(data), out.ctypes.data, len(out), flags, max_block)
+        return None if r == _SIZE_MAX else int(r)
+
     def checksum(self, data, flags, start=None):
         data = _as_u8(data)
         if start is None:
