@@ -96,7 +96,7 @@ def test_memory_compress_over_two_device_lanes(emu, oracle, monkeypatch):
     """ZULTRA_HIP_DEVICES=0,0: zultra_memory_compress cuts the input into two shards of max-blocks, a host thread and a device
     context each (here: on the emulator's one device, the kernels taking turns), and stitches the shards in stream order at the
     bit phase the stream has reached — a stored sub-block sits right behind the cut. Same bytes as the one-stream path."""
-    d = corpus.text_like(4 * 32768 + 5000, 9)
+    d = corpus.text_like(3 * 32768 + 300, 9)           # four max-blocks: two per lane
     d[2 * 32768:2 * 32768 + 12000] = corpus.noise(12000, 4)
     want = oracle.memory_compress(d, 2, 32768)
     monkeypatch.setenv("ZULTRA_HIP_DEVICES", "0,0")
@@ -253,7 +253,7 @@ def test_stream_memory_comes_from_the_callers_allocator(emu, oracle):
         libc.free(p)
 
     zalloc, zfree = ZALLOC_T(za), ZFREE_T(zf)
-    d = corpus.text_like(50000, 6)
+    d = corpus.text_like(20000, 6)
     s = emu.stream(2, 32768, zalloc, zfree)
     assert len(log) >= 5 and len(live) == len(log)      # the state and four per-max-block arrays
     n_init = len(log)
