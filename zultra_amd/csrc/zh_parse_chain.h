@@ -585,7 +585,10 @@ __device__ inline void zh_chain_check_task(zh_chain_ws_t &ws, uint32_t *s_bad_p,
 // once — next to zh_parse_tasks' tens of thousands of waves — and every chain starts at the beginning of the pass. Ticket order:
 // the whole tasks of the two long classes, the segments of the cut tasks, the short whole tasks.
 #define ZH_CHAIN_GRID 1536
-__global__ void __launch_bounds__(ZH_CHAIN_THREADS)
+#ifndef ZH_CHAIN_VGPR_ATTR
+#define ZH_CHAIN_VGPR_ATTR
+#endif
+__global__ void __launch_bounds__(ZH_CHAIN_THREADS) ZH_CHAIN_VGPR_ATTR
 zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
                const uint32_t *__restrict__ hugelist, uint32_t cap, uint4 *segtasks, const uint2 *__restrict__ segitems, int16_t *vecs,
