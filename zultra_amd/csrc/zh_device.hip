@@ -730,6 +730,14 @@ static int zh_build_segments(zultra_hip_ctx_t *c, const zultra_hip_block_t *bloc
    return 0;
 }
 
+// tasks a wave of zh_parse_lanes takes (zh_parse_lanes.h): as many as ZH_LP_TASKS, as few as it takes to fill the chip's wave slots
+static uint32_t zh_tasks_per_wave(const zultra_hip_ctx_t *c, uint32_t ntasks) {
+   const char *e = getenv("ZULTRA_HIP_LANE_TASKS");
+   if (e) return (uint32_t)max(1, min((int)ZH_LP_TASKS, atoi(e)));
+   const uint32_t slots = c->total_cus * 8u;   // (measured: eight tasks per wave at 16 K tasks per run beat four by 2 % of the step)
+   return max(1u, min((uint32_t)ZH_LP_TASKS, (ntasks + slots - 1) / slots));
+}
+
 // barrier bitmap and greedy token chain of `nb` max-blocks starting at batch block b0, in chunks (zh_split.h)
 static int zh_enqueue_tokenize(zultra_hip_ctx_t *c, hipStream_t st, const zh_block_t *blk, uint32_t b0, uint32_t nb) {
    const uint32_t cpb = c->chunks_per_block;
@@ -804,9 +812,10 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
                 (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, c->d_segtasks, (const uint2 *)c->d_segitems, c->d_vecs, 0u, 0u, cnt, (const zh_sbstate_t *)states, best,
                 c->best_stride, hist_part, pass, cnt + ZH_CNT_CHAIN_TICKET + pass, (uint64_t *)NULL);
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
+      const uint32_t tpw = zh_tasks_per_wave(c, task_grid);
       if (c->parse_lanes)
-         ZH_LAUNCH(zh_parse_lanes, (task_grid + ZH_LP_TASKS - 1) / ZH_LP_TASKS, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0));
+         ZH_LAUNCH(zh_parse_lanes, (task_grid + tpw - 1) / tpw, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0), tpw);
       else
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
                 (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
@@ -1158,14 +1167,15 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
             ZH_CHECK(c, hipEventRecord(c->seg_ev[k][pass], sg));
          }
          if (c->parse_lanes) {
-            const uint32_t lane_grid = (task_grid + ZH_LP_TASKS - 1) / ZH_LP_TASKS;
+            const uint32_t tpw = zh_tasks_per_wave(c, task_grid);
+            const uint32_t lane_grid = (task_grid + tpw - 1) / tpw;
             if (nchains || seg_wide || c->always_persistent)
                ZH_LAUNCH(zh_parse_lanes, min(lane_grid, c->num_cus * c->lane_waves), 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                          (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass,
-                         ntasks + ZH_CNT_TASK_TICKET + pass, (const uint2 *)(c->d_taskinfo + t0));
+                         ntasks + ZH_CNT_TASK_TICKET + pass, (const uint2 *)(c->d_taskinfo + t0), tpw);
             else
                ZH_LAUNCH(zh_parse_lanes, lane_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0));
+                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0), tpw);
          }
          else if (nchains || seg_wide || c->always_persistent)
             ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,

@@ -502,7 +502,9 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    ZH_LP_COUNT(5, ZH_LP_CLOCK() - tic2);
 }
 
-// ticket == NULL: one workgroup (= one wave) per ZH_LP_TASKS tasks, the grid covers the task list. Otherwise the workgroups are
+// ticket == NULL: one workgroup (= one wave) per tasks_per_wave tasks, the grid covers the task list. The host gives a wave up to
+// ZH_LP_TASKS tasks — a pool of pieces large enough to keep its sixteen quads busy — but no more than it takes to give every wave slot
+// of the chip a wave: a small batch (one 40 KB input: 20 tasks) is a matter of latency, not of lane utilisation. Otherwise the workgroups are
 // persistent and take task groups from *ticket (see zh_parse_tasks: next to zh_parse_chain the host launches a bounded grid).
 // (118 registers. Capped at 96 — a wave would then fit on a SIMD next to the four 104-register waves of another run's matchfinder
 // workgroup — the compiler spills 17 of them and the kernel takes 1.5 times as long: measured, not kept.)
@@ -510,7 +512,7 @@ __global__ void __launch_bounds__(64)
 zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
                const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all,
-               uint32_t *hist_part, int pass, uint32_t *ticket, const uint2 *__restrict__ taskinfo) {
+               uint32_t *hist_part, int pass, uint32_t *ticket, const uint2 *__restrict__ taskinfo, uint32_t tasks_per_wave /* 1 .. ZH_LP_TASKS */) {
    __shared__ zh_lp_ws_t ws;
    const uint32_t ntasks = cnt[ZH_CNT_TASKS];
    for (;;) {
@@ -519,9 +521,9 @@ zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          if (zh_lane() == 0) w = atomicAdd(ticket, 1u);
          w = zh_readfirstlane(w);
       }
-      const uint32_t g0 = w * ZH_LP_TASKS;
+      const uint32_t g0 = w * tasks_per_wave;
       if (g0 >= ntasks) return;
-      const uint32_t g1 = min(ntasks, g0 + ZH_LP_TASKS);
+      const uint32_t g1 = min(ntasks, g0 + tasks_per_wave);
       // the wave's tasks, sub-block by sub-block
       for (uint32_t g = g0; g < g1;) {
          const uint32_t sb = taskmap[g].x;
