@@ -302,6 +302,13 @@ inline uint64_t zh_clock() { return 0; }
 inline uint64_t zh_wall_clock() { return 0; }
 inline uint32_t zh_load_agent_u32(const uint32_t *p) { return *p; }
 inline uint32_t zh_load_agent_u16(const uint16_t *p) { return *p; }
+inline uint32_t zh_funnel(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
+typedef uint32_t __attribute__((aligned(1))) zh_u32_any_t;
+struct __attribute__((packed, aligned(1))) zh_u128_any_t {
+   uint32_t x, y, z, w;
+};
+inline uint32_t zh_load32_any(const void *p) { return *(const zh_u32_any_t *)p; }
+inline zh_u128_any_t zh_load128_any(const void *p) { return *(const zh_u128_any_t *)p; }
 inline void zh_set_wave_priority_high() {}
 inline void zh_set_wave_priority_mid() {}
 inline void zh_set_wave_priority_normal() {}

@@ -35,7 +35,7 @@ f = L.L.zultra_hip_mf_profile
 f.argtypes = [C.c_void_p, C.c_int]
 f(None, 1)
 ctx.compress_blocks(d, blocks)
-out = np.zeros(8, dtype=np.uint64)
+out = np.zeros(16, dtype=np.uint64)
 f(out.ctypes.data, 0)
 t = ctx.timing()
 names = ["window staging", "chunk head", "byte-run path", "class walk", "row store"]
@@ -43,4 +43,8 @@ tot = float(out[:5].sum())
 print("%s %d bytes: frontier %.2f ms (both runs), group %.2f ms" % (kind, size, t["frontier_ms"], t["group_ms"]))
 for i, n in enumerate(names):
     print("   %-16s %5.1f %%   %.0f wave-cycles per position" % (n, 100.0 * float(out[i]) / tot, float(out[i]) * 64 / size))
-print("   chunks %d, walk iterations per chunk %.1f, lanes alive per iteration %.1f" % (out[6], float(out[5]) / max(1, float(out[6])), float(out[7]) / max(1.0, float(out[5]))))
+o = [float(x) for x in out]
+steps = max(1.0, o[8])
+print("   chunks %d, walk steps per chunk %.1f, lanes alive per step %.1f" % (o[6], o[8] / max(1.0, o[6]), o[9] / steps))
+print("   per step: %.0f cycles to the probes' answer, %.0f cycles of verification (%.2f of the steps have one: %.0f cycles each), %.2f whole-wave extensions"
+      % (o[10] / steps, o[11] / steps, o[12] / steps, o[11] / max(1.0, o[12]), o[13] / steps))

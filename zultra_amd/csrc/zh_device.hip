@@ -221,6 +221,17 @@ __global__ void __launch_bounds__(64) zh_selftest_kernel(uint32_t seed, uint32_t
       if (zh_row_shr<4>(x) != v[(lane & 15) >= 4 ? lane - 4 : lane]) errors++;
       if (zh_row_shl<1>(x) != v[(lane & 15) + 1 < 16 ? lane + 1 : lane]) errors++;
       if (zh_row_shl<2>(x) != v[(lane & 15) + 2 < 16 ? lane + 2 : lane]) errors++;
+      {
+         // reads at any byte address of LDS (zh_load32_any / zh_load128_any: the matchfinder's string probes)
+         const uint8_t *vb = (const uint8_t *)v;
+         const uint32_t o = (lane * 5u + round) % 237u;   // 0..236: 16 bytes from there stay inside the 256
+         uint32_t w[4];
+         for (uint32_t k = 0; k < 4; k++)
+            w[k] = (uint32_t)vb[o + 4 * k] | ((uint32_t)vb[o + 4 * k + 1] << 8) | ((uint32_t)vb[o + 4 * k + 2] << 16) | ((uint32_t)vb[o + 4 * k + 3] << 24);
+         if (zh_load32_any(vb + o) != w[0]) errors++;
+         const zh_u128_any_t q = zh_load128_any(vb + o);
+         if (q.x != w[0] || q.y != w[1] || q.z != w[2] || q.w != w[3]) errors++;
+      }
       zh_sync();
    }
    // RFC 1951 symbol arithmetic against first principles
@@ -1144,10 +1155,10 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       const uint32_t chain_grid = min(nchains, (uint32_t)ZH_CHAIN_GRID);
       const uint32_t persistent_grid = min(task_grid, c->num_cus * c->task_waves);
       for (int pass = 0; pass <= 3; pass++) {
-         if (getenv("ZH_DEBUG_ONEPASS") && pass > 0) break;
          // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
          hipStream_t side = c->side_stream[k];
-         if (nchains) {
+         const int dbg_skip = getenv("ZH_DEBUG_SKIP") ? atoi(getenv("ZH_DEBUG_SKIP")) : 0;   // timing experiments only (wrong output): 1 no chain kernel, 2 no lanes kernel
+         if (nchains && !(dbg_skip & 1)) {
             ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
             ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
             ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
@@ -1166,7 +1177,8 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                       (const uint2 *)taskmap, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, segtasks, (const uint2 *)segwaves, vecs, ntasks);
             ZH_CHECK(c, hipEventRecord(c->seg_ev[k][pass], sg));
          }
-         if (c->parse_lanes) {
+         if (dbg_skip & 2) ;
+         else if (c->parse_lanes) {
             const uint32_t tpw = zh_tasks_per_wave(c, task_grid);
             const uint32_t lane_grid = (task_grid + tpw - 1) / tpw;
             if (nchains || seg_wide || c->always_persistent)
@@ -1185,7 +1197,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
             ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                       (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
          if (seg_wide) ZH_CHECK(c, hipStreamWaitEvent(st, c->seg_ev[k][pass], 0));
-         if (nchains) ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
+         if (nchains && !(dbg_skip & 1)) ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
          ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));
          ZH_LAUNCH(zh_sb_build, ns, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass);
          ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));
@@ -1391,7 +1403,7 @@ extern "C" int zultra_hip_chain_trace(zultra_hip_ctx_t *c, uint64_t *out, uint32
 extern "C" int zultra_hip_mf_profile(unsigned long long *out, int reset) {
    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(zh_mf_prof), sizeof(zh_mf_prof)) != hipSuccess) return -1;
    if (reset) {
-      unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      unsigned long long z[16] = {0};
       if (hipMemcpyToSymbol(HIP_SYMBOL(zh_mf_prof), z, sizeof(z)) != hipSuccess) return -1;
    }
    return 0;

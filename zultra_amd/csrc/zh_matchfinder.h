@@ -47,7 +47,7 @@
 #define ZH_MF_SENTINEL 0xffffffffu   // "no entry": marked, and farther than any legal distance
 
 #define ZH_MF_NONE 0xffffffffu       // prev.x: no earlier occurrence of the trigram
-#define ZH_MF_GROUP_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + 2 * ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1) * 4)   // dynamic LDS bytes of zh_mf_group
+#define ZH_MF_GROUP_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + 2 * ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1 + 256) * 4)   // dynamic LDS bytes of zh_mf_group: window, two counter tables, small variables, 256 cursors
 #define ZH_MF_FRONTIER_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + 8 * ZH_MF_THREADS + 1) * 4)              // ... of zh_mf_frontier
 #define ZH_MF_HELP_WINDOW 4096u       // zh_mf_frontier: a workgroup out of tickets looks at the last 4096 segments for one to help
 #ifndef ZH_MF_HELP_MIN
@@ -112,8 +112,7 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
    const uint32_t lo = wave * seg;
    const uint32_t hi = min(M, lo + seg);
    const uint64_t lt_mask = (1ull << lane) - 1;
-   const uint32_t seg_next = NEXT >= 0 ? zh_mf_slice(M_next) : 1u;
-   const float inv_seg_next = 1.0f / (float)seg_next;
+   (void)M_next;
 
    if (!HAVE)
       for (uint32_t k = tid; k < ZH_MF_WAVES * 256; k += ZH_MF_THREADS) hist[k] = 0;
@@ -147,7 +146,33 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
       }                                                                                             \
    } while (0)
 
-   // per-wave digit histogram of the wave's contiguous slice; four independent fetches in flight per lane
+   // the same in two steps: the element (a load from HBM/L2 — issued a tile ahead), then its digit (LDS, or small tables)
+#define ZH_MF_FETCH_E(idx, e)                                             \
+   do {                                                                   \
+      if (MODE == 0)                                                      \
+         e = (idx);                                                       \
+      else if (MODE == 8)                                                 \
+         e = src ? src[idx] : (idx);                                      \
+      else                                                                \
+         e = src[idx];                                                    \
+   } while (0)
+#define ZH_MF_FETCH_D(idx, e, d)                                                                    \
+   do {                                                                                             \
+      if (MODE == 0)                                                                                \
+         d = win[(idx) + 2];                                                                        \
+      else if (MODE == 1 || MODE == 2)                                                              \
+         d = gwin[e + (MODE == 1 ? 1 : 0)];                                                         \
+      else if (MODE == 8) {                                                                         \
+         const uint32_t after_ = aux_rs[e] + aux_rl[e];                                             \
+         d = after_ < W ? (uint32_t)gwin[after_] : 0u;                                              \
+      }                                                                                             \
+      else if (MODE == 9)                                                                           \
+         d = gwin[aux_rs[e]];                                                                       \
+      else                                                                                          \
+         d = (e + (MODE - 2) < W) ? (uint32_t)gwin[e + (MODE - 2)] : 0xffffffffu;                   \
+   } while (0)
+
+   // ---- digit totals: counted by the pass before (HAVE: per producing wave, summed here) or by a pass over the input -----------
    for (uint32_t base = lo; base < hi && !HAVE; base += 64 * ZH_MF_UNROLL) {
       uint32_t e[ZH_MF_UNROLL], d[ZH_MF_UNROLL];
 #pragma unroll
@@ -162,54 +187,74 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
          if (d[u] != 0xffffffffu) atomicAdd(&hist[wave * 256 + d[u]], 1u);
    }
    __syncthreads();
-
-   // exclusive scan in (digit, wave) order: entry e = digit*16 + wave; each thread owns 4 entries
-   {
-      uint32_t v[4], s = 0;
+   // cursor[d] = where digit d's run of the output starts (exclusive scan of the totals; 256 values: one wave, four per lane)
+   uint32_t *cursor = wave_tot + ZH_MF_WAVES + 1 + ZH_MF_WAVES * 256;   // behind the second counter table (ZH_MF_GROUP_LDS)
+   if (tid < 256) {
+      uint32_t t = 0;
+      for (uint32_t w2 = 0; w2 < ZH_MF_WAVES; w2++) t += hist[w2 * 256 + tid];
+      cursor[tid] = t;
+   }
+   __syncthreads();
+   if (wave == 0) {
+      uint32_t v[4], t = 0;
       for (int q = 0; q < 4; q++) {
-         const uint32_t e = tid * 4 + (uint32_t)q;
-         v[q] = hist[(e & 15) * 256 + (e >> 4)];
-         s += v[q];
+         v[q] = cursor[lane * 4 + (uint32_t)q];
+         t += v[q];
       }
-      uint32_t ex = zh_wave_excl_sum(s);
-      if (lane == 63) wave_tot[wave] = ex + s;
-      __syncthreads();
-      uint32_t pre = 0;
-      for (uint32_t w2 = 0; w2 < wave; w2++) pre += wave_tot[w2];
-      ex += pre;
+      uint32_t ex = zh_wave_excl_sum(t);
       for (int q = 0; q < 4; q++) {
-         const uint32_t e = tid * 4 + (uint32_t)q;
-         hist[(e & 15) * 256 + (e >> 4)] = ex;
+         cursor[lane * 4 + (uint32_t)q] = ex;
          ex += v[q];
       }
    }
    __syncthreads();
 
-   // stable scatter: each wave walks its slice in order, 64 elements per step; the fetches of four steps are issued together
-   uint32_t e_before = ZH_MF_NONE;   // (PREV) wave-uniform: the element before this step's first one
-   if (PREV && lo > 0 && lo < hi) e_before = src[lo - 1];
-   for (uint32_t base4 = lo; base4 < hi; base4 += 64 * ZH_MF_UNROLL) {
+   // ---- stable scatter, a tile of ZH_MF_WAVES x 64 x ZH_MF_UNROLL consecutive elements at a time: wave w takes the w-th stretch of the
+   // tile, counts its digits, the counts of the waves before it (and the digit's cursor) give where its elements go. One cursor per
+   // digit and workgroup: 256 lines of the output are open at a time, and every tile appends to them. (Round 2 gave every wave a
+   // contiguous sixteenth of the input and cursors of its own: 4096 open lines per workgroup, 32 workgroups to an XCD's 4 MB of L2 —
+   // lines left the L2 with a few 4-byte entries in them and the kernel wrote 6 GB per launch for 3.3 GB of stores.)
+   const uint32_t tile = ZH_MF_WAVES * 64u * ZH_MF_UNROLL;
+   // the elements (and payloads) of the next tile are requested before this tile's barriers: their latency hides behind them
+   uint32_t en[ZH_MF_UNROLL], pn[ZH_MF_UNROLL], qn[ZH_MF_UNROLL], ebn = ZH_MF_NONE;
+#define ZH_MF_REQUEST(tile0_)                                                                           \
+   do {                                                                                                 \
+      const uint32_t b4_ = (tile0_) + wave * 64u * ZH_MF_UNROLL;                                        \
+      _Pragma("unroll") for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {                                   \
+         const uint32_t idx = b4_ + u * 64 + lane;                                                      \
+         en[u] = pn[u] = qn[u] = 0;                                                                     \
+         if (idx < M) {                                                                                 \
+            ZH_MF_FETCH_E(idx, en[u]);                                                                  \
+            if (PAY >= 1 && PREV != 3) pn[u] = psrc[idx];                                               \
+            if (PAY >= 2 && !PREV) qn[u] = qsrc[idx];                                                   \
+         }                                                                                              \
+      }                                                                                                 \
+      if (PREV) ebn = (b4_ > 0 && b4_ < M) ? src[b4_ - 1] : ZH_MF_NONE;                                  \
+   } while (0)
+   ZH_MF_REQUEST(0u);
+   for (uint32_t tile0 = 0; tile0 < M; tile0 += tile) {
+      const uint32_t base4 = tile0 + wave * 64u * ZH_MF_UNROLL;
       uint32_t e4[ZH_MF_UNROLL], d4[ZH_MF_UNROLL], p4[ZH_MF_UNROLL], q4[ZH_MF_UNROLL];
+      uint64_t peers4[ZH_MF_UNROLL];
+      for (uint32_t k = lane; k < 256; k += 64) hist[wave * 256 + k] = 0;
 #pragma unroll
       for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {
-         p4[u] = q4[u] = 0;
          const uint32_t idx = base4 + u * 64 + lane;
-         e4[u] = 0;
+         e4[u] = en[u];
+         p4[u] = pn[u];
+         q4[u] = qn[u];
          d4[u] = 0xffffffffu;
-         if (idx < hi) {
-            ZH_MF_FETCH(idx, e4[u], d4[u]);
-            if (PAY >= 1 && PREV != 3) p4[u] = psrc[idx];
-            if (PAY >= 2 && !PREV) q4[u] = qsrc[idx];
-         }
+         if (idx < M) ZH_MF_FETCH_D(idx, e4[u], d4[u]);
       }
       if (PREV) {
+         uint32_t e_before = ebn;   // wave-uniform: the element before this step's first one
 #pragma unroll
          for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {
             const uint32_t idx = base4 + u * 64 + lane;
             const uint32_t pos = e4[u];
             const uint32_t q = zh_wave_shr1(pos, e_before);   // the element before this one in the order
             e_before = zh_readlane(pos, 63);
-            if (idx < hi) {
+            if (idx < M) {
                bool same = q != ZH_MF_NONE;
                if (same) {
                   if (PREV == 3)
@@ -233,44 +278,63 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
             }
          }
       }
+      // the lanes of a step with the same digit (kept for the scatter); the first of them counts them all
 #pragma unroll
       for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {
-         const uint32_t idx = base4 + u * 64 + lane;
-         const uint32_t e = e4[u], d = d4[u];
-         const bool valid = idx < hi && d != 0xffffffffu;
-         const uint32_t slot = valid ? hist[wave * 256 + d] : 0;
+         const uint32_t d = d4[u];
+         const bool valid = d != 0xffffffffu;
          uint64_t peers = zh_ballot(valid);
          for (int bit = 0; bit < 8; bit++) {
             const bool one = (d >> bit) & 1u;
             const uint64_t m = zh_ballot(valid && one);
             peers &= one ? m : ~m;
          }
+         peers4[u] = peers;
+         if (valid && (peers & lt_mask) == 0) hist[wave * 256 + d] += (uint32_t)zh_popc64(peers);
+         zh_ballot(true);   // orders the counter update before the next step's (lock-step anyway on the GPU)
+      }
+      if (tile0 + tile < M) ZH_MF_REQUEST(tile0 + tile);
+      zh_sync_lds();   // (LDS only: the requests above stay in flight)
+      if (tid < 256) {
+         uint32_t run = cursor[tid];
+         for (uint32_t w2 = 0; w2 < ZH_MF_WAVES; w2++) {
+            const uint32_t cnt = hist[w2 * 256 + tid];
+            hist[w2 * 256 + tid] = run;
+            run += cnt;
+         }
+         cursor[tid] = run;
+      }
+      zh_sync_lds();   // (LDS only: the requests above stay in flight)
+#pragma unroll
+      for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {
+         const uint32_t e = e4[u], d = d4[u];
+         const bool valid = d != 0xffffffffu;
+         const uint64_t peers = peers4[u];
+         const uint32_t slot = valid ? hist[wave * 256 + d] : 0;
+         zh_lockstep_sync();   // every lane has read the cursor before the first of its peers moves it
          if (valid) {
             const uint32_t out = slot + (uint32_t)zh_popc64(peers & lt_mask);
-#ifdef ZH_MF_FAKE_SCATTER   // timing experiment (tools/probes/mf_stop_probe.py, with ZH_MF_STOP=2 only): what do the scattered stores cost?
-            dst[out & 4095u] = e;
-#else
             dst[out] = e;
             if (PAY == 1) pdst[out] = p4[u];
             if (PAY == 2) pdst2[out] = make_uint2(p4[u], q4[u]);
-#endif
             if ((peers & lt_mask) == 0) hist[wave * 256 + d] = slot + (uint32_t)zh_popc64(peers);
             if (NEXT >= 0) {
-               // the next pass's digit of this element, counted for the wave whose slice position `out` will fall into
+               // the next pass's digit of this element (which wave counts it does not matter: the next pass adds them up)
                const bool has = NEXT < 5 || e + (uint32_t)(NEXT - 2) < W;
                if (has) {
                   const uint32_t d2 = gwin[e + (NEXT == 1 ? 1u : (NEXT == 2 ? 0u : (uint32_t)(NEXT - 2)))];
-                  uint32_t w2 = min((uint32_t)((float)out * inv_seg_next), (uint32_t)ZH_MF_WAVES - 1u);
-                  w2 -= (w2 * seg_next > out) ? 1u : 0u;
-                  w2 += ((w2 + 1) * seg_next <= out) ? 1u : 0u;
-                  atomicAdd(&hist_next[w2 * 256 + d2], 1u);
+                  atomicAdd(&hist_next[wave * 256 + d2], 1u);
                }
             }
          }
          zh_ballot(true);   // orders the counter update before the next step's read (lock-step anyway on the GPU)
       }
+      // (the next tile's zeroing of this wave's counters comes after these reads in program order; the other waves' are not touched)
    }
 #undef ZH_MF_FETCH
+#undef ZH_MF_FETCH_E
+#undef ZH_MF_FETCH_D
+#undef ZH_MF_REQUEST
    __threadfence_block();
    __syncthreads();
 }
@@ -510,44 +574,86 @@ __device__ __forceinline__ uint32_t zh_trigram(const uint8_t *p) {
 
 // 4 bytes at an arbitrary byte offset x of a dword-aligned buffer: two aligned dword reads + funnel shift
 // (the buffer must be readable up to 7 bytes past x).
+#ifndef ZH_MF_UNALIGNED32
+#define ZH_MF_UNALIGNED32 0
+#endif
+#ifndef ZH_MF_UNALIGNED128
+#define ZH_MF_UNALIGNED128 0
+#endif
 __device__ __forceinline__ uint32_t zh_load32_at(const uint32_t *w32, uint32_t x) {
+#if ZH_MF_UNALIGNED32
+   return zh_load32_any((const uint8_t *)w32 + x);
+#else
    const uint32_t lo = w32[x >> 2], hi = w32[(x >> 2) + 1];
-   const uint32_t sh = (x & 3u) * 8u;
-   return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+   return zh_funnel(hi, lo, x * 8u);   // (the shift counts modulo 32)
+#endif
 }
 // the 16 bytes at byte offset x: five aligned words, all in flight together
 __device__ __forceinline__ void zh_load128_at(const uint32_t *w32, uint32_t x, uint32_t out[4]) {
+#if ZH_MF_UNALIGNED128
+   const zh_u128_any_t v = zh_load128_any((const uint8_t *)w32 + x);
+   out[0] = v.x;
+   out[1] = v.y;
+   out[2] = v.z;
+   out[3] = v.w;
+#else
    const uint32_t *p = w32 + (x >> 2);
    const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4];
-   const uint32_t sh = (x & 3u) * 8u;
-   out[0] = (uint32_t)((((uint64_t)a1 << 32) | a0) >> sh);
-   out[1] = (uint32_t)((((uint64_t)a2 << 32) | a1) >> sh);
-   out[2] = (uint32_t)((((uint64_t)a3 << 32) | a2) >> sh);
-   out[3] = (uint32_t)((((uint64_t)a4 << 32) | a3) >> sh);
+   const uint32_t sh = x * 8u;
+   out[0] = zh_funnel(a1, a0, sh);
+   out[1] = zh_funnel(a2, a1, sh);
+   out[2] = zh_funnel(a3, a2, sh);
+   out[3] = zh_funnel(a4, a3, sh);
+#endif
 }
 
-
-// match length of the strings at byte offsets q and (the lane's own, its first 16 bytes in own16) over their first 16 bytes: 0..16
-__device__ __forceinline__ uint32_t zh_mf_match16(const uint32_t *lwin32, uint32_t q, const uint32_t (&own16)[4]) {
-   uint32_t c16[4];
-   zh_load128_at(lwin32, q, c16);
+// match length of a candidate's first 16 bytes (c16) and the lane's own (own16): 0..16. Without branches: the loads of a walk step
+// (two candidates, five aligned words each) are then all in flight together — with early exits the compiler fetched a candidate's
+// words one round trip at a time
+__device__ __forceinline__ uint32_t zh_mf_len16(const uint32_t (&c16)[4], const uint32_t (&own16)[4]) {
    const uint32_t x0 = c16[0] ^ own16[0], x1 = c16[1] ^ own16[1], x2 = c16[2] ^ own16[2], x3 = c16[3] ^ own16[3];
-   if (x0) return (uint32_t)(__ffs((int)x0) - 1) >> 3;
-   if (x1) return 4u + ((uint32_t)(__ffs((int)x1) - 1) >> 3);
-   if (x2) return 8u + ((uint32_t)(__ffs((int)x2) - 1) >> 3);
-   if (x3) return 12u + ((uint32_t)(__ffs((int)x3) - 1) >> 3);
-   return 16u;
+   const uint32_t xs = x0 ? x0 : x1 ? x1 : x2 ? x2 : x3;
+   const uint32_t base = x0 ? 0u : x1 ? 4u : x2 ? 8u : 12u;
+   return xs ? base + ((uint32_t)__builtin_ctz(xs) >> 3) : 16u;
 }
+
+#ifdef ZH_MF_PROFILE
+// probe builds only (tools/mf_profile.py): wave-cycles of zh_mf_frontier by phase — 0 window staging, 1 chunk head (entries, prev
+// records, first records), 2 byte-run path, 3 class walk, 4 row store; counts — 6 chunks, 8 walk steps, 9 lanes alive in them, 10 cycles
+// up to the probes' answer, 11 cycles of the verification, 12 steps with a verification, 13 rounds of zh_mf_extend_wave. A wave keeps
+// them in registers and adds them up once per segment: an atomic per lap would sit in front of the next wait for a load.
+__device__ unsigned long long zh_mf_prof[16];
+#define ZH_MF_PROF_VARS() uint64_t pf_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_t_ = 0, pf_w_ = 0
+#define ZH_MF_PROF_FLUSH() do { if (lane == 0) { for (int k_ = 0; k_ < 16; k_++) { if (pf_[k_]) atomicAdd(&zh_mf_prof[k_], (unsigned long long)pf_[k_]); pf_[k_] = 0; } } } while (0)
+#define ZH_MF_TIC() pf_t_ = zh_clock()
+#define ZH_MF_LAP(slot_) do { const uint64_t now_ = zh_clock(); pf_[slot_] += now_ - pf_t_; pf_t_ = now_; } while (0)
+#define ZH_MF_COUNT(slot_, n_) pf_[slot_] += (n_)
+#define ZH_MF_WALK_TOP(mask_) do { pf_w_ = zh_clock(); pf_[8]++; pf_[9] += (uint32_t)zh_popc64(mask_); } while (0)
+#define ZH_MF_WALK_PROBED() do { const uint64_t n_ = zh_clock(); pf_[10] += n_ - pf_w_; pf_w_ = n_; } while (0)
+#define ZH_MF_WALK_VERIFIED() do { pf_[11] += zh_clock() - pf_w_; pf_[12]++; } while (0)
+#define ZH_MF_WALK_EXT(need_) pf_[13] += (uint32_t)zh_popc64(zh_ballot(need_))
+#else
+#define ZH_MF_PROF_VARS()
+#define ZH_MF_PROF_FLUSH()
+#define ZH_MF_TIC()
+#define ZH_MF_LAP(slot_)
+#define ZH_MF_COUNT(slot_, n_)
+#define ZH_MF_WALK_TOP(mask_) (void)(mask_)
+#define ZH_MF_WALK_PROBED()
+#define ZH_MF_WALK_VERIFIED()
+#define ZH_MF_WALK_EXT(need_)
+#endif
 
 // Matches that run past 16 bytes are finished by the whole wave: for every lane with `need` in turn, lane k compares the four
 // bytes at offset 16 + 4k of the two strings (64 lanes cover 16..271: every length up to 258 in one step), a ballot finds the
 // first difference. A lane stepping through its own long match four bytes at a time kept the other 63 waiting for up to 60
 // rounds — on source code and other repetitive data that was most of the walk. All lanes call; returns l, or the lane's full
 // match length (not yet clamped to maxlen beyond the comparison range) where it had `need`.
+template <uint32_t BASE = 16u>
 __device__ __forceinline__ uint32_t zh_mf_extend_wave(const uint32_t *lwin32, bool need, uint32_t q, uint32_t i, uint32_t maxlen, uint32_t l) {
    uint64_t todo = zh_ballot(need);
    const uint32_t lane = zh_lane();
-   const uint32_t off = 16u + 4u * lane;
+   const uint32_t off = BASE + 4u * lane;
    while (todo) {
       const int src = zh_ctz64(todo);
       todo &= todo - 1;
@@ -555,27 +661,27 @@ __device__ __forceinline__ uint32_t zh_mf_extend_wave(const uint32_t *lwin32, bo
       const bool beyond = off >= ml;   // (also keeps every read inside the window)
       uint32_t x = 0;
       if (!beyond) x = zh_load32_at(lwin32, qq + off) ^ zh_load32_at(lwin32, ii + off);
-      const uint64_t stop = zh_ballot(beyond || x != 0);   // lane 63 compares offset 268: always beyond
+      const uint64_t stop = zh_ballot(beyond || x != 0);   // lane 63 compares offset 268 or more: always beyond
       const int fl = zh_ctz64(stop);
       const uint32_t xf = zh_readlane(x, fl);
-      const uint32_t len = 16u + 4u * (uint32_t)fl + (xf ? ((uint32_t)(__ffs((int)xf) - 1) >> 3) : 0u);
+      const uint32_t len = BASE + 4u * (uint32_t)fl + (xf ? ((uint32_t)(__ffs((int)xf) - 1) >> 3) : 0u);
       if ((int)lane == src) l = min(len, ml);
    }
    return l;
 }
 
-#ifdef ZH_MF_PROFILE
-// probe builds only (tools/mf_profile.py): wave-cycles of zh_mf_frontier by phase — 0 window staging, 1 chunk head (entries, prev
-// records, first records), 2 byte-run path, 3 class walk, 4 row store, 5 walk iterations, 6 chunks, 7 lanes x walk iterations alive
-__device__ unsigned long long zh_mf_prof[8];
-#define ZH_MF_TIC() const uint64_t tic_ = zh_clock()
-#define ZH_MF_TOC(slot_) do { if (lane == 0) atomicAdd(&zh_mf_prof[slot_], (unsigned long long)(zh_clock() - tic_)); } while (0)
-#define ZH_MF_COUNT(slot_, n_) do { if (lane == 0) atomicAdd(&zh_mf_prof[slot_], (unsigned long long)(n_)); } while (0)
-#else
-#define ZH_MF_TIC()
-#define ZH_MF_TOC(slot_)
-#define ZH_MF_COUNT(slot_, n_)
-#endif
+
+// The length of a match that agrees on its first 16 bytes (lanes with `need`; all lanes call): bytes 16..31 are compared by the lane itself
+// against its own bytes 16..31 in registers — every lane that needs it at once, and half of the long matches of source code end there —
+// and only what still agrees at 32 goes to the whole wave, one lane at a time.
+__device__ __forceinline__ uint32_t zh_mf_length_past16(const uint32_t *lwin32, bool need, uint32_t q, uint32_t i, uint32_t maxlen, const uint32_t (&own32)[4], uint32_t l) {
+   if (!zh_ballot(need)) return l;   // (wave-uniform)
+   uint32_t g[4];
+   zh_load128_at(lwin32, need ? q + 16u : 0u, g);
+   const uint32_t m = zh_mf_len16(g, own32);
+   if (need) l = 16u + m;
+   return zh_mf_extend_wave<32u>(lwin32, need && m == 16u && maxlen > 32u, q, i, maxlen, l);
+}
 
 template <bool LDS_WIN>
 __global__ void __launch_bounds__(ZH_MF_THREADS)
@@ -594,6 +700,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
    const uint32_t lane = threadIdx.x & 63;
    uint32_t seg_id = 0;
    bool owner = true, tickets_left = true;
+   ZH_MF_PROF_VARS();
 
    for (;;) {
    if (tickets_left) {
@@ -654,7 +761,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       ZH_MF_TIC();
       zh_stage_window(lwin32, gwin, W);
       win = (const uint8_t *)lwin32;
-      ZH_MF_TOC(0);
+      ZH_MF_LAP(0);
    }
    if (threadIdx.x == 0) {
       help_key = 0;
@@ -715,12 +822,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       if (c >= M) continue;
 
       ZH_MF_COUNT(6, 1);
-      uint64_t ptic_ = zh_clock();
-#ifdef ZH_MF_PROFILE
-#define ZH_MF_LAP(slot_) do { const uint64_t now_ = zh_clock(); if (lane == 0) atomicAdd(&zh_mf_prof[slot_], (unsigned long long)(now_ - ptic_)); ptic_ = now_; } while (0)
-#else
-#define ZH_MF_LAP(slot_) (void)ptic_
-#endif
+      ZH_MF_TIC();
       const uint32_t t = c + lane;
       const uint32_t own = t < M ? S[t] : ZH_MF_SENTINEL;
       const uint32_t i = own & ZH_MF_POS_MASK;
@@ -741,6 +843,8 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
          else
             own16[0] = zh_ld32(win + i);
       }
+      uint32_t own32[4] = {0, 0, 0, 0};   // bytes 16..31 likewise (past the window end: garbage, and never decisive — lengths are clamped to maxlen)
+      if (mine && LDS_WIN) zh_load128_at(lwin32, i + 16u, own32);
       const uint32_t first4 = own16[0];
       bool has4 = false;
       uint32_t d4 = 0xffffu, d5 = 0xffffu;
@@ -941,11 +1045,12 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       // A candidate can only beat `cur` if its bytes fo..fo+3 equal ci: the 4-byte probe weeds out nearly all; the survivors get
       // their true match length from byte 0 (an entry of a neighbouring class met after the class head fails there) — the
       // first 16 bytes per lane against the lane's own 16 in registers, anything longer by the whole wave at once
-      // (zh_mf_extend_wave). Both probes of an iteration are issued before either is used; a probe taken before `cur` grew
-      // stays a valid pre-filter.
+      // (zh_mf_extend_wave). The walk is a chain of LDS round trips with four waves per SIMD to hide them (round 2: eight to ten
+      // per step — probe, then the candidate's words one early exit at a time, then the record, for each of the two candidates);
+      // a step now has two for the common case: both probes together, then the first 16 bytes of both candidates together, with
+      // the lengths worked out without branches. A probe taken before `cur` grew stays a valid pre-filter.
       while (const uint64_t alive_mask_ = zh_ballot(alive)) {
-         ZH_MF_COUNT(5, 1);
-         ZH_MF_COUNT(7, zh_popc64(alive_mask_));
+         ZH_MF_WALK_TOP(alive_mask_);
          // advance twice: entries c+l-1-2k and c+l-2-2k arrive at lane l; lane 0 takes the next entries below the chunk
          const uint32_t c1 = zh_wave_shr1(cand, zh_readlane(vec, vi));
          const uint32_t c2 = zh_wave_shr1(c1, zh_readlane(vec, vi - 1));
@@ -959,37 +1064,76 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
          const uint32_t q1 = c1 & ZH_MF_POS_MASK, q2 = c2 & ZH_MF_POS_MASK;
          const uint32_t d1 = i - q1, d2 = i - q2;
          const bool ok1 = alive && d1 <= ZH_MAX_DIST, ok2 = alive && d2 <= ZH_MAX_DIST;     // false for the sentinel too
-         // both 4-byte probes are issued before either is used (an out-of-reach candidate probes the lane's own position);
-         // nearly every candidate dies here, so the verification below runs for few lanes
-         // (lanes that are done probe offset 0: their position may be the sentinel)
-         const uint32_t a1 = ok1 ? q1 + fo : (alive ? i + fo : 0u), a2 = ok2 ? q2 + fo : (alive ? i + fo : 0u);
+         // (lanes that are done, or whose candidate is out of reach, probe offset 0: their position may be the sentinel)
+         const uint32_t a1 = ok1 ? q1 + fo : 0u, a2 = ok2 ? q2 + fo : 0u;
          const uint32_t pb1 = LDS_WIN ? zh_load32_at(lwin32, a1) : zh_ld32(win + a1);
          const uint32_t pb2 = LDS_WIN ? zh_load32_at(lwin32, a2) : zh_ld32(win + a2);
-         const uint32_t tgt = ci;
+         const bool v1 = ok1 && pb1 == ci, v2 = ok2 && pb2 == ci;
+         const uint64_t vm1 = zh_ballot(v1), vm2 = zh_ballot(v2);
+         ZH_MF_WALK_PROBED();
+         if (vm1 | vm2) {   // (wave-uniform, and so are the branches on vm1 and vm2: a side without a survivor costs nothing)
+            // the nearer candidate
+            bool rec1 = false;
+            if (vm1) {
+               uint32_t f1[4];
+               if (LDS_WIN)
+                  zh_load128_at(lwin32, v1 ? q1 : 0u, f1);
+               else {
 #pragma unroll
-         for (int which = 0; which < 2; which++) {
-            const uint32_t q = which ? q2 : q1, dist = which ? d2 : d1;
-            bool v = which ? (ok2 && pb2 == tgt && cur < maxlen) : (ok1 && pb1 == tgt);
-            // (the first record of the iteration may have moved fo: the second candidate is probed again where it counts now)
-            if (which && v) v = (LDS_WIN ? zh_load32_at(lwin32, q + fo) : zh_ld32(win + q + fo)) == ci;
-            uint32_t l = 0;
-            if (LDS_WIN) {
-               if (v) l = zh_mf_match16(lwin32, q, own16);   // bytes past the window end are garbage, but l is clamped to maxlen
-               l = zh_mf_extend_wave(lwin32, v && l == 16 && maxlen > 16, q, i, maxlen, l);
-               l = min(l, maxlen);
-            }
-            else if (v) {
-               while (l < maxlen && win[q + l] == win[i + l]) l++;
-            }
-            if (v && l > cur) {
-               myring[(nm & 7u) * ZH_MF_THREADS] = l | (dist << 16);   // offset 32768 needs all 16 bits
-               nm++;
-               cur = l;
-               if (cur < maxlen) {
-                  fo = cur - 3;
-                  ci = LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo);
+                  for (uint32_t u = 0; u < 4; u++) f1[u] = zh_ld32(win + (v1 ? q1 : 0u) + 4u * u);
+               }
+               uint32_t l1 = zh_mf_len16(f1, own16);   // (bytes past the window end are garbage, but the lengths are clamped to maxlen)
+               const bool deep1 = v1 && l1 == 16 && maxlen > 16;
+               ZH_MF_WALK_EXT(deep1);
+               if (LDS_WIN)
+                  l1 = zh_mf_length_past16(lwin32, deep1, q1, i, maxlen, own32, l1);
+               else if (deep1)
+                  while (l1 < maxlen && win[q1 + l1] == win[i + l1]) l1++;
+               l1 = min(l1, maxlen);
+               rec1 = v1 && l1 > cur;
+               if (rec1) {
+                  myring[(nm & 7u) * ZH_MF_THREADS] = l1 | (d1 << 16);   // offset 32768 needs all 16 bits
+                  nm++;
+                  cur = l1;
                }
             }
+            // the farther one has to beat the record as it stands now. Sixteen bytes or fewer: its length is known. More: where the
+            // record has just moved, four bytes ending at the new record are probed first
+            if (vm2) {
+               uint32_t f2[4];
+               if (LDS_WIN)
+                  zh_load128_at(lwin32, v2 ? q2 : 0u, f2);
+               else {
+#pragma unroll
+                  for (uint32_t u = 0; u < 4; u++) f2[u] = zh_ld32(win + (v2 ? q2 : 0u) + 4u * u);
+               }
+               uint32_t l2 = zh_mf_len16(f2, own16);
+               bool deep2 = v2 && l2 == 16 && maxlen > 16 && cur < maxlen;
+               if (zh_ballot(deep2 && rec1)) {
+                  if (deep2 && rec1) {
+                     const uint32_t f = cur - 3u;
+                     deep2 = LDS_WIN ? zh_load32_at(lwin32, q2 + f) == zh_load32_at(lwin32, i + f) : zh_ld32(win + q2 + f) == zh_ld32(win + i + f);
+                  }
+               }
+               ZH_MF_WALK_EXT(deep2);
+               if (LDS_WIN)
+                  l2 = zh_mf_length_past16(lwin32, deep2, q2, i, maxlen, own32, l2);
+               else if (deep2)
+                  while (l2 < maxlen && win[q2 + l2] == win[i + l2]) l2++;
+               l2 = min(l2, maxlen);
+               const bool rec2 = v2 && l2 > cur && (l2 < 16u || deep2 || maxlen <= 16u);
+               if (rec2) {
+                  myring[(nm & 7u) * ZH_MF_THREADS] = l2 | (d2 << 16);
+                  nm++;
+                  cur = l2;
+               }
+               rec1 = rec1 || rec2;
+            }
+            if (rec1 && cur < maxlen) {
+               fo = cur - 3;
+               ci = LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo);
+            }
+            ZH_MF_WALK_VERIFIED();
          }
          // the class ends at its head; beyond 32 KiB everything else is farther still; 258 (or the window end) cannot be beaten
          alive = ok1 && ok2 && !((c1 | c2) & ZH_MF_HEAD) && cur < maxlen;
@@ -1009,6 +1153,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       ZH_MF_LAP(4);
    }
 
+   ZH_MF_PROF_FLUSH();
    __syncthreads();   // every wave is done with the window in LDS
    }
 }

@@ -149,6 +149,19 @@ __device__ __forceinline__ uint32_t zh_load_agent_u32(const uint32_t *p) { retur
 
 __device__ __forceinline__ uint32_t zh_load_agent_u16(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// the 32 bits at bit offset (sh & 31) of hi:lo — one v_alignbit_b32 (the funnel shift of an unaligned 4-byte read from two aligned words)
+__device__ __forceinline__ uint32_t zh_funnel(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+
+// Loads at any byte address. gfx950 serves them in hardware (LDS and global: the HSA targets run in unaligned access mode, and the
+// compiler emits one ds_read_b32 / ds_read_b128 for these types), so a string probe into the window copy in LDS is one
+// instruction, not two aligned reads and a funnel shift. zultra_hip_selftest checks it on the device it runs on.
+typedef uint32_t __attribute__((aligned(1))) zh_u32_any_t;
+struct __attribute__((packed, aligned(1))) zh_u128_any_t {
+   uint32_t x, y, z, w;
+};
+__device__ __forceinline__ uint32_t zh_load32_any(const void *p) { return *(const zh_u32_any_t *)p; }
+__device__ __forceinline__ zh_u128_any_t zh_load128_any(const void *p) { return *(const zh_u128_any_t *)p; }
+
 // LDS visibility between the lanes of a workgroup (a single wave for the 64-thread kernels)
 __device__ __forceinline__ void zh_sync() { __syncthreads(); }
 // Workgroup barrier that orders LDS traffic only. __syncthreads() also drains the wave's outstanding GLOBAL loads
