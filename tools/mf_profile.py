@@ -48,3 +48,6 @@ steps = max(1.0, o[8])
 print("   chunks %d, walk steps per chunk %.1f, lanes alive per step %.1f" % (o[6], o[8] / max(1.0, o[6]), o[9] / steps))
 print("   per step: %.0f cycles to the probes' answer, %.0f cycles of verification (%.2f of the steps have one: %.0f cycles each), %.2f whole-wave extensions"
       % (o[10] / steps, o[11] / steps, o[12] / steps, o[11] / max(1.0, o[12]), o[13] / steps))
+rp = max(1.0, o[5] + o[7] + o[14] + o[15])
+print("   byte-run path, lane 0's share by part: own run %.0f %%, earlier runs (same byte) %.0f %%, second search %.0f %%, runs followed by the same byte %.0f %%"
+      % (100 * o[5] / rp, 100 * o[7] / rp, 100 * o[14] / rp, 100 * o[15] / rp))

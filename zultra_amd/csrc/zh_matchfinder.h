@@ -623,11 +623,13 @@ __device__ __forceinline__ uint32_t zh_mf_len16(const uint32_t (&c16)[4], const 
 // up to the probes' answer, 11 cycles of the verification, 12 steps with a verification, 13 rounds of zh_mf_extend_wave. A wave keeps
 // them in registers and adds them up once per segment: an atomic per lap would sit in front of the next wait for a load.
 __device__ unsigned long long zh_mf_prof[16];
-#define ZH_MF_PROF_VARS() uint64_t pf_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_t_ = 0, pf_w_ = 0
+#define ZH_MF_PROF_VARS() uint64_t pf_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_t_ = 0, pf_w_ = 0, pf_s_ = 0
 #define ZH_MF_PROF_FLUSH() do { if (lane == 0) { for (int k_ = 0; k_ < 16; k_++) { if (pf_[k_]) atomicAdd(&zh_mf_prof[k_], (unsigned long long)pf_[k_]); pf_[k_] = 0; } } } while (0)
 #define ZH_MF_TIC() pf_t_ = zh_clock()
 #define ZH_MF_LAP(slot_) do { const uint64_t now_ = zh_clock(); pf_[slot_] += now_ - pf_t_; pf_t_ = now_; } while (0)
 #define ZH_MF_COUNT(slot_, n_) pf_[slot_] += (n_)
+#define ZH_MF_SUBTIC() pf_s_ = zh_clock()
+#define ZH_MF_SUBLAP(slot_) do { const uint64_t now_ = zh_clock(); pf_[slot_] += now_ - pf_s_; pf_s_ = now_; } while (0)
 #define ZH_MF_WALK_TOP(mask_) do { pf_w_ = zh_clock(); pf_[8]++; pf_[9] += (uint32_t)zh_popc64(mask_); } while (0)
 #define ZH_MF_WALK_PROBED() do { const uint64_t n_ = zh_clock(); pf_[10] += n_ - pf_w_; pf_w_ = n_; } while (0)
 #define ZH_MF_WALK_VERIFIED() do { pf_[11] += zh_clock() - pf_w_; pf_[12]++; } while (0)
@@ -638,6 +640,8 @@ __device__ unsigned long long zh_mf_prof[16];
 #define ZH_MF_TIC()
 #define ZH_MF_LAP(slot_)
 #define ZH_MF_COUNT(slot_, n_)
+#define ZH_MF_SUBTIC()
+#define ZH_MF_SUBLAP(slot_)
 #define ZH_MF_WALK_TOP(mask_) (void)(mask_)
 #define ZH_MF_WALK_PROBED()
 #define ZH_MF_WALK_VERIFIED()
@@ -670,6 +674,20 @@ __device__ __forceinline__ uint32_t zh_mf_extend_wave(const uint32_t *lwin32, bo
    return l;
 }
 
+
+// A lane on its own (the byte-run path, where the lanes of a chunk are at different stages): the strings at p and i agree on their first
+// l bytes; 16 more per round trip. (Round 2 took four: a 40-byte match of an indented line was ten dependent LDS round trips.)
+__device__ __forceinline__ uint32_t zh_mf_extend_lane(const uint32_t *lwin32, uint32_t p, uint32_t i, uint32_t l, uint32_t maxlen) {
+   while (l < maxlen) {
+      uint32_t a[4], b[4];
+      zh_load128_at(lwin32, p + l, a);
+      zh_load128_at(lwin32, i + l, b);
+      const uint32_t m = zh_mf_len16(a, b);
+      l += m;
+      if (m < 16u) break;
+   }
+   return min(l, maxlen);
+}
 
 // The length of a match that agrees on its first 16 bytes (lanes with `need`; all lanes call): bytes 16..31 are compared by the lane itself
 // against its own bytes 16..31 in registers — every lane that needs it at once, and half of the long matches of source code end there —
@@ -889,6 +907,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       // ---- positions with six or more bytes of a byte run ahead: the frontier comes from the run table -----------------
       if (mine && has4 && isrun) {
          alive = false;
+         ZH_MF_SUBTIC();
          const uint32_t c = first4 & 0xffu;
          const uint32_t r = LDS_WIN ? zh_run_length(win, i, W, maxlen) : zh_run_length(gwin, i, W, maxlen);   // run bytes left, clamped to maxlen
          // a candidate with r_p run bytes left matches min(r, r_p) bytes unless r_p == r. Nearest first:
@@ -915,6 +934,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
             //     Four table entries are fetched per round trip.
             //     Only until the record reaches r: from then on the second order takes over (below).
             uint32_t j = a > g0 ? a - 1 : g0;
+            ZH_MF_SUBLAP(5);
             while (j > g0 && cur < r) {
                const uint32_t nf = min(4u, j - g0);
                uint32_t es[4], ls[4];
@@ -946,15 +966,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
                      if (i - p <= ZH_MAX_DIST && (cur < r || win[p + cur] == win[i + cur])) {   // cheap reject: it must agree at byte `cur`
                         uint32_t l = r;
                         if (LDS_WIN) {
-                           while (l < maxlen) {
-                              const uint32_t x = zh_load32_at(lwin32, p + l) ^ zh_load32_at(lwin32, i + l);
-                              if (x) {
-                                 l += (uint32_t)(__ffs((int)x) - 1) >> 3;
-                                 break;
-                              }
-                              l += 4;
-                           }
-                           l = min(l, maxlen);
+                           l = zh_mf_extend_lane(lwin32, p, i, l, maxlen);
                         }
                         else {
                            while (l < maxlen && win[p + l] == win[i + l]) l++;
@@ -970,6 +982,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
             }
             // (3) a match longer than r: only the position with exactly r run bytes left of an earlier run (of at least r bytes)
             //     that is followed by the same byte as this run. Those runs are contiguous in the second order of the table.
+            ZH_MF_SUBLAP(7);
             if (cur >= r && cur < maxlen && a > g0) {
                const uint32_t *RS2 = runs + 2 * Q + 513, *RL2 = RS2 + Q;
                const uint32_t X = win[i + r];                              // cur < maxlen: i + r is inside the window
@@ -982,17 +995,31 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
                   else
                      hi = mid;
                }
+               ZH_MF_SUBLAP(14);
                uint32_t j2 = lo;                                           // entries below j2: runs that start earlier (or end in a smaller byte)
+               // (the table is in HBM/L2: the entries of the round after this one are requested before this round is looked at — on
+               // indented source code this loop is two thirds of the byte-run path, hundreds of runs of spaces followed by the same letter)
+               uint32_t nss[4], nls[4];
+#define ZH_MF_RUNS2_REQUEST()                                    \
+   do {                                                          \
+      const uint32_t nf_ = min(4u, j2 - g0);                     \
+      _Pragma("unroll") for (uint32_t u = 0; u < 4; u++) {       \
+         const uint32_t jj = j2 - 1 - min(u, nf_ - 1);           \
+         nss[u] = RS2[jj];                                       \
+         nls[u] = RL2[jj];                                       \
+      }                                                          \
+   } while (0)
+               if (j2 > g0) ZH_MF_RUNS2_REQUEST();
                while (j2 > g0 && cur < maxlen) {
                   const uint32_t nf = min(4u, j2 - g0);
                   uint32_t ss[4], ls[4];
 #pragma unroll
                   for (uint32_t u = 0; u < 4; u++) {
-                     const uint32_t jj = j2 - 1 - min(u, nf - 1);
-                     ss[u] = RS2[jj];
-                     ls[u] = RL2[jj];
+                     ss[u] = nss[u];
+                     ls[u] = nls[u];
                   }
                   j2 -= nf;
+                  if (j2 > g0) ZH_MF_RUNS2_REQUEST();
 #pragma unroll
                   for (uint32_t u = 0; u < 4; u++) {
                      if (u >= nf || cur >= maxlen) break;
@@ -1006,15 +1033,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
                         if (i - p <= ZH_MAX_DIST && win[p + cur] == win[i + cur]) {   // cheap reject: it must agree at byte `cur`
                            uint32_t l = r;
                            if (LDS_WIN) {
-                              while (l < maxlen) {
-                                 const uint32_t x = zh_load32_at(lwin32, p + l) ^ zh_load32_at(lwin32, i + l);
-                                 if (x) {
-                                    l += (uint32_t)(__ffs((int)x) - 1) >> 3;
-                                    break;
-                                 }
-                                 l += 4;
-                              }
-                              l = min(l, maxlen);
+                              l = zh_mf_extend_lane(lwin32, p, i, l, maxlen);
                            }
                            else {
                               while (l < maxlen && win[p + l] == win[i + l]) l++;
@@ -1028,6 +1047,8 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
                      }
                   }
                }
+#undef ZH_MF_RUNS2_REQUEST
+               ZH_MF_SUBLAP(15);
             }
          }
       }
