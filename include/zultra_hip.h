@@ -86,7 +86,8 @@ const char *zultra_hip_last_error(const zultra_hip_ctx_t *ctx);
 void zultra_hip_ctx_info(const zultra_hip_ctx_t *ctx, int *device, uint32_t *max_block_size, uint32_t *max_blocks, size_t *device_bytes);
 /* Device bytes zultra_hip_create(device, max_block_size, max_blocks) will allocate, computed from the same layout without
  * allocating: callers size their batches against the memory they want to spend. */
-size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max_blocks);
+size_t zultra_hip_context_bytes_on(int device, uint32_t max_block_size, uint32_t max_blocks);
+size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max_blocks);   /* ... on the calling thread's current device */
 
 /* Pinned host staging owned by the context (which: 0 = input side, 1 = output side), at least `size` bytes, valid until
  * the context is destroyed or a larger size is requested. The streaming API stages caller data through these: copies

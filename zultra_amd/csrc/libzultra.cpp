@@ -592,7 +592,7 @@ static zultra_status_t stream_init_sized(zultra_stream_t *s, unsigned flags, uns
    }
    // device bytes per context (MI355X has 288 GB): sized from the layout the context will really allocate
    const uint64_t budget = 24ull << 30;
-   while (batch_blocks > 1 && (uint64_t)zultra_hip_context_bytes(bs, batch_blocks) > budget) batch_blocks = batch_blocks - (batch_blocks + 7) / 8;
+   while (batch_blocks > 1 && (uint64_t)zultra_hip_context_bytes_on(zh_pick_device(), bs, batch_blocks) > budget) batch_blocks = batch_blocks - (batch_blocks + 7) / 8;
    c->batch_blocks = batch_blocks;
    c->blocks = (zultra_hip_block_t *)s->zalloc(s->opaque, batch_blocks, (unsigned)sizeof(zultra_hip_block_t));
    c->raw_off = (uint64_t *)s->zalloc(s->opaque, batch_blocks, (unsigned)sizeof(uint64_t));
@@ -961,7 +961,7 @@ static size_t memory_compress_lanes(const unsigned char *pIn, size_t nIn, unsign
    size_t per = (M.total_blocks + devices.size() - 1) / devices.size();
    const uint64_t budget = 24ull << 30;
    if (per > 8192) per = 8192;
-   while (per > 1 && (uint64_t)zultra_hip_context_bytes(bs, (uint32_t)per) > budget) per -= (per + 7) / 8;
+   while (per > 1 && (uint64_t)zultra_hip_context_bytes_on(devices[0], bs, (uint32_t)per) > budget) per -= (per + 7) / 8;
    for (size_t b = 0; b < M.total_blocks; b += per) M.jobs.push_back(MemJob{b, M.total_blocks - b < per ? M.total_blocks - b : per, 0});
    const size_t lanes = M.jobs.size() < devices.size() ? M.jobs.size() : devices.size();
    for (size_t l = 0; l < lanes; l++) {

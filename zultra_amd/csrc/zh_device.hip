@@ -94,8 +94,8 @@ struct zultra_hip_ctx_s {
    zh_sbstate_t *d_states;
    uint2 *d_taskmap;
    uint2 *d_taskinfo;           // per task: its range and whether zh_list_huge listed it (zh_parse_chain.h)
-   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: per run [0..3] tasks, [40..43] / [4..7] / [12..15] very long / long / other tasks listed for zh_parse_chain, [8..11] their positions,
-                                                     // [16 + 4 run + pass] its tickets, [32 + 4 run + pass] tickets of a persistent zh_parse_tasks
+   uint32_t *d_ntasks, *d_hist_part, *d_task_bits;   // d_ntasks: the runs' counters, ZH_CNT_STRIDE words per run, fields ZH_CNT_* (zh_parse.h): tasks, listed tasks by
+                                                     // length class and their positions, cut tasks / segments, the tickets of the persistent kernels per pass
    uint32_t *h_ntasks;          // pinned mirror, read after the batch (zultra_hip_last_stats)
    uint32_t *d_hugelist;
    uint4 *d_segtasks;           // tasks cut into speculative segments (zh_parse_chain.h): per max-block seg_tasks_per_block entries
@@ -671,9 +671,11 @@ extern "C" void zultra_hip_ctx_info(const zultra_hip_ctx_t *c, int *device, uint
    if (device_bytes) *device_bytes = c->device_bytes;
 }
 
-// Device bytes a context for batches of `max_blocks` max-blocks of `max_block_size` bytes allocates: the same strides and the
-// same list of arrays as zh_create / zh_create_buffers (the layout comment at the top of this file), without allocating.
-extern "C" size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max_blocks) {
+// Device bytes a context on `device` for batches of `max_blocks` max-blocks of `max_block_size` bytes allocates: the strides and the list
+// of arrays of zh_create / zh_create_buffers (the layout comment at the top of this file) restated without allocating — a second
+// formula, held to the real layout by test_context_cache_and_size_estimate (-5 % .. +10 %); files mode (one sub-block per block)
+// allocates less than this. The device matters for one term only: the matchfinder's payload, per compute unit.
+extern "C" size_t zultra_hip_context_bytes_on(int device, uint32_t max_block_size, uint32_t max_blocks) {
    const uint64_t N = zh_clamp_block(max_block_size), B = max_blocks;
    const uint64_t W = N + ZH_HISTORY;
    const uint64_t seg_W = W <= ZH_SEG_WINDOW ? W : (uint64_t)ZH_SEG_WINDOW;
@@ -693,8 +695,8 @@ extern "C" size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max
    bytes += B * (S * (sizeof(zh_seg_t) + 8) + sizeof(zh_block_t) + cpb * 12 + (ZH_MAX_SPLITS + 1) * 4 + 6 * 4) + 8192;
    {
       // payload of the matchfinder's refining passes: per run (ZULTRA_HIP_STREAMS) and persistent workgroup (one per CU)
-      int cus = 0, dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
       const char *e = getenv("ZULTRA_HIP_STREAMS");
       const uint64_t lanes = (uint64_t)max(1, min((int)ZH_MAX_RUNS, e ? atoi(e) : 4));
       bytes += lanes * min((uint64_t)cus, B * S) * 3 * sort_stride * 4;
@@ -703,6 +705,11 @@ extern "C" size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max
       bytes += B * (seg_tasks * sizeof(uint4) + seg_items * (2 * sizeof(uint2) + 2 * ZH_VEC * sizeof(int16_t)));
    }
    return (size_t)bytes;
+}
+extern "C" size_t zultra_hip_context_bytes(uint32_t max_block_size, uint32_t max_blocks) {   // on the calling thread's current device
+   int dev = 0;
+   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+   return zultra_hip_context_bytes_on(dev, max_block_size, max_blocks);
 }
 extern "C" size_t zultra_hip_data_capacity(const zultra_hip_ctx_t *c) { return c ? c->data_cap : 0; }
 
