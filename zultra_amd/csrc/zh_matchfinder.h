@@ -573,7 +573,9 @@ __device__ __forceinline__ uint32_t zh_trigram(const uint8_t *p) {
 }
 
 // 4 bytes at an arbitrary byte offset x of a dword-aligned buffer: two aligned dword reads + funnel shift
-// (the buffer must be readable up to 7 bytes past x).
+// (the buffer must be readable up to 7 bytes past x). ZH_MF_UNALIGNED32 / 128 = 1 (A/B builds, tools/build_variant.sh): the hardware's
+// reads at any byte address instead (zh_platform.h) — measured on gfx950: the 4-byte one is slower than this (frontier 6.6 -> 10.3 ms
+// per 50 MB), the 16-byte one the same as five words.
 #ifndef ZH_MF_UNALIGNED32
 #define ZH_MF_UNALIGNED32 0
 #endif
