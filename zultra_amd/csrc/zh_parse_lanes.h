@@ -70,7 +70,10 @@ struct alignas(16) zh_lp_ws_t {
          uint32_t pmin[ZH_LP_NL][ZH_LP_C];      // [L - 3][piece, see ZH_LP_PCOL]: prefix minimum P(L) of this step
          uint32_t stage0[ZH_LP_C][4][4];        // the batch: [piece][entry][slot 0..3] of the entries' rows,
          uint32_t stage1[ZH_LP_C][4][4];        //            slots 4..7,
-         uint16_t stagef[ZH_LP_C][4][8];        //            per slot stored with length >= 40 the cost behind it,
+         union {
+            uint16_t stagef[ZH_LP_C][4][8];     //            per slot stored with length >= 40 the cost behind it
+            uint4 stagef4[ZH_LP_C][4];          //            (written 16 bytes at a time),
+         };
          uint32_t stageb[ZH_LP_C][4];           //            the entries' bytes
          uint32_t outp[2][ZH_LP_C][4];          // the parse entries of two batches (by batch parity) ...
          uint32_t outc[2][ZH_LP_C][4];          // ... and their costs
@@ -306,7 +309,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
                fv.z = ZH_LP_FAR_PICK(g0, h1.x, pos_, cur.end) | (ZH_LP_FAR_PICK(g1, h1.y, pos_, cur.end) << 16);
                fv.w = ZH_LP_FAR_PICK(g2, h1.z, pos_, cur.end) | (ZH_LP_FAR_PICK(g3, h1.w, pos_, cur.end) << 16);
             }
-            *(uint4 *)&ws.stagef[piece][q][0] = fv;
+            ws.stagef4[piece][q] = fv;
          }
          old_hi = cur_hi;
          cur_hi = zh_ballot((h1.x & 0xffffu) >= ZH_MIN_MATCH) != 0;
