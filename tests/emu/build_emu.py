@@ -19,6 +19,7 @@ def build(force=False):
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-DZH_TOK_CHUNK=1024u", "-DZH_CUT_LEN=512u", "-DZH_CUT_WARM=288u",
            "-Wno-unknown-pragmas", "-I", HERE, "-I", CSRC, "-x", "c++", os.path.join(CSRC, "zh_device.hip"),
            os.path.join(CSRC, "libzultra.cpp"), "-o"]
+    cmd[1:1] = os.environ.get("ZH_EMU_DEFINES", "").split()   # extra -D switches (A/B of compile-time variants under the emulator)
     tmp = "%s.%d.tmp" % (OUT, os.getpid())   # several test processes may build at once: each writes its own file, the rename is atomic
     subprocess.run(cmd + [tmp], check=True)
     os.replace(tmp, OUT)

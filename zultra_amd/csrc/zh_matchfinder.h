@@ -42,6 +42,9 @@
 #ifndef ZH_MF_UNROLL
 #define ZH_MF_UNROLL 4u              // 64-element steps of a sort pass whose loads are issued together
 #endif
+#ifndef ZH_MF_STEP
+#define ZH_MF_STEP 4u                // candidates a lane looks at per step of the class walk (a divisor of 64)
+#endif
 #define ZH_MF_HEAD 0x80000000u       // sorted entry: first position of its 6-gram class
 #define ZH_MF_POS_MASK 0x7fffffffu
 #define ZH_MF_SENTINEL 0xffffffffu   // "no entry": marked, and farther than any legal distance
@@ -1074,92 +1077,90 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       // the lengths worked out without branches. A probe taken before `cur` grew stays a valid pre-filter.
       while (const uint64_t alive_mask_ = zh_ballot(alive)) {
          ZH_MF_WALK_TOP(alive_mask_);
-         // advance twice: entries c+l-1-2k and c+l-2-2k arrive at lane l; lane 0 takes the next entries below the chunk
-         const uint32_t c1 = zh_wave_shr1(cand, zh_readlane(vec, vi));
-         const uint32_t c2 = zh_wave_shr1(c1, zh_readlane(vec, vi - 1));
-         cand = c2;
-         vi -= 2;
+         // advance ZH_MF_STEP times: entries c+l-1-Nk .. c+l-N-Nk arrive at lane l, nearest first; lane 0 takes the next entries below the chunk
+         uint32_t cs[ZH_MF_STEP], qs[ZH_MF_STEP], ds[ZH_MF_STEP], pbs[ZH_MF_STEP];
+         bool oks[ZH_MF_STEP], vs[ZH_MF_STEP];
+         uint64_t vms[ZH_MF_STEP];
+#pragma unroll
+         for (int k = 0; k < (int)ZH_MF_STEP; k++) {
+            cand = zh_wave_shr1(cand, zh_readlane(vec, vi - k));
+            cs[k] = cand;
+         }
+         vi -= (int)ZH_MF_STEP;
          if (vi < 0) {
             vbase -= 64;
             vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_SENTINEL;
             vi = 63;
          }
-         const uint32_t q1 = c1 & ZH_MF_POS_MASK, q2 = c2 & ZH_MF_POS_MASK;
-         const uint32_t d1 = i - q1, d2 = i - q2;
-         const bool ok1 = alive && d1 <= ZH_MAX_DIST, ok2 = alive && d2 <= ZH_MAX_DIST;     // false for the sentinel too
-         // (lanes that are done, or whose candidate is out of reach, probe offset 0: their position may be the sentinel)
-         const uint32_t a1 = ok1 ? q1 + fo : 0u, a2 = ok2 ? q2 + fo : 0u;
-         const uint32_t pb1 = LDS_WIN ? zh_load32_at(lwin32, a1) : zh_ld32(win + a1);
-         const uint32_t pb2 = LDS_WIN ? zh_load32_at(lwin32, a2) : zh_ld32(win + a2);
-         const bool v1 = ok1 && pb1 == ci, v2 = ok2 && pb2 == ci;
-         const uint64_t vm1 = zh_ballot(v1), vm2 = zh_ballot(v2);
+         // all the 4-byte probes of the step are issued before any is used; nearly every candidate dies here, so the verification
+         // below runs for few lanes (lanes that are done, or whose candidate is out of reach, probe offset 0: their position may be
+         // the sentinel)
+         uint32_t heads = 0;
+         bool okall = alive;
+#pragma unroll
+         for (int k = 0; k < (int)ZH_MF_STEP; k++) {
+            qs[k] = cs[k] & ZH_MF_POS_MASK;
+            ds[k] = i - qs[k];
+            oks[k] = alive && ds[k] <= ZH_MAX_DIST;     // false for the sentinel too
+            const uint32_t ad = oks[k] ? qs[k] + fo : 0u;
+            pbs[k] = LDS_WIN ? zh_load32_at(lwin32, ad) : zh_ld32(win + ad);
+            heads |= cs[k];
+            okall = okall && oks[k];
+         }
+         uint64_t vany = 0;
+#pragma unroll
+         for (int k = 0; k < (int)ZH_MF_STEP; k++) {
+            vs[k] = oks[k] && pbs[k] == ci;
+            vms[k] = zh_ballot(vs[k]);
+            vany |= vms[k];
+         }
          ZH_MF_WALK_PROBED();
-         if (vm1 | vm2) {   // (wave-uniform, and so are the branches on vm1 and vm2: a side without a survivor costs nothing)
-            // the nearer candidate
-            bool rec1 = false;
-            if (vm1) {
-               uint32_t f1[4];
+         if (vany) {   // (wave-uniform, and so are the branches on vms[k]: a candidate without a survivor in any lane costs nothing)
+            bool moved = false;   // a record of this step moved `cur`: the probes above were taken at the old one (still a valid pre-filter)
+#pragma unroll
+            for (int k = 0; k < (int)ZH_MF_STEP; k++) {
+               if (!vms[k]) continue;
+               const bool v = vs[k];
+               const uint32_t q = qs[k];
+               uint32_t f[4];
                if (LDS_WIN)
-                  zh_load128_at(lwin32, v1 ? q1 : 0u, f1);
+                  zh_load128_at(lwin32, v ? q : 0u, f);
                else {
 #pragma unroll
-                  for (uint32_t u = 0; u < 4; u++) f1[u] = zh_ld32(win + (v1 ? q1 : 0u) + 4u * u);
+                  for (uint32_t u = 0; u < 4; u++) f[u] = zh_ld32(win + (v ? q : 0u) + 4u * u);
                }
-               uint32_t l1 = zh_mf_len16(f1, own16);   // (bytes past the window end are garbage, but the lengths are clamped to maxlen)
-               const bool deep1 = v1 && l1 == 16 && maxlen > 16;
-               ZH_MF_WALK_EXT(deep1);
-               if (LDS_WIN)
-                  l1 = zh_mf_length_past16(lwin32, deep1, q1, i, maxlen, own32, l1);
-               else if (deep1)
-                  while (l1 < maxlen && win[q1 + l1] == win[i + l1]) l1++;
-               l1 = min(l1, maxlen);
-               rec1 = v1 && l1 > cur;
-               if (rec1) {
-                  myring[(nm & 7u) * ZH_MF_THREADS] = l1 | (d1 << 16);   // offset 32768 needs all 16 bits
-                  nm++;
-                  cur = l1;
-               }
-            }
-            // the farther one has to beat the record as it stands now. Sixteen bytes or fewer: its length is known. More: where the
-            // record has just moved, four bytes ending at the new record are probed first
-            if (vm2) {
-               uint32_t f2[4];
-               if (LDS_WIN)
-                  zh_load128_at(lwin32, v2 ? q2 : 0u, f2);
-               else {
-#pragma unroll
-                  for (uint32_t u = 0; u < 4; u++) f2[u] = zh_ld32(win + (v2 ? q2 : 0u) + 4u * u);
-               }
-               uint32_t l2 = zh_mf_len16(f2, own16);
-               bool deep2 = v2 && l2 == 16 && maxlen > 16 && cur < maxlen;
-               if (zh_ballot(deep2 && rec1)) {
-                  if (deep2 && rec1) {
-                     const uint32_t f = cur - 3u;
-                     deep2 = LDS_WIN ? zh_load32_at(lwin32, q2 + f) == zh_load32_at(lwin32, i + f) : zh_ld32(win + q2 + f) == zh_ld32(win + i + f);
+               uint32_t l = zh_mf_len16(f, own16);   // (bytes past the window end are garbage, but the lengths are clamped to maxlen)
+               // a candidate has to beat the record as it stands now. Sixteen bytes or fewer: its length is known. More: where the
+               // record has moved since the probe, four bytes ending at the new record are probed first
+               bool deep = v && l == 16 && maxlen > 16 && cur < maxlen;
+               if (k > 0 && zh_ballot(deep && moved)) {
+                  if (deep && moved) {
+                     const uint32_t fn = cur - 3u;
+                     deep = LDS_WIN ? zh_load32_at(lwin32, q + fn) == zh_load32_at(lwin32, i + fn) : zh_ld32(win + q + fn) == zh_ld32(win + i + fn);
                   }
                }
-               ZH_MF_WALK_EXT(deep2);
+               ZH_MF_WALK_EXT(deep);
                if (LDS_WIN)
-                  l2 = zh_mf_length_past16(lwin32, deep2, q2, i, maxlen, own32, l2);
-               else if (deep2)
-                  while (l2 < maxlen && win[q2 + l2] == win[i + l2]) l2++;
-               l2 = min(l2, maxlen);
-               const bool rec2 = v2 && l2 > cur && (l2 < 16u || deep2 || maxlen <= 16u);
-               if (rec2) {
-                  myring[(nm & 7u) * ZH_MF_THREADS] = l2 | (d2 << 16);
+                  l = zh_mf_length_past16(lwin32, deep, q, i, maxlen, own32, l);
+               else if (deep)
+                  while (l < maxlen && win[q + l] == win[i + l]) l++;
+               l = min(l, maxlen);
+               const bool rec = v && l > cur && (l < 16u || deep || maxlen <= 16u);
+               if (rec) {
+                  myring[(nm & 7u) * ZH_MF_THREADS] = l | (ds[k] << 16);   // offset 32768 needs all 16 bits
                   nm++;
-                  cur = l2;
+                  cur = l;
                }
-               rec1 = rec1 || rec2;
+               moved = moved || rec;
             }
-            if (rec1 && cur < maxlen) {
+            if (moved && cur < maxlen) {
                fo = cur - 3;
                ci = LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo);
             }
             ZH_MF_WALK_VERIFIED();
          }
          // the class ends at its head; beyond 32 KiB everything else is farther still; 258 (or the window end) cannot be beaten
-         alive = ok1 && ok2 && !((c1 | c2) & ZH_MF_HEAD) && cur < maxlen;
+         alive = okall && !(heads & ZH_MF_HEAD) && cur < maxlen;
       }
       ZH_MF_LAP(3);
       if (mine) {
