@@ -35,7 +35,7 @@ f = L.L.zultra_hip_lp_profile
 f.argtypes = [C.c_void_p, C.c_int]
 f(None, 1)
 ctx.compress_blocks(d, blocks)
-out = np.zeros(8, dtype=np.uint64)
+out = np.zeros(12, dtype=np.uint64)
 f(out.ctypes.data, 0)
 t = ctx.timing()
 o = [float(x) for x in out]
@@ -43,3 +43,6 @@ print("%s %d bytes: parse %.2f ms (all runs, 4 passes)" % (kind, size, t["parse_
 print("   groups %d, pieces per group %.1f, steps per group %.1f" % (o[3], o[6] / max(1, o[3]), o[0] / max(1, o[3])))
 print("   quads with a position per step %.1f of 16, batches with a second plane %.2f" % (o[1] / max(1, o[0]), 4 * o[7] / max(1, o[0])))
 print("   cycles per step %.0f; per group: setup %.0f, steps %.0f, histogram %.0f cycles" % (o[2] / max(1, o[0]), o[4] / max(1, o[3]), o[2] / max(1, o[3]), o[5] / max(1, o[3])))
+lap = max(1.0, o[8] + o[9] + o[10] + o[11])
+print("   step loop by part (s_memtime laps, which drain the LDS queue: shares, not cycles): staging a batch %.0f %%, stage C (decision) %.0f %%, stage B (window, prefix minima) %.0f %%, stage A (slots, prices) %.0f %%"
+      % (100 * o[8] / lap, 100 * o[9] / lap, 100 * o[10] / lap, 100 * (o[11]) / lap))

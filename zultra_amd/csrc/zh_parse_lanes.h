@@ -56,7 +56,7 @@
 #ifdef ZH_LP_PROFILE
 // probe builds only (tools/lp_profile.py): 0 steps, 1 quad-steps with a position, 2 cycles of the step loops, 3 groups, 4 cycles of the
 // group setup, 5 cycles of the histogram walks, 6 pieces, 7 batches with a second plane
-__device__ unsigned long long zh_lp_prof[8];
+__device__ unsigned long long zh_lp_prof[12];   // 8..11: cycles of the batch staging, stage C, stage B, stage A of the step loop
 #define ZH_LP_COUNT(slot_, n_) do { if (zh_lane() == 0) atomicAdd(&zh_lp_prof[slot_], (unsigned long long)(n_)); } while (0)
 #define ZH_LP_CLOCK() zh_clock()
 #else
@@ -186,6 +186,8 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    const uint64_t tic1 = ZH_LP_CLOCK();
 #ifdef ZH_LP_PROFILE
    uint32_t prof_steps = 0, prof_quads = 0, prof_hi = 0;
+   uint64_t prof_lap[4] = {0, 0, 0, 0}, prof_t = ZH_LP_CLOCK();
+#define ZH_LP_LAP(k_) do { const uint64_t n_ = ZH_LP_CLOCK(); prof_lap[k_] += n_ - prof_t; prof_t = n_; } while (0)
    (void)prof_hi;
 #endif
 
@@ -324,6 +326,9 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
       ZH_LP_FETCH_HI();
       ZH_LP_FETCH(b2, a2, y2);
 
+#ifdef ZH_LP_PROFILE
+      ZH_LP_LAP(0);
+#endif
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {
          // ======== stage A, first half, of entry (cur, j): its slots and its byte ==========================================================
@@ -341,6 +346,9 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
          prof_quads += (uint32_t)zh_popc64(zh_ballot(na.act && q == 0));
 #endif
 
+#ifdef ZH_LP_PROFILE
+         ZH_LP_LAP(3);
+#endif
          // ======== stage C of the entry two before: literal first; a match must be strictly cheaper (:292,:307) =====================
          {
             const uint32_t bestkey = zh_quad_min(min(eb.key0, eb.key1));
@@ -381,6 +389,9 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
             }
          }
 
+#ifdef ZH_LP_PROFILE
+         ZH_LP_LAP(1);
+#endif
          // ======== stage B of the entry before: its window, one position down; then the prefix minima over the lengths, P(L) = min over
          //          3 <= k <= L of (cost[pos + k] + price(k)) << 9 | (39 - k): the lane's own ten, then the minimum of the lanes below it ====
          zh_lp_b_t nb;
@@ -430,6 +441,9 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
             nb.fresh = ea.fresh;
          }
 
+#ifdef ZH_LP_PROFILE
+         ZH_LP_LAP(2);
+#endif
          // ======== stage A, second half: the slots' distance prices, the literal's price; for a slot stored with length >= 40 the
          //          price of its clamped length and the cost behind it ========================================================================
          {
@@ -478,6 +492,8 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    ZH_LP_COUNT(0, prof_steps);
    ZH_LP_COUNT(1, prof_quads);
    ZH_LP_COUNT(7, prof_hi);
+   for (int k = 0; k < 4; k++) ZH_LP_COUNT(8 + k, prof_lap[k]);
+#undef ZH_LP_LAP
 #endif
    ZH_LP_COUNT(2, ZH_LP_CLOCK() - tic1);
    const uint64_t tic2 = ZH_LP_CLOCK();
