@@ -16,7 +16,7 @@ def build(force=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-DZH_TOK_CHUNK=1024u", "-DZH_CUT_LEN=512u", "-DZH_CUT_WARM=288u",
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-DZH_TOK_CHUNK=1024u", "-DZH_CUT_LEN=512u", "-DZH_CUT_WARM=288u", "-DZH_MFL_CAP_LIMIT=512u",
            "-Wno-unknown-pragmas", "-I", HERE, "-I", CSRC, "-x", "c++", os.path.join(CSRC, "zh_device.hip"),
            os.path.join(CSRC, "libzultra.cpp"), "-o"]
     cmd[1:1] = os.environ.get("ZH_EMU_DEFINES", "").split()   # extra -D switches (A/B of compile-time variants under the emulator)

@@ -174,6 +174,22 @@ inline void zh_lockstep_sync() {
    zh_emu::collect(0, [] { return (uint64_t)0; });
 }
 
+inline uint64_t zh_ballot(bool p);
+inline unsigned zh_lane();
+inline uint64_t zh_peers8(uint32_t d, bool valid) {
+   uint64_t peers = zh_ballot(valid);
+   for (int bit = 0; bit < 8; bit++) {
+      const bool one = (d >> bit) & 1u;
+      const uint64_t m = zh_ballot(valid && one);
+      peers &= one ? m : ~m;
+   }
+   return peers;
+}
+inline uint32_t zh_rank_below(uint64_t m) { return (uint32_t)__builtin_popcountll(m & ((1ull << zh_lane()) - 1ull)); }
+inline void zh_lockstep_point() {
+   zh_emu::collect(0, [] { return (uint64_t)0; });
+}
+
 inline unsigned zh_lane() { return (unsigned)zh_emu::g_cur & 63u; }
 inline uint64_t zh_ballot(bool p) {
    using namespace zh_emu;
@@ -291,6 +307,11 @@ inline int atomicAdd(int *p, int v) {
 inline uint32_t atomicMax(uint32_t *p, uint32_t v) {
    uint32_t o = *p;
    if (v > o) *p = v;
+   return o;
+}
+inline uint32_t atomicMin(uint32_t *p, uint32_t v) {
+   uint32_t o = *p;
+   if (v < o) *p = v;
    return o;
 }
 inline uint32_t atomicOr(uint32_t *p, uint32_t v) {

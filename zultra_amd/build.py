@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzultra_amd.so")
 CLI = os.path.join(HERE, "zultra_amd_cli")
 SOURCES = ["zh_device.hip", "libzultra.cpp"]
-HEADERS = ["zh_platform.h", "zh_common.h", "zh_matchfinder.h", "zh_huffman.h", "zh_split.h", "zh_parse.h", "zh_parse_chain.h", "zh_parse_lanes.h", "zh_encode.h", "zh_stitch.h"]
+HEADERS = ["zh_platform.h", "zh_common.h", "zh_matchfinder.h", "zh_mf_group_lds.h", "zh_huffman.h", "zh_split.h", "zh_parse.h", "zh_parse_chain.h", "zh_parse_lanes.h", "zh_encode.h", "zh_stitch.h"]
 
 
 def hipcc_path():

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -77,6 +78,7 @@ struct zultra_hip_ctx_s {
    std::vector<zh_seg_t> segs;
    std::vector<uint32_t> seg_base;
    zh_match_t *d_match;
+   uint32_t mf_lds_cap;         // zh_mf_group: chunk size of the refinement in LDS, 0 = through HBM
    uint32_t *d_pay;             // zh_mf_group: 3 x sort_stride words per persistent workgroup (payload of the refining sort passes)
    uint32_t *d_longest;         // (round 2: a copy of slot 0 of every match row; no longer written — its readers take the rows)
    uint32_t *d_tok_pos;
@@ -231,6 +233,37 @@ __global__ void __launch_bounds__(64) zh_selftest_kernel(uint32_t seed, uint32_t
          if (zh_load32_any(vb + o) != w[0]) errors++;
          const zh_u128_any_t q = zh_load128_any(vb + o);
          if (q.x != w[0] || q.y != w[1] || q.z != w[2] || q.w != w[3]) errors++;
+      }
+      {
+         // Returning LDS atomics hand out their values in lane order among the lanes that meet at an address, and in program order between
+         // instructions: the stable counting passes of the matchfinder take a lane's place among the lanes of its digit from one of them
+         // (zh_mf_group_lds.h, zh_mf_sort_pass). Digits from alphabets of 1 to 256 symbols, plain counters and two 16-bit counters to a word.
+         __shared__ uint32_t cnt32[256], cnt16[128];
+         for (uint32_t k = lane; k < 256; k += 64) cnt32[k] = 0;
+         for (uint32_t k = lane; k < 128; k += 64) cnt16[k] = 0;
+         zh_sync();
+         const uint32_t alpha = 1u << (round % 9u);
+         for (uint32_t step = 0; step < 3; step++) {
+            const uint32_t y = (x ^ (step * 0x9e3779b9u)) * 2654435761u;
+            const uint32_t d = ((y >> 11) % alpha) * (256u / alpha);
+            const bool valid = (y & 0x7u) != 0;
+            uint32_t got32 = 0, got16 = 0;
+            if (valid) {
+               got32 = zh_atomic_add_lds(&cnt32[d], 1u);
+               got16 = (zh_atomic_add_lds(&cnt16[d >> 1], 1u << ((d & 1u) << 4)) >> ((d & 1u) << 4)) & 0xffffu;
+            }
+            zh_lockstep_point();
+            v[lane] = valid ? d : 0xffffffffu;
+            zh_sync();
+            uint32_t below = 0, all = 0;
+            for (uint32_t k = 0; k < 64; k++) {
+               if (v[k] == d && k < lane) below++;
+               if (v[k] == d) all++;
+            }
+            // the counter held `all` less before this step's lanes arrived; this lane is the (below)-th of them
+            if (valid && (got32 != cnt32[d] - all + below || got16 != got32)) errors++;
+            zh_sync();
+         }
       }
       zh_sync();
    }
@@ -454,6 +487,22 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    const uint64_t B = c->max_blocks, N = c->max_block;
    ZH_CHECK(c, hipSetDevice(c->device));
    {
+      // once per device and process: the wave primitives and the LDS behaviour the kernels rely on (zh_selftest_kernel) — a device that
+      // fails gets no context (the library has no other path)
+      static std::mutex checked_mutex;
+      static uint64_t checked_ok[4] = {0, 0, 0, 0};
+      std::lock_guard<std::mutex> lock(checked_mutex);
+      const uint32_t dv = (uint32_t)c->device & 255u;
+      if (!((checked_ok[dv >> 6] >> (dv & 63u)) & 1ull)) {
+         const int bad = zultra_hip_selftest();
+         if (bad != 0) {
+            snprintf(c->err, sizeof(c->err), "device %d fails the self-check of the wave and LDS primitives (%d)", c->device, bad);
+            return -1;
+         }
+         checked_ok[dv >> 6] |= 1ull << (dv & 63u);
+      }
+   }
+   {
       int n = 0;
       if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || n <= 0) n = 256;
       c->total_cus = (uint32_t)n;
@@ -496,6 +545,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->parse_lanes = pl ? atoi(pl) : 1;
       const char *lw = getenv("ZULTRA_HIP_LANE_WAVES");
       c->lane_waves = lw ? (uint32_t)max(1, min(16, atoi(lw))) : 12u;
+      const char *mfl = getenv("ZULTRA_HIP_MF_CAP");   // elements per chunk of zh_mf_group's refinement in LDS (zh_mf_group_lds.h); 0: rounds 1-3's passes through HBM (A/B runs)
+      c->mf_lds_cap = mfl ? (uint32_t)max(0, atoi(mfl)) : (uint32_t)ZH_MFL_CAP_LIMIT;
       const char *mfp = getenv("ZULTRA_HIP_MF_CUS");   // share of the CUs the matchfinder's persistent workgroups take, in percent (tuning experiments)
       c->mf_cu_pct = mfp ? (uint32_t)max(1, min(100, atoi(mfp))) : 100u;
       const char *sg = getenv("ZULTRA_HIP_STAGGER");   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group (default), 3 zh_mf_frontier, 4 the splitter
@@ -805,7 +856,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    const zh_match_t *match = c->d_match + (uint64_t)b0 * c->match_stride;
    // (counters, payload slots and the copies of the results are the caller's, on the stream the runs fork from: zh_enqueue_files)
    ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), sa, sb, p3, rn, c->sort_stride, c->run_stride, 0, nb,
-             ctr + (size_t)nb * 2 + 1, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride);
+             ctr + (size_t)nb * 2 + 1, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride, c->mf_lds_cap);
    ZH_CHECK(c, hipEventRecord(c->lane_ev[k][2], st));   // the next run's matchfinder starts here
    // (segment descriptors carry batch-wide input indices: the rows go to d_match + input * match_stride)
    ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), (const uint32_t *)sa, (const uint2 *)p3,
@@ -1064,7 +1115,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       // token bits are ORed into the payload slots: cleared here, long before stage 3 needs them (the fill runs next to the matchfinder)
       ZH_CHECK(c, hipMemsetAsync(c->d_payload + (uint64_t)b0 * c->slot_stride, 0, (size_t)nb * c->slot_stride, st));
       ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, rn, c->sort_stride, c->run_stride, mf_stop, nsg,
-                ctr + (size_t)nsg * 2 + 1, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride);
+                ctr + (size_t)nsg * 2 + 1, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride, c->mf_lds_cap);
       ZH_CHECK(c, hipEventRecord(ev[2], st));
       if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
       // (segment descriptors carry batch-wide block indices: the rows go to d_match + block * match_stride)
@@ -1412,6 +1463,17 @@ extern "C" int zultra_hip_mf_profile(unsigned long long *out, int reset) {
    if (reset) {
       unsigned long long z[16] = {0};
       if (hipMemcpyToSymbol(HIP_SYMBOL(zh_mf_prof), z, sizeof(z)) != hipSuccess) return -1;
+   }
+   return 0;
+}
+#endif
+
+#ifdef ZH_MFG_PROFILE
+extern "C" int zultra_hip_mfg_profile(unsigned long long *out, int reset) {
+   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(zh_mfg_prof), sizeof(zh_mfg_prof)) != hipSuccess) return -1;
+   if (reset) {
+      unsigned long long z[32] = {0};
+      if (hipMemcpyToSymbol(HIP_SYMBOL(zh_mfg_prof), z, sizeof(z)) != hipSuccess) return -1;
    }
    return 0;
 }

@@ -50,7 +50,8 @@
 #define ZH_MF_SENTINEL 0xffffffffu   // "no entry": marked, and farther than any legal distance
 
 #define ZH_MF_NONE 0xffffffffu       // prev.x: no earlier occurrence of the trigram
-#define ZH_MF_GROUP_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + 2 * ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1 + 256) * 4)   // dynamic LDS bytes of zh_mf_group: window, two counter tables, small variables, 256 cursors
+#define ZH_MF_GROUP_LDS 163840u        // dynamic LDS bytes of zh_mf_group: all of the CU's. Window, two counter tables, small variables, 256 cursors for the
+                                      // passes through HBM ((ZH_MF_LDS_WINDOW / 4 + 4 + 2 * ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1 + 256) * 4 bytes); the rest for the chunks of zh_mf_group_lds.h
 #define ZH_MF_FRONTIER_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + 8 * ZH_MF_THREADS + 1) * 4)              // ... of zh_mf_frontier
 #define ZH_MF_HELP_WINDOW 4096u       // zh_mf_frontier: a workgroup out of tickets looks at the last 4096 segments for one to help
 #ifndef ZH_MF_HELP_MIN
@@ -92,6 +93,8 @@ __device__ inline void zh_stage_window(uint32_t *lwin32, const uint8_t *gwin, ui
 // NEXT >= 0: count the digits of pass mode NEXT into hist_next the same way (M_next = number of elements this pass writes).
 __device__ __forceinline__ uint32_t zh_mf_slice(uint32_t M) { return (((M + ZH_MF_WAVES - 1) / ZH_MF_WAVES) + 63) & ~63u; }
 
+// MODE 4: byte 2 likewise (a class of the bigram order that is refined through HBM, zh_mf_group_lds.h). MODE 10/11: the bigram order —
+// 10 reads the identity permutation, digit = byte 1, and writes position | byte 0 << 24; 11 takes its digit from there and writes the position.
 // MODE 8/9: the elements are indices into the run table (aux_rs = run starts, aux_rl = run lengths): digit = the byte that follows the
 // run (0 where the run reaches the window end) / the run's byte. MODE 8 with src == nullptr reads the identity permutation.
 // PAY: the elements carry a payload through the pass — 1: one word (psrc -> pdst), 2: two words (psrc, qsrc -> the pairs pdst2).
@@ -143,7 +146,15 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
          e = src[idx];                                                                              \
          d = gwin[aux_rs[e]];                                                                       \
       }                                                                                             \
-      else { /* MODE 5/6/7: byte 3/4/5 of the string at e; strings that end before it are dropped */ \
+      else if (MODE == 10) {                                                                        \
+         e = (idx) | ((uint32_t)gwin[idx] << 24);                                                   \
+         d = gwin[(idx) + 1];                                                                       \
+      }                                                                                             \
+      else if (MODE == 11) {                                                                        \
+         e = src[idx];                                                                              \
+         d = e >> 24;                                                                               \
+      }                                                                                             \
+      else { /* MODE 4/5/6/7: byte 3/4/5 of the string at e; strings that end before it are dropped */ \
          e = src[idx];                                                                              \
          d = (e + (MODE - 2) < W) ? (uint32_t)gwin[e + (MODE - 2)] : 0xffffffffu;                   \
       }                                                                                             \
@@ -154,6 +165,8 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
    do {                                                                   \
       if (MODE == 0)                                                      \
          e = (idx);                                                       \
+      else if (MODE == 10)                                                \
+         e = (idx) | ((uint32_t)gwin[idx] << 24);                         \
       else if (MODE == 8)                                                 \
          e = src ? src[idx] : (idx);                                      \
       else                                                                \
@@ -171,6 +184,10 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
       }                                                                                             \
       else if (MODE == 9)                                                                           \
          d = gwin[aux_rs[e]];                                                                       \
+      else if (MODE == 10)                                                                          \
+         d = gwin[(idx) + 1];                                                                       \
+      else if (MODE == 11)                                                                          \
+         d = e >> 24;                                                                               \
       else                                                                                          \
          d = (e + (MODE - 2) < W) ? (uint32_t)gwin[e + (MODE - 2)] : 0xffffffffu;                   \
    } while (0)
@@ -238,8 +255,8 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
    for (uint32_t tile0 = 0; tile0 < M; tile0 += tile) {
       const uint32_t base4 = tile0 + wave * 64u * ZH_MF_UNROLL;
       uint32_t e4[ZH_MF_UNROLL], d4[ZH_MF_UNROLL], p4[ZH_MF_UNROLL], q4[ZH_MF_UNROLL];
-      uint64_t peers4[ZH_MF_UNROLL];
       for (uint32_t k = lane; k < 256; k += 64) hist[wave * 256 + k] = 0;
+      zh_lockstep_point();
 #pragma unroll
       for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {
          const uint32_t idx = base4 + u * 64 + lane;
@@ -281,20 +298,21 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
             }
          }
       }
-      // the lanes of a step with the same digit (kept for the scatter); the first of them counts them all
+      // a lane's place among the wave's elements of its digit in this tile: the lanes of a step with the same digit find each other with
+      // eight ballots (zh_peers8); everybody reads the wave's counter of the digit — what the steps before put there — and the first of them
+      // moves it. (A returning LDS atomic per lane would do it in one instruction, and costs a wave a cycle per lane: zh_mf_group_lds.h.)
+      uint32_t o4[ZH_MF_UNROLL];
 #pragma unroll
       for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {
          const uint32_t d = d4[u];
          const bool valid = d != 0xffffffffu;
-         uint64_t peers = zh_ballot(valid);
-         for (int bit = 0; bit < 8; bit++) {
-            const bool one = (d >> bit) & 1u;
-            const uint64_t m = zh_ballot(valid && one);
-            peers &= one ? m : ~m;
-         }
-         peers4[u] = peers;
-         if (valid && (peers & lt_mask) == 0) hist[wave * 256 + d] += (uint32_t)zh_popc64(peers);
-         zh_ballot(true);   // orders the counter update before the next step's (lock-step anyway on the GPU)
+         const uint64_t peers = zh_peers8(d, valid);
+         const uint32_t rank = zh_rank_below(peers);
+         const uint32_t before = valid ? hist[wave * 256 + d] : 0u;
+         zh_lockstep_point();   // (every lane has read the counter before the first of its peers moves it)
+         if (valid && rank == 0) hist[wave * 256 + d] = before + (uint32_t)zh_popc64(peers);
+         zh_lockstep_point();
+         o4[u] = before + rank;
       }
       if (tile0 + tile < M) ZH_MF_REQUEST(tile0 + tile);
       zh_sync_lds();   // (LDS only: the requests above stay in flight)
@@ -312,26 +330,22 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
       for (uint32_t u = 0; u < ZH_MF_UNROLL; u++) {
          const uint32_t e = e4[u], d = d4[u];
          const bool valid = d != 0xffffffffu;
-         const uint64_t peers = peers4[u];
-         const uint32_t slot = valid ? hist[wave * 256 + d] : 0;
-         zh_lockstep_sync();   // every lane has read the cursor before the first of its peers moves it
          if (valid) {
-            const uint32_t out = slot + (uint32_t)zh_popc64(peers & lt_mask);
-            dst[out] = e;
+            const uint32_t out = hist[wave * 256 + d] + o4[u];
+            dst[out] = MODE == 11 ? (e & 0xffffffu) : e;
             if (PAY == 1) pdst[out] = p4[u];
             if (PAY == 2) pdst2[out] = make_uint2(p4[u], q4[u]);
-            if ((peers & lt_mask) == 0) hist[wave * 256 + d] = slot + (uint32_t)zh_popc64(peers);
             if (NEXT >= 0) {
                // the next pass's digit of this element (which wave counts it does not matter: the next pass adds them up)
-               const bool has = NEXT < 5 || e + (uint32_t)(NEXT - 2) < W;
+               const bool has = NEXT < 5 || NEXT == 11 || e + (uint32_t)(NEXT - 2) < W;
                if (has) {
-                  const uint32_t d2 = gwin[e + (NEXT == 1 ? 1u : (NEXT == 2 ? 0u : (uint32_t)(NEXT - 2)))];
+                  const uint32_t d2 = NEXT == 11 ? e >> 24 : (uint32_t)gwin[(e & 0xffffffu) + (NEXT == 1 ? 1u : (NEXT == 2 ? 0u : (uint32_t)(NEXT - 2)))];
                   atomicAdd(&hist_next[wave * 256 + d2], 1u);
                }
             }
          }
-         zh_ballot(true);   // orders the counter update before the next step's read (lock-step anyway on the GPU)
       }
+      zh_lockstep_sync();   // (the next tile zeroes this wave's counters: after these reads)
       // (the next tile's zeroing of this wave's counters comes after these reads in program order; the other waves' are not touched)
    }
 #undef ZH_MF_FETCH
@@ -364,7 +378,21 @@ __device__ __forceinline__ uint32_t zh_run_length(const uint8_t *g, uint32_t q, 
    return l;
 }
 
-__device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin, uint32_t W, uint32_t Qn, uint32_t *T, uint32_t *runs, uint32_t *hist, uint32_t *wave_tot) {
+#ifdef ZH_MFG_PROFILE
+// probe builds only (tools/mfg_profile.py): cycles of thread 0 of every workgroup by phase — 0 window staging and ticket, 1 the two passes through
+// HBM, 2 chunk load and boundary, 3 the four passes of a chunk, 4 its sweep, 5 oversized classes, 6 run starts, 7 first run order,
+// 8 run lengths, 9 second run order, 10 its table; counts — 12 chunks, 13 oversized classes, 14 their entries, 15 segments
+__device__ unsigned long long zh_mfg_prof[32];   // 16..23: inside a pass of a chunk — counting, wait, totals, wait, scan and places, wait, scatter, wait
+#define ZH_MFG_LAP(slot_) do { if (threadIdx.x == 0) { const uint64_t n_ = zh_clock(); atomicAdd(&zh_mfg_prof[slot_], (unsigned long long)(n_ - mfg_t_)); mfg_t_ = n_; } } while (0)
+#define ZH_MFG_COUNT(slot_, n_) do { if (threadIdx.x == 0) atomicAdd(&zh_mfg_prof[slot_], (unsigned long long)(n_)); } while (0)
+#define ZH_MFG_TIC() mfg_t_ = zh_clock()
+#else
+#define ZH_MFG_LAP(slot_)
+#define ZH_MFG_COUNT(slot_, n_)
+#define ZH_MFG_TIC()
+#endif
+
+__device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin, uint32_t W, uint32_t Qn, uint32_t *T, uint32_t *runs, uint32_t *hist, uint32_t *wave_tot, uint64_t &mfg_t_) {
    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const uint32_t Q = zh_runs_q(W);
    uint32_t *RS = runs, *RL = runs + Q, *first = runs + 2 * Q, *end = first + 256, *count = end + 256;
@@ -395,7 +423,9 @@ __device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin,
 #undef ZH_IS_RUN_START
    __threadfence_block();
    __syncthreads();
+   ZH_MFG_LAP(6);
    zh_mf_sort_pass<2>(win, gwin, total, T, RS, hist, wave_tot);   // stable by byte value: digit = gwin[start]
+   ZH_MFG_LAP(7);
    for (uint32_t idx = tid; idx < total; idx += ZH_MF_THREADS) {
       const uint32_t q = RS[idx];
       const uint32_t c = gwin[q];
@@ -413,8 +443,10 @@ __device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin,
    uint32_t *Pa = T + Q, *Pb = T + 2 * Q;
    __threadfence_block();
    __syncthreads();
+   ZH_MFG_LAP(8);
    zh_mf_sort_pass<8>(win, gwin, total, nullptr, Pa, hist, wave_tot, W, nullptr, 0, RS, RL);
    zh_mf_sort_pass<9>(win, gwin, total, Pa, Pb, hist, wave_tot, W, nullptr, 0, RS, RL);
+   ZH_MFG_LAP(9);
    for (uint32_t idx = tid; idx < total; idx += ZH_MF_THREADS) {
       const uint32_t e = Pb[idx];
       const uint32_t st = RS[e], ln = RL[e];
@@ -422,6 +454,7 @@ __device__ inline void zh_mf_build_runs(const uint8_t *win, const uint8_t *gwin,
       RS2[idx] = st | (x << 24);
       RL2[idx] = ln;
    }
+   ZH_MFG_LAP(10);
 }
 
 // The nearest earlier position sharing K bytes (K = 3, 4, 5) with the position at entry idx of the K-gram order X (MK entries) is
@@ -525,54 +558,8 @@ __device__ inline void zh_mf_group_body(const uint8_t *win, const uint8_t *gwin,
       }
    }
    __syncthreads();
-   zh_mf_build_runs(win, gwin, W, Qn, B, runs, hist, wave_tot);   // B is free again: scratch for the run starts
-}
-
-template <bool LDS_WIN>
-__global__ void __launch_bounds__(ZH_MF_THREADS)
-zh_mf_group(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs, uint32_t *sort_a,
-            uint32_t *sort_b, uint2 *prev_all, uint32_t *runs_all, uint64_t sort_stride, uint64_t run_stride, int stop, uint32_t nsegs,
-            uint32_t *ticket, uint32_t *pay_all /* 3 x sort_stride words per workgroup: the payload of the refining passes */) {
-   // All of this kernel's LDS is dynamic (ZH_MF_GROUP_LDS bytes at launch). Measured on gfx950: next to a workgroup with
-   // 128 KiB of STATIC LDS, workgroups of another stream's kernel that use static LDS are not scheduled at all although
-   // they would fit (a 0.3 ms kernel took 6.4 ms); with the allocation made dynamic on either side they run side by side
-   // (tools/probes/corun_probe.hip).
-   ZH_DYN_LDS(dyn_lds);
-   uint32_t *lwin32 = dyn_lds;                                   // ZH_MF_LDS_WINDOW / 4 + 4 words
-   uint32_t *hist = dyn_lds + ZH_MF_LDS_WINDOW / 4 + 4;          // ZH_MF_WAVES x 256
-   uint32_t *wave_tot = hist + ZH_MF_WAVES * 256;                // ZH_MF_WAVES
-   uint32_t &cur_seg = wave_tot[ZH_MF_WAVES];
-   // Persistent workgroups (the host launches one per CU) take segments from a ticket counter. A grid of one workgroup
-   // per segment would keep workgroups of 114 KiB LDS waiting for a CU throughout the kernel, and while such a workgroup
-   // waits the dispatcher holds back the small kernels of the other run's stream (measured: a 0.3 ms kernel took 6.4 ms).
-   for (;;) {
-   __syncthreads();   // the previous segment is done with LDS (and with cur_seg)
-   if (threadIdx.x == 0) cur_seg = atomicAdd(ticket, 1u);
-   __syncthreads();
-   const uint32_t seg = cur_seg;
-   if (seg >= nsegs) return;
-   const zh_seg_t blk = segs[seg];
-   const uint8_t *win = data + blk.win_off;
-   const uint32_t W = blk.prev + blk.n + blk.tail;
-   uint32_t *A = sort_a + (uint64_t)seg * sort_stride;
-   uint32_t *B = sort_b + (uint64_t)seg * sort_stride;
-   uint2 *prev3 = prev_all + (uint64_t)seg * sort_stride;
-   uint32_t *runs = runs_all + (uint64_t)seg * run_stride;
-   const uint8_t *gwin = win;
-   if (LDS_WIN) {
-      zh_stage_window(lwin32, win, W);
-      gwin = (const uint8_t *)lwin32;
-   }
-   zh_mf_group_body(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, pay_all + (uint64_t)blockIdx.x * 3u * sort_stride, sort_stride, runs, hist, wave_tot,
-                    stop);
-   }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// zh_mf_frontier
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t zh_trigram(const uint8_t *p) {
-   return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+   uint64_t mfg_t_ = 0;
+   zh_mf_build_runs(win, gwin, W, Qn, B, runs, hist, wave_tot, mfg_t_);   // B is free again: scratch for the run starts
 }
 
 // 4 bytes at an arbitrary byte offset x of a dword-aligned buffer: two aligned dword reads + funnel shift
@@ -593,6 +580,63 @@ __device__ __forceinline__ uint32_t zh_load32_at(const uint32_t *w32, uint32_t x
    return zh_funnel(hi, lo, x * 8u);   // (the shift counts modulo 32)
 #endif
 }
+#include "zh_mf_group_lds.h"
+
+// lds_cap: elements per chunk of the in-LDS refinement (zh_mf_group_lds.h; the layout may allow fewer); 0: rounds 1-3's six passes through HBM
+template <bool LDS_WIN>
+__global__ void __launch_bounds__(ZH_MF_THREADS)
+zh_mf_group(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs, uint32_t *sort_a,
+            uint32_t *sort_b, uint2 *prev_all, uint32_t *runs_all, uint64_t sort_stride, uint64_t run_stride, int stop, uint32_t nsegs,
+            uint32_t *ticket, uint32_t *pay_all /* 3 x sort_stride words per workgroup: the payload of the refining passes */, uint32_t lds_cap) {
+   // All of this kernel's LDS is dynamic (ZH_MF_GROUP_LDS bytes at launch). Measured on gfx950: next to a workgroup with
+   // 128 KiB of STATIC LDS, workgroups of another stream's kernel that use static LDS are not scheduled at all although
+   // they would fit (a 0.3 ms kernel took 6.4 ms); with the allocation made dynamic on either side they run side by side
+   // (tools/probes/corun_probe.hip).
+   ZH_DYN_LDS(dyn_lds);
+   uint32_t *lwin32 = dyn_lds;                                   // ZH_MF_LDS_WINDOW / 4 + 4 words
+   uint32_t *hist = dyn_lds + ZH_MF_LDS_WINDOW / 4 + 4;          // ZH_MF_WAVES x 256
+   uint32_t *wave_tot = hist + ZH_MF_WAVES * 256;                // ZH_MF_WAVES
+   uint32_t &cur_seg = wave_tot[ZH_MF_WAVES];
+   // Persistent workgroups (the host launches one per CU) take segments from a ticket counter. A grid of one workgroup
+   // per segment would keep workgroups of 114 KiB LDS waiting for a CU throughout the kernel, and while such a workgroup
+   // waits the dispatcher holds back the small kernels of the other run's stream (measured: a 0.3 ms kernel took 6.4 ms).
+   uint64_t mfg_t_ = 0;
+   ZH_MFG_TIC();
+   for (;;) {
+   __syncthreads();   // the previous segment is done with LDS (and with cur_seg)
+   if (threadIdx.x == 0) cur_seg = atomicAdd(ticket, 1u);
+   __syncthreads();
+   const uint32_t seg = cur_seg;
+   if (seg >= nsegs) return;
+   const zh_seg_t blk = segs[seg];
+   const uint8_t *win = data + blk.win_off;
+   const uint32_t W = blk.prev + blk.n + blk.tail;
+   uint32_t *A = sort_a + (uint64_t)seg * sort_stride;
+   uint32_t *B = sort_b + (uint64_t)seg * sort_stride;
+   uint2 *prev3 = prev_all + (uint64_t)seg * sort_stride;
+   uint32_t *runs = runs_all + (uint64_t)seg * run_stride;
+   const uint8_t *gwin = win;
+   if (LDS_WIN) {
+      zh_stage_window(lwin32, win, W);
+      gwin = (const uint8_t *)lwin32;
+   }
+#ifdef ZH_MF_GROUP_HBM   // A/B builds (tools/build_variant.sh): rounds 1-3's six passes through HBM when the host passes lds_cap = 0 (ZULTRA_HIP_MF_CAP=0)
+   if (!LDS_WIN || !lds_cap)
+      zh_mf_group_body(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, pay_all + (uint64_t)blockIdx.x * 3u * sort_stride, sort_stride, runs, hist, wave_tot,
+                       stop);
+   else
+#endif
+      zh_mf_group_body_lds(win, dyn_lds, W, blk.prev + blk.n, A, B, prev3, pay_all + (uint64_t)blockIdx.x * 3u * sort_stride, sort_stride, runs, hist, wave_tot, stop, lds_cap, mfg_t_);
+   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// zh_mf_frontier
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zh_trigram(const uint8_t *p) {
+   return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+
 // the 16 bytes at byte offset x: five aligned words, all in flight together
 __device__ __forceinline__ void zh_load128_at(const uint32_t *w32, uint32_t x, uint32_t out[4]) {
 #if ZH_MF_UNALIGNED128

@@ -121,14 +121,17 @@ __device__ __forceinline__ uint32_t zh_wave_sum(uint32_t v) {
    v = zh_row_sum(v);
    return zh_readlane(v, 0) + zh_readlane(v, 16) + zh_readlane(v, 32) + zh_readlane(v, 48);
 }
-// exclusive prefix sum over the 64 lanes
+// exclusive prefix sum over the 64 lanes: Hillis-Steele inside each 16-lane row (row_shr 1, 2, 4, 8, lanes without a source add 0), then the
+// row totals travel down with row_bcast:15 / row_bcast:31 — ten DPP adds on the VALU. (Rounds 1-3: six __shfl_up steps, each a
+// ds_bpermute round trip through the LDS crossbar behind the last.)
 __device__ __forceinline__ uint32_t zh_wave_excl_sum(uint32_t v) {
    uint32_t x = v;
-#pragma unroll
-   for (int d = 1; d < 64; d <<= 1) {
-      uint32_t y = (uint32_t)__shfl_up((int)x, d, 64);
-      if ((int)zh_lane() >= d) x += y;
-   }
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // rows 1, 3 += lane 15 of rows 0, 2
+   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // rows 2, 3 += lane 31
    return x - v;
 }
 
@@ -204,6 +207,28 @@ __device__ __forceinline__ void zh_lockstep_sync() {
    __builtin_amdgcn_wave_barrier();
    asm volatile("" ::: "memory");
 }
+
+// The lanes (among those with `valid`) that hold the same 8-bit digit as the calling lane, itself included: one ballot per bit, and per lane
+// the OR over the bits of "lanes whose bit differs from mine" (ballot XOR own bit spread over the word).
+__device__ __forceinline__ uint64_t zh_peers8(uint32_t d, bool valid) {
+   uint32_t dlo = 0, dhi = 0;
+#pragma unroll
+   for (int bit = 0; bit < 8; bit++) {
+      const uint32_t s = (uint32_t)((int32_t)(d << (31 - bit)) >> 31);   // all ones where this lane's bit is set
+      const uint64_t m = __ballot(s != 0);                               // (lanes without `valid` are masked out at the end)
+      dlo |= (uint32_t)m ^ s;
+      dhi |= (uint32_t)(m >> 32) ^ s;
+   }
+   const uint64_t v = __ballot(valid);
+   return v & ~(((uint64_t)dhi << 32) | dlo);
+}
+// number of set bits of m below the calling lane (v_mbcnt_lo / v_mbcnt_hi)
+__device__ __forceinline__ uint32_t zh_rank_below(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+// Between two instructions whose ORDER ACROSS THE LANES matters (a returning LDS atomic per step of an unrolled loop: every lane's step u
+// before any lane's step u + 1): on the GPU a wave executes in lock step and this is nothing — no compiler barrier either, the loads of the
+// steps stay in flight together; the CPU emulator of tests/emu runs a lane until its next collective, and makes this one.
+__device__ __forceinline__ void zh_lockstep_point() {}
 
 __device__ __forceinline__ uint32_t zh_atomic_add_lds(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t zh_atomic_add_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
