@@ -324,7 +324,7 @@ __device__ inline void zh_assign_codes_wave(const uint8_t *len, uint16_t *code, 
 }
 
 // huffencoder.c:279-375: lengths, limit to maxbits, canonical codes. All lanes call. Returns 0 / -1 (uniform).
-__device__ inline int zh_huff_build_wave(const int32_t *freq, uint8_t *len, uint16_t *code, int nsym, int maxbits,
+__device__ __forceinline__ int zh_huff_build_wave(const int32_t *freq, uint8_t *len, uint16_t *code, int nsym, int maxbits,
                                          zh_huff_scratch_t *sc) {
    const int lane = (int)zh_lane();
    zh_huff_lengths_wave(freq, len, nsym, sc);
@@ -368,6 +368,8 @@ struct zh_cl_t {
    int32_t freq[ZH_NCL];
    uint8_t len[ZH_NCL];
    uint16_t code[ZH_NCL];
+   uint32_t keys[ZH_NCL];   // work arrays of the single-lane builds below: in the slice (LDS), not in private memory — arrays indexed at run
+   int32_t A[ZH_NCL];       // time live in scratch, and a kernel with scratch pays a memory round trip per access
 };
 
 __device__ __forceinline__ int zh_cl_order(int k) {
@@ -398,8 +400,8 @@ __device__ inline int zh_small_sorted_keys(const T *value, int nsym, uint32_t *o
 }
 
 __device__ inline void zh_cl_lengths_lane(zh_cl_t *h) {
-   uint32_t keys[ZH_NCL];
-   int32_t A[ZH_NCL];
+   uint32_t *keys = h->keys;
+   int32_t *A = h->A;
    int n = zh_small_sorted_keys(h->freq, ZH_NCL, keys);
    for (int s = 0; s < ZH_NCL; s++) h->len[s] = 0;
    if (n <= 1) {
@@ -412,7 +414,7 @@ __device__ inline void zh_cl_lengths_lane(zh_cl_t *h) {
 }
 
 __device__ inline int zh_cl_build_lane(zh_cl_t *h, int maxbits) {
-   uint32_t keys[ZH_NCL];
+   uint32_t *keys = h->keys;
    zh_cl_lengths_lane(h);
    int n = zh_small_sorted_keys(h->len, ZH_NCL, keys);
    if (n > 0 && (int)(keys[n - 1] >> 9) > maxbits) {

@@ -842,24 +842,24 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
    if (owner && threadIdx.x < 5 && W >= 1 + threadIdx.x) {
       const uint32_t i = W - 1 - threadIdx.x, maxlen = threadIdx.x + 1;
       if (i >= prev && i < Qn) {
-         uint32_t m[3] = {0, 0, 0}, n = 0;
+         uint32_t e3 = 0, e4 = 0, e5 = 0;   // the entries of length 3, 4 and 5 (0: none)
          if (maxlen >= 3) {
             const uint2 pv = prevs[i];   // (the last positions' records are indexed by position, zh_mf_prev_level)
             const uint32_t d3 = pv.x & 0xffffu;
             if (d3 != 0xffffu) {
                const uint32_t p3 = i - 1u - d3;
-               if (maxlen == 3 || gwin[p3 + 3] != gwin[i + 3]) m[n++] = 3u | ((d3 + 1u) << 16);
+               if (maxlen == 3 || gwin[p3 + 3] != gwin[i + 3]) e3 = 3u | ((d3 + 1u) << 16);
                const uint32_t d4 = pv.x >> 16, d5 = pv.y & 0xffffu;
                if (maxlen >= 4 && d4 != 0xffffu) {
-                  if (maxlen == 4 || gwin[i - 1 - d4 + 4] != gwin[i + 4]) m[n++] = 4u | ((d4 + 1) << 16);
-                  if (maxlen >= 5 && d5 != 0xffffu) m[n++] = 5u | ((d5 + 1) << 16);
+                  if (maxlen == 4 || gwin[i - 1 - d4 + 4] != gwin[i + 4]) e4 = 4u | ((d4 + 1) << 16);
+                  if (maxlen >= 5 && d5 != 0xffffu) e5 = 5u | ((d5 + 1) << 16);
                }
             }
          }
-         uint4 a;
-         a.x = n > 0 ? m[n - 1] : 0u;   // rows are longest first
-         a.y = n > 1 ? m[n - 2] : 0u;
-         a.z = n > 2 ? m[n - 3] : 0u;
+         uint4 a;   // rows are longest first (selects, not an array indexed at run time: that would live in scratch memory)
+         a.x = e5 ? e5 : (e4 ? e4 : e3);
+         a.y = e5 ? (e4 ? e4 : e3) : (e4 ? e3 : 0u);
+         a.z = (e5 && e4) ? e3 : 0u;
          a.w = 0;
          rows_lo[i - prev] = a;
       }

@@ -274,7 +274,7 @@ struct zh_split_shared_t {
 
 // blockdeflate.c:577-618 for the histogram in (lit, dist): unlimited lengths, body bits, header bits, +3.
 // All lanes of one wave call; returns the same value in every lane.
-__device__ inline int zh_dynamic_cost_wave(const int32_t *lit, const int32_t *dist, uint8_t *lit_len, uint8_t *dist_len,
+__device__ __forceinline__ int zh_dynamic_cost_wave(const int32_t *lit, const int32_t *dist, uint8_t *lit_len, uint8_t *dist_len,
                                            uint8_t *lens, zh_cl_t *cl, int32_t *tmp, zh_huff_scratch_t *sc,
                                            bool compute_lengths) {
    const int lane = (int)zh_lane();
