@@ -169,8 +169,12 @@ class CyclicCorpus:
         self.name, self.base = name, base
 
     def shard(self, rank, size):
-        lead = _cyclic(self.base, rank * size - HIST, HIST) if rank else None
-        return lead, _cyclic(self.base, rank * size, size)
+        return self.range(rank * size, size)
+
+    def range(self, start, size):
+        """bytes [start, start + size) of the stream, and the 32 KiB in front of them (None at the stream's start)"""
+        lead = _cyclic(self.base, start - HIST, HIST) if start else None
+        return lead, _cyclic(self.base, start, size)
 
 
 class SyntheticText:
@@ -196,6 +200,17 @@ class MixedConfig4:
         first = rank * (size // seg)
         lead = corpus.mixed_config4(first - 1, 1)[-HIST:].copy() if rank else None
         return lead, corpus.mixed_config4(first, size // seg)
+
+    def range(self, start, size):
+        import corpus
+        seg = corpus.CONFIG4_SEGMENT
+        s0, s1 = start // seg, (start + size + seg - 1) // seg
+        body = corpus.mixed_config4(s0, s1 - s0)[start - s0 * seg: start - s0 * seg + size].copy()
+        lead = None
+        if start:
+            l0 = (start - HIST) // seg
+            lead = corpus.mixed_config4(l0, (start + seg - 1) // seg - l0)[start - HIST - l0 * seg: start - l0 * seg].copy()
+        return lead, body
 
 
 def text_corpus(world, size):
@@ -347,8 +362,11 @@ class OneRank:   # N == 1: same code path without a process group
 # ---------------------------------------------------------------------------------------------------------------------
 # one leg of a stream configuration (2, 3, 4): compress this rank's shard `steps` times, assemble on rank 0
 # ---------------------------------------------------------------------------------------------------------------------
-def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
+def run_stream_leg(env, lead, shard, flags, bs, steps, warmup, last_rank=None):
+    """last_rank: the rank that holds the stream's last max-block (strong scaling: ranks behind it have empty shards)."""
     L, torch, dist, device, rank, world = env["L"], env["torch"], env["dist"], env["device"], env["rank"], env["world"]
+    group = bool(env.get("group"))   # a process group exists (always for N > 1; for N = 1 with --scaling strong: the same calls over RCCL)
+    last_rank = world - 1 if last_rank is None else last_rank
     from zultra_amd import sharded
     import ctypes as C
     n = len(shard)
@@ -361,10 +379,10 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
         blocks.append((nlead + b * bs - prev, prev, min(bs, n - b * bs)))
     block_lens = np.array([b[2] for b in blocks], dtype=np.uint32)
 
-    d_data = torch.from_numpy(host).to(device)   # input resident in HBM before the timed region
+    d_data = torch.from_numpy(host if n else np.zeros(1, dtype=np.uint8)).to(device)   # input resident in HBM before the timed region
     torch.cuda.synchronize()
-    ctx = L.context(bs, nblocks, device=env["local_rank"])
-    D = dist if world > 1 else OneRank
+    ctx = L.context(bs, nblocks, device=env["local_rank"]) if nblocks else None   # (strong scaling: more ranks than max-blocks leaves empty shards)
+    D = dist if group else OneRank
     L.L.zultra_adler32_append.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t]
     L.L.zultra_adler32_append.restype = C.c_uint32
     L.L.zultra_hip_block_adler32.argtypes = [C.c_void_p, C.c_void_p]
@@ -386,13 +404,21 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
             return a
         return 0
 
+    colls = []
+
     def step():
-        ctx.compress_blocks(d_data.data_ptr(), blocks, data_on_device=True, data_size=d_data.numel())
-        t = ctx.timing()
-        extra = np.array([shard_checksum(), n], dtype=np.int64)
-        body, info = sharded.assemble(L, ctx, bs, D, torch, device, nblocks - 1 if rank == world - 1 else -1, extra=extra)
-        t["stitch_ms"] = ctx.timing()["stitch_ms"]
-        timings.append(t)
+        if ctx is not None:
+            ctx.compress_blocks(d_data.data_ptr(), blocks, data_on_device=True, data_size=d_data.numel())
+            t = ctx.timing()
+            extra = np.array([shard_checksum(), n], dtype=np.int64)
+        else:
+            t = None
+            extra = np.array([0, 0], dtype=np.int64)   # (no bytes: a zero state stays zero, for both checksums)
+        body, info = sharded.assemble(L, ctx, bs, D, torch, device, nblocks - 1 if (rank == last_rank and nblocks) else -1, extra=extra, force_collectives=group)
+        if t is not None:
+            t["stitch_ms"] = ctx.timing()["stitch_ms"]
+            timings.append(t)
+        colls.append((info.get("collective_ms", 0.0), info.get("sent_bytes", 0), info.get("received_bytes", 0)))
         return body, info
 
     def barrier():
@@ -403,6 +429,7 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
     for _ in range(warmup):
         step()
     timings.clear()
+    colls.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -414,7 +441,19 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    res = {"n": n, "nblocks": nblocks, "dt": dt, "stats": ctx.stats(), "ctx": ctx, "d_data": d_data}
+    if rank == 0 and ctx is None:
+        raise RuntimeError("bench.py: rank 0 has no max-block (fewer max-blocks than ranks)")
+    res = {"n": n, "nblocks": nblocks, "dt": dt, "stats": ctx.stats() if ctx is not None else None, "ctx": ctx, "d_data": d_data}
+    # what every rank spent where: device pipeline (first launch to last completion of a batch), the exchange steps of the assembly
+    mine = [float(np.mean([t["total_ms"] for t in timings])) if timings else 0.0, float(np.mean([c[0] for c in colls])), float(colls[-1][1]), float(colls[-1][2]), float(n)]
+    per_rank = [mine]
+    if group and world > 1:
+        tt = torch.tensor(mine, dtype=torch.float64, device=device)
+        allr = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allr, tt)
+        per_rank = [[float(x) for x in a.cpu().tolist()] for a in allr]
+    res["per_rank"] = {"device_pipeline_ms": [round(p[0], 3) for p in per_rank], "collective_ms": [round(p[1], 3) for p in per_rank],
+                       "sent_bytes": [int(p[2]) for p in per_rank], "received_bytes_rank0": int(per_rank[0][3]), "input_bytes": [int(p[4]) for p in per_rank]}
     if rank == 0:
         # fold the ranks' checksum contributions in stream order
         total_in, chk = 0, (0 if flags == 2 else 1)
@@ -463,7 +502,7 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup):
 
 def summarize_leg(r):
     return {k: r[k] for k in ("ms_per_step", "kernel_ms", "device_pipeline_ms", "d2h_ms", "kernel_only_MBps", "sub_blocks_per_block",
-                              "parse_huge_share_of_positions", "parse_tasks", "parse_huge_tasks", "chain_cut")}
+                              "parse_huge_share_of_positions", "parse_tasks", "parse_huge_tasks", "chain_cut", "per_rank")}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -482,29 +521,44 @@ def prepare_stream_config(args, rank, world):
         flags, bs, size = 2, args.block or 65536, args.size or (1 << 30)
         corp, data_note = MixedConfig4(), "synthetic 8 GiB mixed-entropy corpus (tests/gen/zgen.c: splitmix64 seed 0x5EED, 1 MiB segments over the self-test grid, 1/16 noise, 1/16 constant): 1 GiB per GPU"
         metric = "input MB/s, gzip 64 KiB max-blocks, synthetic mixed-entropy corpus 1 GiB per GPU, bit-exact vs CPU zultra"
-    lead, shard = corp.shard(rank, size)
+    last_rank = world - 1
+    if args.scaling == "strong" or getattr(args, "strong_leg", False):
+        # strong scaling: the configuration's ONE stream of `size` bytes, its max-blocks cut contiguously over the ranks (zultra_amd.sharded.shard_range)
+        from zultra_amd.sharded import shard_range
+        nb_total = (size + bs - 1) // bs
+        lo, hi = shard_range(nb_total, rank, world)
+        last_rank = max(r for r in range(world) if shard_range(nb_total, r, world)[1] > shard_range(nb_total, r, world)[0])
+        if hi > lo:
+            lead, shard = corp.range(lo * bs, min(size, hi * bs) - lo * bs)
+        else:
+            lead, shard = None, np.zeros(0, dtype=np.uint8)
+    else:
+        lead, shard = corp.shard(rank, size)
     cb = ref_out = None
     sample = shard[: min(args.cpu_sample, len(shard))]
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.profile_run:
         cb, ref_out = cpu_baseline_stream(sample, flags, bs, corp.name)
     return dict(cfg=cfg, flags=flags, bs=bs, size=size, corp=corp, data_note=data_note, metric=metric, lead=lead, shard=shard, sample=sample, cb=cb,
-                ref_out=ref_out)
+                ref_out=ref_out, last_rank=last_rank)
 
 
 def run_stream_config(args, env, prep):
     L, rank, world = env["L"], env["rank"], env["world"]
     cfg, flags, bs, size, corp, data_note, metric = (prep[k] for k in ("cfg", "flags", "bs", "size", "corp", "data_note", "metric"))
     lead, shard, sample, cb, ref_out = (prep[k] for k in ("lead", "shard", "sample", "cb", "ref_out"))
-    head = run_stream_leg(env, lead, shard, flags, bs, args.steps, args.warmup)
+    strong = args.scaling == "strong"
+    head = run_stream_leg(env, lead, shard, flags, bs, args.steps, args.warmup, last_rank=prep["last_rank"])
     line = None
     failed = False
     if rank == 0:
         line = {
             "metric": metric, "value": round(head["MBps"], 3), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(head["ms_per_step"], 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32",
+            "ms_per_step": round(head["ms_per_step"], 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8/int32",
             "data": "real" if corp.name.startswith(("enwik8", "real")) else "synthetic",
-            "config": {"workload": "config %d: %s, %d B per GPU, flags=%d, nMaxBlockSize=%d, %d max-blocks per GPU" % (cfg, data_note, size, flags, bs, head["nblocks"]),
-                       "parallelism": "blocks sharded over %d GPU(s), phase-table all-gather + exact-length transfers to rank 0" % world},
+            "config": {"workload": ("config %d: %s, %d B in all (one stream cut over the GPUs), flags=%d, nMaxBlockSize=%d, %d max-blocks on rank 0" if strong else
+                                    "config %d: %s, %d B per GPU, flags=%d, nMaxBlockSize=%d, %d max-blocks per GPU") % (cfg, data_note, size, flags, bs, head["nblocks"]),
+                       "parallelism": "blocks sharded over %d GPU(s), phase-table all-gather + exact-length transfers to rank 0%s" % (
+                           world, " (1 rank: the same collectives over RCCL, nothing to transfer)" if (world == 1 and env.get("group")) else "")},
             "rccl_ranks_seen": env["ranks_seen"],
         }
         line.update(summarize_leg(head))
@@ -522,8 +576,25 @@ def run_stream_config(args, env, prep):
         line["inflate_roundtrip_ok"] = ok
         failed |= not ok
     ctx, d_data = head.pop("ctx"), head.pop("d_data")
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     del d_data
+    if world > 1 and not strong and not args.profile_run:
+        # beside the weak-scaling value: the configuration's ONE stream (its own size) cut over the same ranks — what BASELINE.json's metric names
+        args.strong_leg = True
+        sp = prepare_stream_config(args, rank, world)
+        args.strong_leg = False
+        sl = run_stream_leg(env, sp["lead"], sp["shard"], flags, bs, args.steps, args.warmup, last_rank=sp["last_rank"])
+        c2 = sl.pop("ctx")
+        if c2 is not None:
+            c2.close()
+        sl.pop("d_data")
+        if rank == 0:
+            sframed = frame(L, flags, sl["body"].tobytes(), sl["checksum"], sl["total_in"])
+            sok = inflate_check(flags, sframed, sp["shard"], sl["total_in"])
+            failed |= not sok
+            line["strong_scaling"] = {"value": round(sl["MBps"], 3), "unit": "MB/s", "ms_per_step": round(sl["ms_per_step"], 3), "total_input_bytes": sl["total_in"],
+                                      "inflate_roundtrip_ok": sok, "per_rank": sl["per_rank"], "compressed_bytes_total": len(sl["body"])}
 
     if rank == 0 and world == 1:
         # whole-input ratio against zlib-9 (README.md:16-46 quotes sizes against zlib/zopfli)
@@ -762,6 +833,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank takes a shard of the configuration's size of ONE N-times-larger stream; strong: the configuration's one stream is cut "
+                         "over the N ranks (N = 1: the same job, driven through a 1-rank RCCL group so that the collectives of N > 1 execute). At N > 1 the weak "
+                         "line carries the strong measurement beside it (strong_scaling)")
     ap.add_argument("--size", type=int, default=0, help="bytes per GPU (default: the configuration's own size)")
     ap.add_argument("--block", type=int, default=0, help="nMaxBlockSize (default: the configuration's own)")
     ap.add_argument("--files", type=int, default=1_000_000, help="config 5: inputs per GPU")
@@ -808,8 +883,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     ranks_seen = 1
-    if world > 1:
+    group = world > 1 or (args.scaling == "strong" and args.config in (2, 3, 4))
+    if group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world)
         one = torch.ones(1, dtype=torch.int64, device=device)
         dist.all_reduce(one)   # every rank present and reachable over RCCL
@@ -821,7 +898,8 @@ def main():
     L = zultra_amd.lib()   # raises if libzultra_amd.so is missing: there is no fallback path
     if L.device_count() < 1:
         raise RuntimeError("no HIP device")
-    env = {"L": L, "torch": torch, "dist": dist, "device": device, "rank": rank, "local_rank": local_rank, "world": world, "ranks_seen": ranks_seen, "config": args.config}
+    env = {"L": L, "torch": torch, "dist": dist, "device": device, "rank": rank, "local_rank": local_rank, "world": world, "ranks_seen": ranks_seen, "config": args.config,
+           "group": group}
 
     line, failed = {1: run_config1, 5: run_config5}.get(args.config, run_stream_config)(args, env, prep)
     if rank == 0:
@@ -829,7 +907,7 @@ def main():
             line["other_configs"] = other
             failed |= any(o.get("rc", 1) != 0 for o in other.values())
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if group:
         flag = torch.tensor([1 if failed else 0], dtype=torch.int64, device=device)
         dist.all_reduce(flag)
         failed = bool(flag.item())

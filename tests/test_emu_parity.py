@@ -262,3 +262,4 @@ def test_stream_memory_comes_from_the_callers_allocator(emu, oracle):
     assert len(log) == n_init                           # compressing allocates nothing more on the host side of the stream
     s.end()
     assert not live
+

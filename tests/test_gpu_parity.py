@@ -158,6 +158,33 @@ def test_streaming_api_chunking(gpu, oracle):
         assert bytes(out) == want
 
 
+def test_streaming_output_cadence(gpu, oracle, monkeypatch):
+    """libzultra.c:424-462 publishes output after every max-block; the device build collects max-blocks into batches, but a caller that
+    feeds small pieces with ZULTRA_CONTINUE sees output once ZULTRA_HIP_FLUSH_BYTES of full blocks are staged (default 4 MiB), not
+    only when the 64 MiB staging area is full or at ZULTRA_FINALIZE. The bytes are the reference's either way."""
+    d = corpus.text_like(9 * 65536 + 1000, 17)
+    want = oracle.memory_compress(d, 2, 65536)
+    for flush, early in (("131072", True), (None, False), ("0", False)):   # (default 4 MiB: more than this input)
+        if flush is None:
+            monkeypatch.delenv("ZULTRA_HIP_FLUSH_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("ZULTRA_HIP_FLUSH_BYTES", flush)
+        s = gpu.stream(2, 65536)
+        out = bytearray()
+        before_final = 0
+        pos = 0
+        while pos < len(d):
+            part = d[pos:pos + 16384]
+            pos += len(part)
+            st, b = s.compress(part, finalize=(pos >= len(d)), out_chunk=65536)
+            out += b
+            if pos < len(d):
+                before_final = len(out)
+        s.end()
+        assert bytes(out) == want
+        assert (before_final > 10) == early, (flush, before_final)   # (10 = the gzip header)
+
+
 def test_errors(gpu):
     t = corpus.text_like(100, 1)
     assert gpu.memory_compress(t[:0], 2, 0) is None
@@ -576,6 +603,73 @@ dist.destroy_process_group()
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "SHARDED_GPU_OK" in outs[0], outs[0]
+
+
+def test_sharded_assembly_under_a_one_rank_rccl_group(tmp_path):
+    """The collectives of the N > 1 path (zultra_amd.sharded.assemble: all_gather of the phase tables, gather of the first bytes, the
+    slice views of rank 0's stream buffer) on DEVICE tensors over RCCL — a process group of one rank with backend "nccl", which is all a
+    one-GPU box can host (RCCL refuses two ranks on one device). force_collectives takes the world of one through the same calls as
+    N > 1. The stream equals the oracle's; a stored sub-block sits in the middle."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    worker = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+import corpus, zlibs, zultra_amd
+from zultra_amd import sharded
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+dev = torch.device("cuda", 0)
+one = torch.ones(1, dtype=torch.int64, device=dev)
+dist.all_reduce(one)
+assert int(one.item()) == 1
+L = zultra_amd.lib()
+bs = 65536
+data = corpus.text_like_fast(12 * bs + 5000, 5)
+data[6 * bs:6 * bs + 30000] = corpus.noise(30000, 8)
+n = len(data)
+nb = (n + bs - 1) // bs
+blocks = [(b * bs - (32768 if b else 0), 32768 if b else 0, min(bs, n - b * bs)) for b in range(nb)]
+d_data = torch.from_numpy(data).to(dev)
+ctx = L.context(bs, nb, device=0)
+ctx.compress_blocks(d_data.data_ptr(), blocks, data_on_device=True, data_size=d_data.numel())
+stream, info = sharded.assemble(L, ctx, bs, dist, torch, dev, nb - 1, extra=np.array([7, n], dtype=np.int64), force_collectives=True)
+want = zlibs.Oracle().memory_compress(data, 0, bs)
+assert stream.tobytes() == want, (len(stream), len(want))
+assert [int(x) for x in info["extras"][0]] == [7, n] and info["start_phase"] == 0 and "collective_ms" in info
+print("RCCL_ONE_RANK_OK", len(want), round(info["collective_ms"], 3))
+dist.destroy_process_group()
+'''
+    script = tmp_path / "worker.py"
+    script.write_text(worker % {"root": root, "here": here})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in out, out
+
+
+def test_reference_selftest_grid_sampled(gpu, oracle):
+    """A sample of the grid the reference tool's self-test walks (tool/zultra.c:529-534: twelve alphabet sizes x match probabilities
+    0 .. 0.995 x sizes 16 384 .. 131 072; the full grid is test_reference_cli_full_selftest_on_device, 13 minutes): every alphabet x
+    three probabilities x the two end sizes, same construction of the data (tests/corpus.py: selftest_data), each case through
+    zultra_memory_compress of the device library — the bytes are the oracle's, and zlib inflates them back."""
+    n_cases = 0
+    for a_i, alphabet in enumerate((1, 2, 3, 15, 30, 56, 96, 137, 178, 191, 255, 256)):
+        for p_i, prob in enumerate((0.0, 0.5, 0.995)):
+            for size in (16384, 131072):
+                d = corpus.selftest_data(size, 1000 + 37 * a_i + 7 * p_i + (size >> 14), alphabet, prob)
+                got = gpu.memory_compress(d, 2, 0)
+                want = oracle.memory_compress(d, 2, 0)
+                assert got is not None and got == want, "alphabet %d probability %.3f size %d: %d bytes, oracle %d" % (alphabet, prob, size, len(got or b""), len(want))
+                assert zlib.decompress(got, 31) == d.tobytes()
+                n_cases += 1
+    assert n_cases == 72
 
 
 def test_many_sub_blocks_in_one_max_block(gpu, oracle):

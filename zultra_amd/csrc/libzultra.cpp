@@ -525,6 +525,7 @@ struct _zultra_compressor_s {
    unsigned flags;
    uint32_t max_block;
    uint32_t batch_blocks;       // max-blocks per device batch
+   uint64_t flush_bytes;        // staged full max-blocks of this many bytes are compressed when a call's input is used up (0: only when the staging area is full)
    const void *dict;
    int dict_size;
    unsigned state;
@@ -594,6 +595,10 @@ static zultra_status_t stream_init_sized(zultra_stream_t *s, unsigned flags, uns
    const uint64_t budget = 24ull << 30;
    while (batch_blocks > 1 && (uint64_t)zultra_hip_context_bytes_on(zh_pick_device(), bs, batch_blocks) > budget) batch_blocks = batch_blocks - (batch_blocks + 7) / 8;
    c->batch_blocks = batch_blocks;
+   {
+      const char *e = getenv("ZULTRA_HIP_FLUSH_BYTES");
+      c->flush_bytes = e ? (uint64_t)strtoull(e, NULL, 10) : (4ull << 20);
+   }
    c->blocks = (zultra_hip_block_t *)s->zalloc(s->opaque, batch_blocks, (unsigned)sizeof(zultra_hip_block_t));
    c->raw_off = (uint64_t *)s->zalloc(s->opaque, batch_blocks, (unsigned)sizeof(uint64_t));
    c->crc = (uint32_t *)s->zalloc(s->opaque, batch_blocks, (unsigned)sizeof(uint32_t));
@@ -807,8 +812,12 @@ extern "C" zultra_status_t zultra_stream_compress(zultra_stream_t *s, const int 
             // A full max-block may be compressed once input beyond it has been seen (libzultra.c:269). Nothing obliges us to do it
             // at once: blocks are kept until the staging area is full, so that a caller feeding small chunks (the reference's
             // CLI reads 16 KiB at a time) still gets device batches of many max-blocks instead of one launch sequence per block.
+            // Neither may a caller that pipes the output on wait for it for long: once the caller has nothing more to give in this call and
+            // `flush_bytes` of full blocks are staged (4 MiB unless ZULTRA_HIP_FLUSH_BYTES says otherwise; the reference publishes after every
+            // max-block, libzultra.c:424-462), they go to the device. A caller that hands over tens of MiB at once still fills the whole
+            // staging area (64 MiB) first: the big batches are for those who have the data.
             const uint32_t ready = (rem || s->avail_in) ? full : full - 1;
-            if (c->in_bytes >= cap || (ready >= c->batch_blocks)) count = ready;
+            if (c->in_bytes >= cap || (ready >= c->batch_blocks) || (c->flush_bytes && s->avail_in == 0 && (uint64_t)ready * bs >= c->flush_bytes)) count = ready;
          }
          if (count) err = compress_staged(s, c, count, last_n, final_last && count > 0);
       }

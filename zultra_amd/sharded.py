@@ -84,22 +84,28 @@ def _to_host(torch, t):
     return buf[:n].numpy()
 
 
-def assemble(lib, ctx, max_block, dist, torch, device, final_block_local, extra=None):
+def assemble(lib, ctx, max_block, dist, torch, device, final_block_local, extra=None, force_collectives=False):
     """Stitch this rank's last batch on its GPU at its true bit offset and gather the stream on rank 0.
     ctx = None for a rank whose shard is empty (it still takes part in the collectives).
     final_block_local = index (in this rank's batch) of the last max-block of the whole stream, or -1.
     extra = a small int64 vector per rank (same length everywhere) that rides along with the phase tables, e.g. the shard's
     checksum contribution; info["extras"] holds every rank's, in rank order.
+    force_collectives: a world of ONE rank normally returns before the first collective (there is nothing to exchange); with this flag
+    it walks the same path as N > 1 — all_gather of the phase table, gather of the first byte, the slice views of the stream buffer —
+    so that a 1-GPU box executes those calls on device tensors over RCCL (tests, `bench.py --gpus 1 --scaling strong`).
+    info["collective_ms"] = host wall time of the exchange steps (1) and (3) on this rank.
     Returns (stream bytes as a uint8 numpy array on rank 0 / None elsewhere, info dict)."""
+    import time
     rank, world = dist.get_rank(), dist.get_world_size()
     extra = np.zeros(0, dtype=np.int64) if extra is None else np.ascontiguousarray(extra, dtype=np.int64)
 
-    if world == 1:
+    if world == 1 and not force_collectives:
         end_bit, _ = ctx.stitch_device(final_block_local, phase=0)
         nbytes = (end_bit + 7) // 8
-        return _to_host(torch, _stream_tensor(ctx, torch, device, nbytes)), {"shard_bytes": nbytes, "start_phase": 0, "sent_bytes": 0, "extras": [extra]}
+        return _to_host(torch, _stream_tensor(ctx, torch, device, nbytes)), {"shard_bytes": nbytes, "start_phase": 0, "sent_bytes": 0, "extras": [extra], "collective_ms": 0.0}
 
     # (1) phase tables of every rank -> start phase and byte offset of every shard
+    t_coll = time.perf_counter()
     mine = torch.from_numpy(np.concatenate([phase_table(lib, ctx, max_block).reshape(-1), extra])).to(device)
     tabs = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(tabs, mine)
@@ -117,6 +123,7 @@ def assemble(lib, ctx, max_block, dist, torch, device, final_block_local, extra=
         phase = end_bit & 7
     total_bytes = off + (1 if phase else 0)
     my_phase, my_off, my_end = starts[rank]
+    coll_s = time.perf_counter() - t_coll
 
     # (2) stitch on the device at the shard's true phase: byte 0 carries only this shard's bits
     nbytes = 0
@@ -128,6 +135,7 @@ def assemble(lib, ctx, max_block, dist, torch, device, final_block_local, extra=
         local = _stream_tensor(ctx, torch, device, nbytes)
 
     # (3) first byte of every shard, then exact-length transfers into place on rank 0
+    t_coll = time.perf_counter()
     edge = torch.zeros(1, dtype=torch.uint8, device=device)
     if nbytes:
         edge[0] = local[0]
@@ -148,6 +156,7 @@ def assemble(lib, ctx, max_block, dist, torch, device, final_block_local, extra=
             for q in reqs:
                 q.wait()
             info["sent_bytes"] = n - skip
+        info["collective_ms"] = (coll_s + time.perf_counter() - t_coll) * 1e3
         return None, info
 
     stream = torch.zeros(total_bytes + 1, dtype=torch.uint8, device=device)
@@ -167,4 +176,8 @@ def assemble(lib, ctx, max_block, dist, torch, device, final_block_local, extra=
         o, n, skip = touched(r)
         if skip:
             stream[o] |= int(edges[r][0])
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    info["collective_ms"] = (coll_s + time.perf_counter() - t_coll) * 1e3
+    info["received_bytes"] = int(sum(max(0, touched(r)[1] - touched(r)[2]) for r in range(1, world)))
     return _to_host(torch, stream[:total_bytes]), info
