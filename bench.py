@@ -349,6 +349,22 @@ def committed_traffic(kernel, config):
     return int(k["hbm_bytes_per_launch"]), os.path.basename(files[-1])
 
 
+def committed_sq(config, ms_per_step):
+    """Issue and residency figures from the committed SQ-counter pass of this configuration (profiles/*_sq_c<N>.json, tools/sq_profile.py):
+    valu_issue_frac = the step's vector instructions x 2 cycles / (1024 SIMDs x the cycles of THIS run's step at 2.4 GHz), and the average
+    number of resident waves of every kernel while it ran. None when no pass is committed."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_c%s.json" % config)))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    issue_ms = float(t.get("valu_issue_ms_per_step", 0.0))
+    return {"valu_issue_frac": round(issue_ms / ms_per_step, 4) if ms_per_step > 0 else None, "valu_issue_ms_per_step": issue_ms,
+            "valu_insts_per_step": t.get("valu_insts_per_step"),
+            "resident_waves_avg": {k: v.get("resident_waves_avg") for k, v in t.get("kernels", {}).items() if v.get("resident_waves_avg") is not None},
+            "source": os.path.basename(files[-1])}
+
+
 class OneRank:   # N == 1: same code path without a process group
     @staticmethod
     def get_rank():
@@ -564,6 +580,9 @@ def run_stream_config(args, env, prep):
         line.update(summarize_leg(head))
         line["compressed_bytes_total"] = len(head["body"])
         line["roofline"] = head["roofline"]
+        sq = committed_sq(cfg, head["ms_per_step"])
+        if sq:
+            line["issue"] = sq
         if args.profile_run:
             L.traffic_probe(256 << 20)
             return line, False
@@ -864,6 +883,12 @@ def main():
         sys.stderr.write("bench.py: configuration 1 is a single 39 680-byte input: there is nothing to shard\n")
         sys.exit(2)
 
+    # Only the JSON line goes to this process's stdout: libraries that print there on their own (RCCL's version banner comes out of C stdio
+    # at exit, i.e. AFTER the line) are sent to stderr for the whole run.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     # ---- the other configurations' legs, as child processes, before this process touches a GPU ---------------------------------------
     other = None
     if args.config == 2 and world == 1 and not have_launcher and not args.profile_run and not args.leg and not args.no_other_configs:
@@ -906,7 +931,8 @@ def main():
         if other is not None:
             line["other_configs"] = other
             failed |= any(o.get("rc", 1) != 0 for o in other.values())
-        print(json.dumps(line), flush=True)
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
     if group:
         flag = torch.tensor([1 if failed else 0], dtype=torch.int64, device=device)
         dist.all_reduce(flag)

@@ -51,6 +51,22 @@ def test_stages_vs_oracle(emu, oracle, case):
     check_window(emu, oracle, gen(), prev, n, tag=name)
 
 
+@pytest.mark.parametrize("case", [
+    ("text", "256", lambda: corpus.text_like(9000, 3), 1000, 8000),
+    ("binary2", "256", lambda: corpus.selftest_data(5000, 5, 2, 0.3), 0, 5000),
+    ("byte_runs", "256", lambda: corpus.indented(7000, 11), 2000, 5000),
+    ("zeros", "16", lambda: corpus.constant(3000), 500, 2500),
+    ("end_clamp", "16", lambda: np.concatenate([corpus.noise(300, 2), corpus.constant(700, 65)]), 0, 1000),
+], ids=lambda c: c[0] + "/cap" + c[1])
+def test_matchfinder_chunks_and_oversized_classes(emu, oracle, monkeypatch, case):
+    """zh_mf_group_lds.h with chunks of 256 elements: a window of a few KB is then several chunks of the bigram order, refined in LDS one
+    after the other, and every bigram class above 256 entries (byte runs, the four classes of a two-symbol alphabet) goes through the
+    passes in HBM on its range; with 16, nearly every class does. (By default such windows are one chunk: the whole-window path.)"""
+    name, cap, gen, prev, n = case
+    monkeypatch.setenv("ZULTRA_HIP_MF_CAP", cap)
+    check_window(emu, oracle, gen(), prev, n, tag=name + "/cap" + cap)
+
+
 @pytest.mark.parametrize("wide", ["1", "1000000", "whole"], ids=["as_waves_of_zh_parse_segments", "as_jobs_of_zh_parse_chain", "few_and_short_stay_whole"])
 def test_chain_segments_are_both_accepted_and_redone(emu, oracle, monkeypatch, wide):
     """The speculative segments of long barrier-free tasks (zh_parse.h; the emulator build cuts every 512 positions with a

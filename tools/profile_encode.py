@@ -40,7 +40,7 @@ blocks = [(b * bs - (32768 if b else 0), 32768 if b else 0, min(bs, size - b * b
 ctx = L.context(bs, nb)
 for it in range(3):
     if it == 2 and os.environ.get("PE_SKIP"):   # timing experiments: the last (timed) batch without one of the parse kernels
-        os.environ["ZH_DEBUG_SKIP"] = os.environ["PE_SKIP"]
+        os.environ["ZH_DEBUG_SKIP"] = os.environ["PE_SKIP"]   # (needs a -DZH_DEBUG_SKIP_BUILD build of the library)
     ctx.compress_blocks(d, blocks)
 t = ctx.timing()
 subs, _, cnt = ctx.subblocks()

@@ -899,12 +899,32 @@ static void staged_copy(uint8_t *dst, const uint8_t *src, size_t n) {
    }
    const size_t nt = n / piece < 4 ? n / piece : 4;
    std::vector<std::thread> th;
-   for (size_t t = 1; t < nt; t++) th.emplace_back([=] { memcpy(dst + n * t / nt, src + n * t / nt, n * (t + 1) / nt - n * t / nt); });
+   size_t started = 1;   // pieces 1 .. started - 1 have a thread; nothing thrown here may cross the C ABI (extern "C" callers end in std::terminate)
+   try {
+      th.reserve(nt);
+      for (; started < nt; started++) th.emplace_back([=] { memcpy(dst + n * started / nt, src + n * started / nt, n * (started + 1) / nt - n * started / nt); });
+   } catch (...) {
+   }
    memcpy(dst, src, n / nt);
+   if (started < nt) memcpy(dst + n * started / nt, src + n * started / nt, n - n * started / nt);   // (no thread for the rest: copied here)
    for (auto &t : th) t.join();
 }
 
+static void mem_lane_body(MemLanes *M, size_t lane);
 static void mem_lane_thread(MemLanes *M, size_t lane) {
+   try {
+      mem_lane_body(M, lane);
+   } catch (...) {   // (std::bad_alloc from the block list: the batch fails, the process does not)
+      {
+         std::lock_guard<std::mutex> lk(M->m);
+         for (size_t j = lane; j < M->jobs.size(); j += M->ctx.size())
+            if (M->jobs[j].state == 0) M->jobs[j].state = -1;
+         M->abort = true;
+      }
+      M->cv.notify_all();
+   }
+}
+static void mem_lane_body(MemLanes *M, size_t lane) {
    zultra_hip_ctx_t *c = M->ctx[lane];
    std::vector<zultra_hip_block_t> blocks;
    for (size_t j = lane; j < M->jobs.size(); j += M->ctx.size()) {
@@ -970,19 +990,33 @@ static size_t memory_compress_lanes(const unsigned char *pIn, size_t nIn, unsign
    size_t per = (M.total_blocks + devices.size() - 1) / devices.size();
    const uint64_t budget = 24ull << 30;
    if (per > 8192) per = 8192;
-   while (per > 1 && (uint64_t)zultra_hip_context_bytes_on(devices[0], bs, (uint32_t)per) > budget) per -= (per + 7) / 8;
-   for (size_t b = 0; b < M.total_blocks; b += per) M.jobs.push_back(MemJob{b, M.total_blocks - b < per ? M.total_blocks - b : per, 0});
-   const size_t lanes = M.jobs.size() < devices.size() ? M.jobs.size() : devices.size();
-   for (size_t l = 0; l < lanes; l++) {
-      zultra_hip_ctx_t *c = ctx_acquire_on(devices[l], bs, (uint32_t)per);
-      if (!c) {
-         for (auto *k : M.ctx) ctx_release(k);
-         return (size_t)-1;
-      }
-      M.ctx.push_back(c);
-   }
+   for (int dv : devices)   // (the listed devices need not be alike: a job must fit the smallest budget)
+      while (per > 1 && (uint64_t)zultra_hip_context_bytes_on(dv, bs, (uint32_t)per) > budget) per -= (per + 7) / 8;
    std::vector<std::thread> threads;
-   for (size_t l = 0; l < lanes; l++) threads.emplace_back(mem_lane_thread, &M, l);
+   size_t lanes = 0;
+   try {
+      for (size_t b = 0; b < M.total_blocks; b += per) M.jobs.push_back(MemJob{b, M.total_blocks - b < per ? M.total_blocks - b : per, 0});
+      const size_t want = M.jobs.size() < devices.size() ? M.jobs.size() : devices.size();
+      // a lane whose context cannot be had (a second large context on a device listed twice, a busy or smaller device) is left out: the
+      // jobs go round the lanes that exist; none at all is the only failure
+      for (size_t l = 0; l < want; l++) {
+         zultra_hip_ctx_t *c = ctx_acquire_on(devices[l], bs, (uint32_t)per);
+         if (c) M.ctx.push_back(c);
+      }
+      lanes = M.ctx.size();
+      if (!lanes) return (size_t)-1;
+      threads.reserve(lanes);
+      for (size_t l = 0; l < lanes; l++) threads.emplace_back(mem_lane_thread, &M, l);
+   } catch (...) {   // std::bad_alloc / std::system_error must not cross the C ABI
+      {
+         std::lock_guard<std::mutex> lk(M.m);
+         M.abort = true;
+      }
+      M.cv.notify_all();
+      for (auto &t : threads) t.join();
+      for (auto *k : M.ctx) ctx_release(k);
+      return (size_t)-1;
+   }
 
    size_t w = 0;
    bool fail = false;
@@ -1000,7 +1034,12 @@ static size_t memory_compress_lanes(const unsigned char *pIn, size_t nIn, unsign
    zultra_hip_bitstate_t bit;
    bit.acc = bit.nacc = 0;
    std::vector<uint32_t> parts;
-   for (size_t j = 0; j < M.jobs.size(); j++) {
+   try {
+      parts.reserve(2 * per);
+   } catch (...) {
+      fail = true;
+   }
+   for (size_t j = 0; j < M.jobs.size() && !fail; j++) {
       MemJob &J = M.jobs[j];
       {
          std::unique_lock<std::mutex> lk(M.m);
@@ -1059,6 +1098,13 @@ static size_t memory_compress_lanes(const unsigned char *pIn, size_t nIn, unsign
       }
       M.cv.notify_all();
       if (fail) break;
+   }
+   if (fail) {
+      {
+         std::lock_guard<std::mutex> lk(M.m);
+         M.abort = true;
+      }
+      M.cv.notify_all();
    }
    for (auto &t : threads) t.join();
    for (auto *k : M.ctx) ctx_release(k);

@@ -78,6 +78,7 @@ struct zultra_hip_ctx_s {
    std::vector<zh_seg_t> segs;
    std::vector<uint32_t> seg_base;
    zh_match_t *d_match;
+   uint32_t lane_tasks;         // zh_parse_lanes: tasks per wave when forced (0: chosen per run)
    uint32_t mf_lds_cap;         // zh_mf_group: chunk size of the refinement in LDS, 0 = through HBM
    uint32_t *d_pay;             // zh_mf_group: 3 x sort_stride words per persistent workgroup (payload of the refining sort passes)
    uint32_t *d_longest;         // (round 2: a copy of slot 0 of every match row; no longer written — its readers take the rows)
@@ -356,6 +357,11 @@ __global__ void __launch_bounds__(256) zh_probe_copy_x4(const uint4 *__restrict_
 #undef __builtin_nontemporal_load
 #undef __builtin_nontemporal_store
 #endif
+// the plainest form, what the guide's figure is quoted for: one 16-byte element per thread, default cache policy, a grid that covers the buffer
+__global__ void __launch_bounds__(256) zh_probe_copy_plain(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+   const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+   if (k < n16) dst[k] = src[k];
+}
 
 extern "C" double zultra_hip_copy_bandwidth(size_t nbytes, int iters) {
    uint4 *a = NULL, *b = NULL;
@@ -370,19 +376,35 @@ extern "C" double zultra_hip_copy_bandwidth(size_t nbytes, int iters) {
    hipEvent_t e0 = NULL, e1 = NULL;
    (void)hipEventCreate(&e0);
    (void)hipEventCreate(&e1);
-   ZH_LAUNCH(zh_probe_copy_x4, 256 * 32, 256, 0, (const uint4 *)a, b, n16);   // warm-up
-   (void)hipEventRecord(e0, 0);
-   for (int i = 0; i < iters; i++) ZH_LAUNCH(zh_probe_copy_x4, 256 * 32, 256, 0, (const uint4 *)a, b, n16);
-   (void)hipEventRecord(e1, 0);
-   const hipError_t e = hipEventSynchronize(e1);
-   float ms = 0;
-   (void)hipEventElapsedTime(&ms, e0, e1);
+   // the better of two forms, each its own timed loop: four non-temporal loads in flight per lane from persistent workgroups (round 3: 5.0-5.1
+   // TB/s on this pool), and one element per thread from a grid over the whole buffer (the guide's float4 copy: 6.29 TB/s)
+   float best_ms = 0;
+   hipError_t e = hipSuccess;
+   for (int form = 0; form < 2 && e == hipSuccess; form++) {
+      const uint32_t plain_grid = (uint32_t)((n16 + 255) / 256);
+      if (form == 0)
+         ZH_LAUNCH(zh_probe_copy_x4, 256 * 32, 256, 0, (const uint4 *)a, b, n16);   // warm-up
+      else
+         ZH_LAUNCH(zh_probe_copy_plain, plain_grid, 256, 0, (const uint4 *)a, b, n16);
+      (void)hipEventRecord(e0, 0);
+      for (int i = 0; i < iters; i++) {
+         if (form == 0)
+            ZH_LAUNCH(zh_probe_copy_x4, 256 * 32, 256, 0, (const uint4 *)a, b, n16);
+         else
+            ZH_LAUNCH(zh_probe_copy_plain, plain_grid, 256, 0, (const uint4 *)a, b, n16);
+      }
+      (void)hipEventRecord(e1, 0);
+      e = hipEventSynchronize(e1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (e == hipSuccess && ms > 0 && (best_ms == 0 || ms < best_ms)) best_ms = ms;
+   }
    (void)hipEventDestroy(e0);
    (void)hipEventDestroy(e1);
    (void)hipFree(a);
    (void)hipFree(b);
-   if (e != hipSuccess || ms <= 0) return -2.0;
-   return 2.0 * (double)(n16 * 16) * iters / (ms * 1e-3) / 1e9;
+   if (e != hipSuccess || best_ms <= 0) return -2.0;
+   return 2.0 * (double)(n16 * 16) * iters / (best_ms * 1e-3) / 1e9;
 }
 
 // The pipeline uses up to five streams per context (two runs, a side stream each for zh_parse_chain, one for the stitcher) next
@@ -545,6 +567,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->parse_lanes = pl ? atoi(pl) : 1;
       const char *lw = getenv("ZULTRA_HIP_LANE_WAVES");
       c->lane_waves = lw ? (uint32_t)max(1, min(16, atoi(lw))) : 12u;
+      const char *lt = getenv("ZULTRA_HIP_LANE_TASKS");   // tasks per wave of zh_parse_lanes (tuning experiments); not set: by the size of the run
+      c->lane_tasks = lt ? (uint32_t)max(1, min((int)ZH_LP_TASKS, atoi(lt))) : 0u;
       const char *mfl = getenv("ZULTRA_HIP_MF_CAP");   // elements per chunk of zh_mf_group's refinement in LDS (zh_mf_group_lds.h); 0: rounds 1-3's passes through HBM (A/B runs)
       c->mf_lds_cap = mfl ? (uint32_t)max(0, atoi(mfl)) : (uint32_t)ZH_MFL_CAP_LIMIT;
       const char *mfp = getenv("ZULTRA_HIP_MF_CUS");   // share of the CUs the matchfinder's persistent workgroups take, in percent (tuning experiments)
@@ -801,8 +825,7 @@ static int zh_build_segments(zultra_hip_ctx_t *c, const zultra_hip_block_t *bloc
 
 // tasks a wave of zh_parse_lanes takes (zh_parse_lanes.h): as many as ZH_LP_TASKS, as few as it takes to fill the chip's wave slots
 static uint32_t zh_tasks_per_wave(const zultra_hip_ctx_t *c, uint32_t ntasks) {
-   const char *e = getenv("ZULTRA_HIP_LANE_TASKS");
-   if (e) return (uint32_t)max(1, min((int)ZH_LP_TASKS, atoi(e)));
+   if (c->lane_tasks) return c->lane_tasks;   // ZULTRA_HIP_LANE_TASKS, read once at context creation
    const uint32_t slots = c->total_cus * 8u;   // (measured: eight tasks per wave at 16 K tasks per run beat four by 2 % of the step)
    return max(1u, min((uint32_t)ZH_LP_TASKS, (ntasks + slots - 1) / slots));
 }
@@ -1088,15 +1111,26 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       if (per_run_stage) {
          // this run's windows: from the first block's history to the last block's end (the 32 KiB in front of the run go up twice,
          // with the run before it: the same bytes)
-         const uint64_t lo = blocks[b0].win_off, hi = blocks[b1 - 1].win_off + blocks[b1 - 1].prev + blocks[b1 - 1].n;
+         // (min / max over the run's blocks: the windows of a batch need not ascend, nor be contiguous — what lies between them goes up too)
+         uint64_t lo = blocks[b0].win_off, hi = blocks[b0].win_off + blocks[b0].prev + blocks[b0].n;
+         for (uint32_t b = b0 + 1; b < b1; b++) {
+            lo = min(lo, (uint64_t)blocks[b].win_off);
+            hi = max(hi, (uint64_t)blocks[b].win_off + blocks[b].prev + blocks[b].n);
+         }
          const uint8_t *src = (const uint8_t *)data + lo;
          uint8_t *dst = per_run_stage + lo;
          const size_t len = (size_t)(hi - lo), piece = 8u << 20;
          if (len >= 2 * piece) {   // (a run of tens of MB: the host copy is split over a few threads)
             const size_t nt = len / piece < 4 ? len / piece : 4;
             std::vector<std::thread> th;
-            for (size_t t = 1; t < nt; t++) th.emplace_back([=] { memcpy(dst + len * t / nt, src + len * t / nt, len * (t + 1) / nt - len * t / nt); });
+            size_t started = 1;   // (nothing thrown here may cross the C ABI: pieces without a thread are copied by this one)
+            try {
+               th.reserve(nt);
+               for (; started < nt; started++) th.emplace_back([=] { memcpy(dst + len * started / nt, src + len * started / nt, len * (started + 1) / nt - len * started / nt); });
+            } catch (...) {
+            }
             memcpy(dst, src, len / nt);
+            if (started < nt) memcpy(dst + len * started / nt, src + len * started / nt, len - len * started / nt);
             for (auto &t : th) t.join();
          }
          else
@@ -1215,7 +1249,11 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       for (int pass = 0; pass <= 3; pass++) {
          // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
          hipStream_t side = c->side_stream[k];
-         const int dbg_skip = getenv("ZH_DEBUG_SKIP") ? atoi(getenv("ZH_DEBUG_SKIP")) : 0;   // timing experiments only (wrong output): 1 no chain kernel, 2 no lanes kernel
+#ifdef ZH_DEBUG_SKIP_BUILD   // probe builds only (tools/build_variant.sh ... -DZH_DEBUG_SKIP_BUILD): timing experiments with WRONG output — 1 no chain kernel, 2 no lanes kernel
+         const int dbg_skip = getenv("ZH_DEBUG_SKIP") ? atoi(getenv("ZH_DEBUG_SKIP")) : 0;
+#else
+         const int dbg_skip = 0;
+#endif
          if (nchains && !(dbg_skip & 1)) {
             ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
             ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));

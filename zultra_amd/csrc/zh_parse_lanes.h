@@ -49,6 +49,10 @@
 #define ZH_LP_MAXP (ZH_LP_TASKS * 32u) // pieces per group: a task without a run of more than ZH_COOP_MIN positions has fewer than 32
 #define ZH_LP_LONG 192u            // pieces of at least this many positions are handed out first
 #define ZH_LP_NOKEY 0xFFFFFFFFu
+// a task that is parsed here has no barrier-free run of more than ZH_COOP_MIN positions, so it has fewer than 32 pieces of >= ZH_PIECE positions
+// (zh_task_pieces); a group whose pieces outgrew ZH_LP_MAXP would silently lose a task — variant builds (-D...) must keep these
+static_assert((ZH_TASK + ZH_COOP_MIN + ZH_PIECE - 1) / ZH_PIECE <= 32, "pieces per task must stay below 32 (ZH_LP_MAXP = 32 per task)");
+static_assert(ZH_LP_TASKS >= 1 && ZH_LP_TASKS <= 64, "the parsed-task mask of a group is 64 bits");
 // The prefix scratch [row][column]: row L - 3, and piece i in column i ^ 8 for the rows of lanes 2 and 3 — the four lanes of a quad
 // write rows 9 q + k, whose LDS banks (16 per row) would coincide for lanes 0 / 2 and for lanes 1 / 3
 #define ZH_LP_PCOL(row_, piece_) ((piece_) ^ ((row_) >= 2u * ZH_LP_QSTRIDE ? 8u : 0u))
