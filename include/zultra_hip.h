@@ -57,6 +57,7 @@ typedef struct zultra_hip_timing_s {
    float h2d_ms, matchfinder_ms, tokenize_split_ms, encode_ms, d2h_ms, total_ms;
    float group_ms, frontier_ms, stitch_ms;
    float init_ms, parse_ms, build_ms, post_ms, emit_ms;   /* parts of encode_ms: zh_sb_init, 4 x zh_parse_tasks, 4 x zh_sb_build, zh_post_tasks, zh_emit_tasks */
+   float loop_ms;                                          /* zh_parse_loop: the sub-blocks that take their four passes on their own, next to the pass-by-pass kernels */
 } zultra_hip_timing_t;
 
 /* Number of usable HIP devices (0 if none). */

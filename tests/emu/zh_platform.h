@@ -309,6 +309,17 @@ inline uint32_t atomicMax(uint32_t *p, uint32_t v) {
    if (v > o) *p = v;
    return o;
 }
+inline uint32_t atomicSub(uint32_t *p, uint32_t v) {
+   uint32_t o = *p;
+   *p = o - v;
+   return o;
+}
+inline uint32_t atomicCAS(uint32_t *p, uint32_t cmp, uint32_t val) {
+   uint32_t o = *p;
+   if (o == cmp) *p = val;
+   return o;
+}
+inline void zh_stores_done() {}
 inline uint32_t atomicMin(uint32_t *p, uint32_t v) {
    uint32_t o = *p;
    if (v < o) *p = v;

@@ -158,6 +158,17 @@ def test_streaming_api_chunking(gpu, oracle):
         assert bytes(out) == want
 
 
+def test_sub_blocks_on_their_own(gpu, oracle, monkeypatch):
+    """ZULTRA_HIP_PARSE_LOOP=1: the sub-blocks without a chain task are taken through their four parse passes by a workgroup of their
+    own (zh_parse_own, zh_parse_loop.h) while those with chains go pass by pass — off by default (it is slower on the 100 MB step), same
+    bytes: text that splits, and near-copies whose sub-blocks have chains."""
+    monkeypatch.setenv("ZULTRA_HIP_PARSE_LOOP", "1")
+    check_window(gpu, oracle, corpus.text_like(60000, 21), 0, 60000, max_block=65536, tag="own/text")
+    check_window(gpu, oracle, corpus.duplicated(50000, 3, 1500), 2000, 48000, max_block=65536, tag="own/near_copies")
+    d = np.concatenate([corpus.text_like(300000, 4), corpus.duplicated(200000, 5, 3000), corpus.noise(40000, 2), corpus.indented(200000, 6)])
+    assert gpu.memory_compress(d, 2, 65536) == oracle.memory_compress(d, 2, 65536)
+
+
 def test_streaming_output_cadence(gpu, oracle, monkeypatch):
     """libzultra.c:424-462 publishes output after every max-block; the device build collects max-blocks into batches, but a caller that
     feeds small pieces with ZULTRA_CONTINUE sees output once ZULTRA_HIP_FLUSH_BYTES of full blocks are staged (default 4 MiB), not

@@ -37,7 +37,7 @@ tr = np.zeros((4, 4, slots.value, 3), dtype=np.uint64)
 assert L.L.zultra_hip_chain_trace(ctx.h, tr.ctypes.data, C.byref(slots)) == 0
 print(ctx.timing())
 print(ctx.stats())
-for run in range(2):
+for run in range(3):
     for p in range(4):
         t = tr[run, p]
         t = t[t[:, 0] > 0]

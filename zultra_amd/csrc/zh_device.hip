@@ -34,6 +34,7 @@
 #include "zh_parse.h"
 #include "zh_parse_chain.h"
 #include "zh_parse_lanes.h"
+#include "zh_parse_loop.h"
 #include "zh_split.h"
 #include "zh_stitch.h"
 
@@ -141,6 +142,12 @@ struct zultra_hip_ctx_s {
    hipEvent_t lane_ev[ZH_MAX_RUNS][24];
    hipStream_t side_stream[ZH_MAX_RUNS];     // per run: zh_parse_chain runs next to zh_parse_tasks
    hipEvent_t side_ev[ZH_MAX_RUNS][8];       // per pass: fork, join
+   hipStream_t loop_stream[ZH_MAX_RUNS];     // per run: zh_parse_own (zh_parse_loop.h), next to the pass-by-pass kernels of the sub-blocks with chains
+   hipEvent_t loop_ev[ZH_MAX_RUNS][2];
+   uint32_t *d_sbflags;                      // per sub-block: bit 0 = has a chain task (zh_list_huge)
+   int use_loop;                             // ZULTRA_HIP_PARSE_LOOP (default 0)
+   int own_after;                            // ZULTRA_HIP_OWN_AFTER
+   bool loop_had[ZH_MAX_RUNS];               // the last batch launched zh_parse_loop for this run
    hipStream_t seg_stream[ZH_MAX_RUNS];      // per run: zh_parse_segments, likewise
    hipEvent_t seg_ev[ZH_MAX_RUNS][4];        // per pass: join
    hipEvent_t ev_input;
@@ -459,6 +466,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_states);
    (void)hipFree(c->d_taskmap);
    (void)hipFree(c->d_taskinfo);
+   (void)hipFree(c->d_sbflags);
    (void)hipFree(c->d_ntasks);
    (void)hipFree(c->d_hugelist);
    (void)hipFree(c->d_segtasks);
@@ -480,6 +488,9 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
       for (int i = 0; i < 4; i++)
          if (c->seg_ev[k][i]) (void)hipEventDestroy(c->seg_ev[k][i]);
       if (c->seg_stream[k]) (void)hipStreamDestroy(c->seg_stream[k]);
+      for (int i = 0; i < 2; i++)
+         if (c->loop_ev[k][i]) (void)hipEventDestroy(c->loop_ev[k][i]);
+      if (c->loop_stream[k]) (void)hipStreamDestroy(c->loop_stream[k]);
    }
    if (c->ev_input) (void)hipEventDestroy(c->ev_input);
    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
@@ -567,6 +578,10 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->parse_lanes = pl ? atoi(pl) : 1;
       const char *lw = getenv("ZULTRA_HIP_LANE_WAVES");
       c->lane_waves = lw ? (uint32_t)max(1, min(16, atoi(lw))) : 12u;
+      const char *pl2 = getenv("ZULTRA_HIP_PARSE_LOOP");   // 1: sub-blocks without a chain task go through their passes on their own (zh_parse_own); 0: every sub-block pass by pass
+      c->use_loop = pl2 ? atoi(pl2) : 0;   // (off: measured on the 100 MB step, 40.4 ms with it against 37.9 — zh_parse_loop.h)
+      const char *oa = getenv("ZULTRA_HIP_OWN_AFTER");   // zh_parse_own starts after this stage of the batch's LAST run: 0 at once, 1 its upload, 2 zh_mf_group, 3 zh_mf_frontier
+      c->own_after = oa ? atoi(oa) : 0;
       const char *lt = getenv("ZULTRA_HIP_LANE_TASKS");   // tasks per wave of zh_parse_lanes (tuning experiments); not set: by the size of the run
       c->lane_tasks = lt ? (uint32_t)max(1, min((int)ZH_LP_TASKS, atoi(lt))) : 0u;
       const char *mfl = getenv("ZULTRA_HIP_MF_CAP");   // elements per chunk of zh_mf_group's refinement in LDS (zh_mf_group_lds.h); 0: rounds 1-3's passes through HBM (A/B runs)
@@ -617,6 +632,13 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
             (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
             ZH_CHECK(c, hipStreamCreateWithPriority(&c->seg_stream[k], hipStreamNonBlocking, hi_prio));
             for (int i = 0; i < 4; i++) ZH_CHECK(c, hipEventCreate(&c->seg_ev[k][i]));
+            {
+               int lo_prio = 0, hi_prio = 0;
+               (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+               const char *op = getenv("ZULTRA_HIP_OWN_PRIO");   // 1: the lowest stream priority for zh_parse_own's stream
+               ZH_CHECK(c, hipStreamCreateWithPriority(&c->loop_stream[k], hipStreamNonBlocking, (op && atoi(op)) ? lo_prio : 0));
+            }
+            for (int i = 0; i < 2; i++) ZH_CHECK(c, hipEventCreate(&c->loop_ev[k][i]));
          }
       }
       ZH_CHECK(c, hipEventCreate(&c->ev_input));
@@ -635,6 +657,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->seg_tasks_per_block = c->files_mode ? 1 : N / (2u * ZH_CUT_WARM) + 1;
    c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_WARM + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;   // a task of len positions has at most len / ZH_CUT_LEN + ZH_CUT_ROWS segments
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) || zh_alloc(c, &c->d_taskinfo, c->max_tasks) ||
+       zh_alloc(c, &c->d_sbflags, B * c->max_subs) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
        zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, 3 * c->max_tasks) ||
        zh_alloc(c, &c->d_segtasks, B * c->seg_tasks_per_block) || zh_alloc(c, &c->d_segwaves, B * c->seg_items_per_block) || zh_alloc(c, &c->d_segitems, B * c->seg_items_per_block) ||
@@ -895,7 +918,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    // (inputs of a files batch are never cut into speculative segments: seg_min = all ones)
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
              (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu,
-             (uint32_t)ZH_CUT_LEN, cnt, c->d_taskinfo + t0);
+             (uint32_t)ZH_CUT_LEN, cnt, c->d_taskinfo + t0, (uint32_t *)NULL);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
@@ -907,12 +930,12 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
       const uint32_t tpw = zh_tasks_per_wave(c, task_grid);
       if (c->parse_lanes)
          ZH_LAUNCH(zh_parse_lanes, (task_grid + tpw - 1) / tpw, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0), tpw);
+                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0), tpw, (const uint32_t *)NULL);
       else
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
                 (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
       ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
-      ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass);
+      ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, (const uint32_t *)NULL);
    }
    ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt,
              (const zh_sbstate_t *)states, best, c->best_stride, task_bits, (const uint2 *)(c->d_taskinfo + t0));
@@ -1231,8 +1254,23 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)(c->d_ntok + b0), (const uint32_t *)(c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1)),
                 (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
       ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
+      uint32_t *sbflags = c->d_sbflags + s0;
+      ZH_CHECK(c, hipMemsetAsync(sbflags, 0, (size_t)ns * sizeof(uint32_t), st));
       ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, c->cut_len, ntasks, c->d_taskinfo + t0);
+                (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, c->cut_len, ntasks, c->d_taskinfo + t0, sbflags);
+      // The sub-blocks without a chain task go through their four passes on their own, one wave each (zh_parse_loop.h): launched at once, on a
+      // stream of its own — nothing about it depends on the counts the host is about to read
+      if (c->use_loop) {
+         hipStream_t ls = c->loop_stream[k];
+         ZH_CHECK(c, hipEventRecord(c->loop_ev[k][0], st));
+         ZH_CHECK(c, hipStreamWaitEvent(ls, c->loop_ev[k][0], 0));
+         // (its workgroups live for milliseconds and hold 40 KB of LDS each: a matchfinder workgroup, which needs a CU to itself, would wait for
+         // them — they start when the batch's last matchfinder kernel has started / ended: ZULTRA_HIP_OWN_AFTER)
+         if (c->own_after && c->own_after <= 3) ZH_CHECK(c, hipStreamWaitEvent(ls, c->lane_ev[lanes - 1][c->own_after], 0));
+         ZH_LAUNCH(zh_parse_own, ns, 64 * ZH_OWN_WAVES, ls, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, states, best,
+                   c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, (const uint2 *)(c->d_taskinfo + t0), payload, (const uint32_t *)sbflags, ns);
+         ZH_CHECK(c, hipEventRecord(c->loop_ev[k][1], ls));
+      }
       // Does this run have chains at all? With none (text without long repeats) zh_parse_tasks gets the whole chip; with chains it
       // runs as a bounded number of persistent waves per CU, so that the chain workgroups find room the moment they are launched.
       ZH_CHECK(c, hipMemcpyAsync(h_cnt, ntasks, ZH_CNT_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1246,6 +1284,9 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       const uint32_t nchains = h_cnt[ZH_CNT_VLONG] + h_cnt[ZH_CNT_LONG] + h_cnt[ZH_CNT_SHORT] + nseg_chain;
       const uint32_t chain_grid = min(nchains, (uint32_t)ZH_CHAIN_GRID);
       const uint32_t persistent_grid = min(task_grid, c->num_cus * c->task_waves);
+      const bool by_pass = !c->use_loop || nchains || nsegtasks;   // some sub-block has a chain task: those go pass by pass, as all did before
+      const uint32_t *pass_flags = c->use_loop ? (const uint32_t *)sbflags : (const uint32_t *)NULL;
+      c->loop_had[k] = c->use_loop != 0;
       for (int pass = 0; pass <= 3; pass++) {
          // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
          hipStream_t side = c->side_stream[k];
@@ -1273,17 +1314,17 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                       (const uint2 *)taskmap, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, segtasks, (const uint2 *)segwaves, vecs, ntasks);
             ZH_CHECK(c, hipEventRecord(c->seg_ev[k][pass], sg));
          }
-         if (dbg_skip & 2) ;
+         if ((dbg_skip & 2) || !by_pass) ;
          else if (c->parse_lanes) {
             const uint32_t tpw = zh_tasks_per_wave(c, task_grid);
             const uint32_t lane_grid = (task_grid + tpw - 1) / tpw;
             if (nchains || seg_wide || c->always_persistent)
                ZH_LAUNCH(zh_parse_lanes, min(lane_grid, c->num_cus * c->lane_waves), 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                          (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass,
-                         ntasks + ZH_CNT_TASK_TICKET + pass, (const uint2 *)(c->d_taskinfo + t0), tpw);
+                         ntasks + ZH_CNT_TASK_TICKET + pass, (const uint2 *)(c->d_taskinfo + t0), tpw, pass_flags);
             else
                ZH_LAUNCH(zh_parse_lanes, lane_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0), tpw);
+                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0), tpw, pass_flags);
          }
          else if (nchains || seg_wide || c->always_persistent)
             ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
@@ -1295,9 +1336,10 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          if (seg_wide) ZH_CHECK(c, hipStreamWaitEvent(st, c->seg_ev[k][pass], 0));
          if (nchains && !(dbg_skip & 1)) ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
          ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));
-         ZH_LAUNCH(zh_sb_build, ns, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass);
+         if (by_pass) ZH_LAUNCH(zh_sb_build, ns, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, pass_flags);
          ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));
       }
+      if (c->use_loop) ZH_CHECK(c, hipStreamWaitEvent(st, c->loop_ev[k][1], 0));   // every sub-block is through its passes
       ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
                 (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, task_bits, (const uint2 *)(c->d_taskinfo + t0));
       ZH_CHECK(c, hipEventRecord(ev[14], st));
@@ -1344,6 +1386,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          add(c->timing.parse_ms, ev[5 + 2 * pass], ev[6 + 2 * pass]);
          add(c->timing.build_ms, ev[6 + 2 * pass], ev[7 + 2 * pass]);
       }
+      if (c->loop_had[k]) add(c->timing.loop_ms, c->loop_ev[k][0], c->loop_ev[k][1]);
       add(c->timing.post_ms, ev[13], ev[14]);
       add(c->timing.emit_ms, ev[14], ev[15]);
       add(c->timing.d2h_ms, ev[15], ev[16]);

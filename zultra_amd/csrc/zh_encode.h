@@ -185,12 +185,11 @@ struct zh_cl_write_sink {
 };
 
 // ---- zh_sb_build: blockdeflate.c:887-919 for pass 0..3; after pass 3 also :925-992 -----------------------------------
-__global__ void __launch_bounds__(64)
-zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint32_t *__restrict__ hist_part, uint8_t *payload, int pass) {
-   __shared__ zh_sb_ws_t ws;
-   const zh_work_t wk = work[blockIdx.x];
-   zh_sbstate_t *st = states + blockIdx.x;
-   if (st->failed || !st->is_dynamic) return;
+// One sub-block by one wave (all 64 lanes call; the syncs are the wave's: it may be one of several of a workgroup, zh_parse_own); `ws` is the
+// wave's own workspace in LDS. Returns (in every lane) whether the sub-block has failed.
+__device__ __forceinline__ uint32_t zh_sb_build_one(zh_sb_ws_t &ws, const zh_work_t wk, zh_sbstate_t *st, const uint32_t *__restrict__ hist_part, uint8_t *payload, int pass) {
+   if (st->failed) return 1u;
+   if (!st->is_dynamic) return 0u;
    const uint32_t lane = zh_lane();
    uint32_t failed = 0;
 
@@ -203,7 +202,7 @@ zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint
       else
          ws.dist_freq[s - ZH_NLIT] = (int32_t)v;
    }
-   zh_sync();
+   zh_wave_sync();
    if (pass == 3 && lane == 0) {   // at least two distance codes among 0..29 (:893-913)
       int used = 0;
       for (int s = 0; used < 2 && s < ZH_NDIST - 2; s++)
@@ -217,17 +216,17 @@ zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint
             ws.dist_freq[0] = 1;
       }
    }
-   zh_sync();
+   zh_wave_sync();
    if (zh_huff_build_wave(ws.lit_freq, ws.lit_len, ws.lit_code, ZH_NLIT, 15, &ws.sc) < 0) failed = 1;
    if (zh_huff_build_wave(ws.dist_freq, ws.dist_len, ws.dist_code, ZH_NDIST, 15, &ws.sc) < 0) failed = 1;
 
    if (pass < 3) {
       zh_store_codes_wave(st, &ws);
       if (failed && lane == 0) st->failed = 1;
-      return;
+      return failed;
    }
 
-   // the prices literalisation will use: the codes of the last pass (:923)
+   // the prices literalisation will use: the codes of the last pass (:923) (read by later kernels only: plain stores, like the header below)
    for (uint32_t s = lane; s < ZH_NLIT; s += 64) st->pre_lit_len[s] = ws.lit_len[s];
    if (lane < ZH_NDIST) st->pre_dist_len[lane] = ws.dist_len[lane];
 
@@ -237,12 +236,12 @@ zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint
                                                 &ws.sc, false);
       for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws.alt_lit_freq[s] = ws.lit_freq[s];
       if (lane < ZH_NDIST) ws.alt_dist_freq[lane] = ws.dist_freq[lane];
-      zh_sync();
+      zh_wave_sync();
       if (lane == 0) {
          zh_smooth_for_rle_lane(ZH_NLIT, ws.alt_lit_freq, ws.keep);
          zh_smooth_for_rle_lane(ZH_NDIST, ws.alt_dist_freq, ws.keep);
       }
-      zh_sync();
+      zh_wave_sync();
       if (zh_huff_build_wave(ws.alt_lit_freq, ws.alt_lit_len, ws.alt_lit_code, ZH_NLIT, 15, &ws.sc) < 0) failed = 1;
       if (zh_huff_build_wave(ws.alt_dist_freq, ws.alt_dist_len, ws.alt_dist_code, ZH_NDIST, 15, &ws.sc) < 0) failed = 1;
       const int alt_cost = zh_dynamic_cost_wave(ws.alt_lit_freq, ws.alt_dist_freq, ws.alt_lit_len, ws.alt_dist_len, ws.lens,
@@ -257,7 +256,7 @@ zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint
             ws.dist_code[lane] = ws.alt_dist_code[lane];
          }
       }
-      zh_sync();
+      zh_wave_sync();
    }
 
    // ---- blockdeflate.c:947-992: header ---------------------------------------------------------------------------------
@@ -265,7 +264,7 @@ zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint
    const int ndist = zh_defined_count(ws.dist_len, ZH_NDIST, 1);
    for (int s = (int)lane; s < nlit; s += 64) ws.lens[s] = ws.lit_len[s];
    if ((int)lane < ndist) ws.lens[nlit + (int)lane] = ws.dist_len[lane];
-   zh_sync();
+   zh_wave_sync();
 
    const int nruns = zh_cl_make_runs_wave(ws.lens, nlit + ndist, ws.runs, ws.sc.keys);
    uint32_t mkey = 0xFFFFFFFFu;
@@ -284,7 +283,7 @@ zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint
          mkey = ((uint32_t)ss.bits << 6) | (63u - lane);   // cheapest; among equals the last tried (:966)
       }
    }
-   zh_sync();
+   zh_wave_sync();
    const uint32_t mbest = zh_wave_min(mkey);
    const uint32_t anybad = zh_wave_sum(mkey == 0xFFFFFFFEu ? 1u : 0u);
    if (anybad) failed = 1;
@@ -309,13 +308,23 @@ zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint
          ws.tmp = (int32_t)w.nbits;
       }
    }
-   zh_sync();
+   zh_wave_sync();
    if (ws.tmp < 0) failed = 1;
    zh_store_codes_wave(st, &ws);
    if (lane == 0) {
       st->hdr_bits = ws.tmp < 0 ? 0u : (uint32_t)ws.tmp;
       if (failed) st->failed = 1;
    }
+   return failed;
+}
+
+// sbflags != NULL: only the sub-blocks with a chain task (bit 0; zh_list_huge) — the others are rebuilt by the wave of zh_parse_loop that
+// finishes their pass (zh_parse_loop.h)
+__global__ void __launch_bounds__(64)
+zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint32_t *__restrict__ hist_part, uint8_t *payload, int pass, const uint32_t *__restrict__ sbflags) {
+   __shared__ zh_sb_ws_t ws;
+   if (sbflags && !(sbflags[blockIdx.x] & 1u)) return;
+   (void)zh_sb_build_one(ws, work[blockIdx.x], states + blockIdx.x, hist_part, payload, pass);
 }
 
 // ---- prices / sizes of the codes in a sub-block state, staged in LDS by the task kernels -------------------------

@@ -174,7 +174,7 @@ __device__ inline void zh_walk_histogram_wave(uint32_t *hist /* ZH_NSYM, zeroed 
             atomicAdd(&hist[byte], 1u);
       }
    }
-   zh_sync();
+   zh_wave_sync();
 }
 
 // ---- the parse kernel ---------------------------------------------------------------------------------------------

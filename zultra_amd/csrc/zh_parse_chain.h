@@ -422,7 +422,7 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
 __global__ void __launch_bounds__(64)
 zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
              const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ longest, uint64_t longest_stride, uint32_t *hugelist, uint32_t cap, uint4 *segtasks,
-             uint2 *segitems, uint2 *segwaves, uint32_t seg_min, uint32_t cut_len, uint32_t *cnt, uint2 *taskinfo) {
+             uint2 *segitems, uint2 *segwaves, uint32_t seg_min, uint32_t cut_len, uint32_t *cnt, uint2 *taskinfo, uint32_t *sbflags /* zeroed; bit 0: the sub-block has a listed task */) {
    __shared__ uint32_t bnd[ZH_MAXPIECES + 1];
    const uint32_t gt = blockIdx.x;
    if (gt >= cnt[ZH_CNT_TASKS]) return;
@@ -440,6 +440,7 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
    // barrier bitmap, 64 positions per dependent load — on data with few barriers that was a third of that kernel's time
    if (lane == 0) taskinfo[gt] = make_uint2(t0, t1 | (huge ? 0x80000000u : 0u));
    if (!huge) return;
+   if (lane == 0 && sbflags) atomicOr(&sbflags[tm.x], 1u);
    const uint32_t len = t1 - t0;
    if (len >= seg_min) {
       // periodic? (a 258-byte match at most positions: the costs 258 apart copy each other, a speculative start never converges)
@@ -543,7 +544,8 @@ __device__ __forceinline__ void zh_chain_histogram(zh_chain_ws_t &ws, const zh_c
    __syncthreads();
    for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) ws.hist[k] = 0;
    __syncthreads();
-   zh_walk_histogram_wave(ws.hist, T.win, T.prev, (tid >> 6) == 0 ? T.t0 : T.t1, T.t1, T.best);   // the other waves walk nothing (they join the barrier)
+   zh_walk_histogram_wave(ws.hist, T.win, T.prev, (tid >> 6) == 0 ? T.t0 : T.t1, T.t1, T.best);   // the other waves walk nothing
+   zh_sync();   // (the walk ends with a sync of its own wave only: zh_parse_own calls it from waves that are not in step)
    for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) hp[k] = ws.hist[k];
 }
 

@@ -104,7 +104,8 @@ struct zh_lp_batch_t {
    bool fresh;
 };
 
-// Parses the tasks [g0, g1) of one sub-block (all of sub-block tm.x). All 64 lanes call.
+// Parses the tasks [g0, g1) of one sub-block (all of sub-block tm.x). All 64 lanes of ONE wave call; the workspace is the wave's own, and the
+// syncs are the wave's (zh_wave_sync): the wave may be one of several of a workgroup (zh_parse_own).
 __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_t g1, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
                                             const zh_match_t *__restrict__ match, uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride,
                                             const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
@@ -113,7 +114,8 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    const zh_work_t wk = work[tm0.x];
    const zh_sbstate_t *st = states + tm0.x;
    if (st->failed) return;
-   if (!st->is_dynamic && pass > 0) return;   // static sub-blocks are parsed once (blockdeflate.c:836-858)
+   const bool sb_dynamic = st->is_dynamic != 0;
+   if (!sb_dynamic && pass > 0) return;   // static sub-blocks are parsed once (blockdeflate.c:836-858)
    const zh_block_t blk = blocks[wk.block];
    const uint8_t *win = data + blk.win_off;
    const uint32_t prev = blk.prev;
@@ -127,7 +129,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    const uint64_t lt_mask = (1ull << lane) - 1ull, lt_quad = (1ull << (lane & ~3u)) - 1ull;
 
    const uint64_t tic0 = ZH_LP_CLOCK();
-   zh_sync();   // the previous group is done with the workspace
+   zh_wave_sync();   // the previous group is done with the workspace
    // ---- prices of the codes in force; unused symbols price at 9 / 6 bits (blockdeflate.c:873-881) ---------------
    for (uint32_t k = lane; k < ZH_NLIT; k += 64) {
       const uint32_t l = st->lit_len[k];
@@ -138,12 +140,12 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
       const uint32_t l = st->dist_len[sym];
       ws.distprice[k] = (uint8_t)((l ? l : 6u) + (uint32_t)zh_dist_xbits(sym));
    }
-   zh_sync();
+   zh_wave_sync();
    for (uint32_t e = lane; e < 256; e += 64) {
       const int idx = zh_len_idx(e + 3);
       ws.lencost[e] = (uint8_t)(ws.litprice[257 + idx] + zh_lenidx_xbits(idx));
    }
-   zh_sync();
+   zh_wave_sync();
    // price << 9 | (39 - k) of the lane's ten lengths k = 3 + 9 q + j
    uint32_t kc[ZH_LP_KPL];
 #pragma unroll
@@ -162,7 +164,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
       if (ti.y >> 31) continue;
       const uint32_t t0 = ti.x, t1 = ti.y;
       const uint32_t np = zh_task_pieces(ws.bnd, bar, prev, t0, t1, lane);
-      zh_sync();
+      zh_wave_sync();
       if (nlongp + nshortp + np <= ZH_LP_MAXP) {
          const uint32_t lo = lane < np ? ws.bnd[lane] : 0u, hi = lane < np ? ws.bnd[lane + 1] : 0u;
          const bool is_l = hi - lo >= ZH_LP_LONG, is_s = hi > lo && !is_l;   // (empty pieces are dropped)
@@ -181,7 +183,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
          nshortp += (uint32_t)zh_popc64(ms);
          parsed |= 1ull << (gt - g0);
       }
-      zh_sync();
+      zh_wave_sync();
    }
    const uint32_t npieces = nlongp + nshortp;
    ZH_LP_COUNT(3, 1);
@@ -503,17 +505,17 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    const uint64_t tic2 = ZH_LP_CLOCK();
 
    // ---- histogram of the group's parse; the per-sub-block sum is taken by zh_sb_build ------------------------------------
-   if (st->is_dynamic) {
+   if (sb_dynamic) {
       __threadfence_block();
-      zh_sync();
+      zh_wave_sync();
       for (uint32_t k = lane; k < ZH_NSYM; k += 64) ws.hist[k] = 0;
-      zh_sync();
+      zh_wave_sync();
       for (uint32_t gt = g0; gt < g1; gt++) {
          if (!((parsed >> (gt - g0)) & 1ull)) continue;
          const uint2 ti = taskinfo[gt];
          zh_walk_histogram_wave(ws.hist, win, prev, ti.x, ti.y, best);
       }
-      zh_sync();
+      zh_wave_sync();
       bool first = true;
       for (uint32_t gt = g0; gt < g1; gt++) {
          if (!((parsed >> (gt - g0)) & 1ull)) continue;
@@ -535,7 +537,8 @@ __global__ void __launch_bounds__(64)
 zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
                const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all,
-               uint32_t *hist_part, int pass, uint32_t *ticket, const uint2 *__restrict__ taskinfo, uint32_t tasks_per_wave /* 1 .. ZH_LP_TASKS */) {
+               uint32_t *hist_part, int pass, uint32_t *ticket, const uint2 *__restrict__ taskinfo, uint32_t tasks_per_wave /* 1 .. ZH_LP_TASKS */,
+               const uint32_t *__restrict__ sbflags /* != NULL: only sub-blocks with a chain task (bit 0); zh_parse_loop takes the others through all their passes */) {
    __shared__ zh_lp_ws_t ws;
    const uint32_t ntasks = cnt[ZH_CNT_TASKS];
    for (;;) {
@@ -552,6 +555,10 @@ zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          const uint32_t sb = taskmap[g].x;
          uint32_t ge = g + 1;
          while (ge < g1 && taskmap[ge].x == sb) ge++;
+         if (sbflags && !(sbflags[sb] & 1u)) {
+            g = ge;
+            continue;
+         }
          zh_lp_group(ws, g, ge, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, cost_all, hist_part, pass, taskinfo);
          g = ge;
       }

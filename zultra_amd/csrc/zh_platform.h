@@ -230,5 +230,8 @@ __device__ __forceinline__ uint32_t zh_rank_below(uint64_t m) { return __builtin
 // steps stay in flight together; the CPU emulator of tests/emu runs a lane until its next collective, and makes this one.
 __device__ __forceinline__ void zh_lockstep_point() {}
 
+// a wave's own global stores are out (before a barrier after which other waves of the workgroup, or the wave itself, read them back)
+__device__ __forceinline__ void zh_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ uint32_t zh_atomic_add_lds(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t zh_atomic_add_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
