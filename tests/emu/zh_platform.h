@@ -285,6 +285,14 @@ inline uint32_t zh_wave_sum(uint32_t v) {
       return s;
    });
 }
+inline uint32_t zh_wave_incl_max(uint32_t v) {
+   using namespace zh_emu;
+   return (uint32_t)collect(v, [] {
+      uint64_t m = 0;
+      for (int i = wave_base(); i <= g_cur; i++) m = std::max(m, g_slot[i]);
+      return m;
+   });
+}
 inline uint32_t zh_wave_excl_sum(uint32_t v) {
    using namespace zh_emu;
    return (uint32_t)collect(v, [] {

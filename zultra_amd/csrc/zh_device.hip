@@ -147,6 +147,7 @@ struct zultra_hip_ctx_s {
    uint32_t *d_sbflags;                      // per sub-block: bit 0 = has a chain task (zh_list_huge)
    int use_loop;                             // ZULTRA_HIP_PARSE_LOOP (default 0)
    int own_after;                            // ZULTRA_HIP_OWN_AFTER
+   int files_own;                            // files mode: inputs without a chain task through zh_parse_own<1> (ZULTRA_HIP_FILES_OWN, default 1)
    bool loop_had[ZH_MAX_RUNS];               // the last batch launched zh_parse_loop for this run
    hipStream_t seg_stream[ZH_MAX_RUNS];      // per run: zh_parse_segments, likewise
    hipEvent_t seg_ev[ZH_MAX_RUNS][4];        // per pass: join
@@ -219,6 +220,11 @@ __global__ void __launch_bounds__(64) zh_selftest_kernel(uint32_t seed, uint32_t
       if (zh_wave_min_bcast(x) != mn) errors++;
       if (zh_wave_sum(x) != sm) errors++;
       if (zh_wave_excl_sum(x) != ex) errors++;
+      {
+         uint32_t im = 0;
+         for (uint32_t k = 0; k <= lane; k++) im = max(im, v[k]);
+         if (zh_wave_incl_max(x) != im) errors++;
+      }
       if (zh_row_min(x) != rmn) errors++;
       if (zh_readlane(x, (int)(round & 63)) != v[round & 63]) errors++;
       if (zh_shfl(x, (int)((lane * 7 + round) & 63)) != v[(lane * 7 + round) & 63]) errors++;
@@ -580,6 +586,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->lane_waves = lw ? (uint32_t)max(1, min(16, atoi(lw))) : 12u;
       const char *pl2 = getenv("ZULTRA_HIP_PARSE_LOOP");   // 1: sub-blocks without a chain task go through their passes on their own (zh_parse_own); 0: every sub-block pass by pass
       c->use_loop = pl2 ? atoi(pl2) : 0;   // (off: measured on the 100 MB step, 40.4 ms with it against 37.9 — zh_parse_loop.h)
+      const char *fo = getenv("ZULTRA_HIP_FILES_OWN");
+      c->files_own = (c->files_mode && c->parse_lanes) ? (fo ? atoi(fo) : 1) : 0;
       const char *oa = getenv("ZULTRA_HIP_OWN_AFTER");   // zh_parse_own starts after this stage of the batch's LAST run: 0 at once, 1 its upload, 2 zh_mf_group, 3 zh_mf_frontier
       c->own_after = oa ? atoi(oa) : 0;
       const char *lt = getenv("ZULTRA_HIP_LANE_TASKS");   // tasks per wave of zh_parse_lanes (tuning experiments); not set: by the size of the run
@@ -916,9 +924,16 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    ZH_LAUNCH(zh_sb_init, nb, 64, st, (const uint16_t *)(c->d_tok_info + (uint64_t)b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
    const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
    // (inputs of a files batch are never cut into speculative segments: seg_min = all ones)
+   uint32_t *sbflags = c->files_own ? c->d_sbflags + b0 : (uint32_t *)NULL;   // (one sub-block per input)
+   if (sbflags) ZH_CHECK(c, hipMemsetAsync(sbflags, 0, (size_t)nb * sizeof(uint32_t), st));
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
              (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu,
-             (uint32_t)ZH_CUT_LEN, cnt, c->d_taskinfo + t0, (uint32_t *)NULL);
+             (uint32_t)ZH_CUT_LEN, cnt, c->d_taskinfo + t0, sbflags);
+   // An input without a chain task — nearly all of them — goes through its four passes on ONE wave, in one launch (zh_parse_loop.h: for
+   // max-blocks that lost to the pass-by-pass kernels; here a pass over an input is two tasks, and eight launches per batch wait for each other)
+   if (sbflags)
+      ZH_LAUNCH(zh_parse_own<1u>, nb, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, states, best,
+                c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, (const uint2 *)(c->d_taskinfo + t0), payload, (const uint32_t *)sbflags, nb);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
@@ -930,12 +945,12 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
       const uint32_t tpw = zh_tasks_per_wave(c, task_grid);
       if (c->parse_lanes)
          ZH_LAUNCH(zh_parse_lanes, (task_grid + tpw - 1) / tpw, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0), tpw, (const uint32_t *)NULL);
+                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0), tpw, (const uint32_t *)sbflags);
       else
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
                 (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
       ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
-      ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, (const uint32_t *)NULL);
+      ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, (const uint32_t *)sbflags);
    }
    ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt,
              (const zh_sbstate_t *)states, best, c->best_stride, task_bits, (const uint2 *)(c->d_taskinfo + t0));
@@ -1267,7 +1282,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          // (its workgroups live for milliseconds and hold 40 KB of LDS each: a matchfinder workgroup, which needs a CU to itself, would wait for
          // them — they start when the batch's last matchfinder kernel has started / ended: ZULTRA_HIP_OWN_AFTER)
          if (c->own_after && c->own_after <= 3) ZH_CHECK(c, hipStreamWaitEvent(ls, c->lane_ev[lanes - 1][c->own_after], 0));
-         ZH_LAUNCH(zh_parse_own, ns, 64 * ZH_OWN_WAVES, ls, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, states, best,
+         ZH_LAUNCH(zh_parse_own<ZH_OWN_WAVES>, ns, 64 * ZH_OWN_WAVES, ls, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, states, best,
                    c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, (const uint2 *)(c->d_taskinfo + t0), payload, (const uint32_t *)sbflags, ns);
          ZH_CHECK(c, hipEventRecord(c->loop_ev[k][1], ls));
       }

@@ -107,6 +107,32 @@ __device__ __forceinline__ uint32_t zh_mf_slice(uint32_t M) { return (((M + ZH_M
 // one more read of the order and one more write of the payload per level — 0.7 of this kernel's 4 ms per 50 MB and a quarter of its
 // HBM traffic.) The last five window positions drop out of the orders before they reach the 6-gram order: theirs go to tail[pos]
 // (the frontier's position-indexed table: entries from W - 5 on are free, the 6-gram order has at most W - 5 entries).
+// Run-interior positions: the byte before and the six from the position on are all the same. Such a position never enters the orders (round 4,
+// zh_mf_group_lds.h): the nearest earlier occurrence of its 3-, 4- and 5-gram is the position before it, its 6-gram class "cccccc" is
+// never walked (zh_mf_frontier takes the frontier of such positions from the run table) — and in indented source code or zero-padded
+// binaries they are a fifth of all positions, one bigram class that fits no chunk. g = the window (LDS), readable up to p + 5 < W.
+__device__ __forceinline__ bool zh_mf_run_interior(const uint8_t *g, uint32_t p, uint32_t W) {
+   if (p == 0 || p + 5u >= W) return false;
+   // (the four bytes from p on first, with two aligned words: on text hardly any position gets past them)
+   const uint32_t *g32 = (const uint32_t *)g;
+   const uint32_t w = zh_funnel(g32[(p >> 2) + 1], g32[p >> 2], p * 8u);
+   const uint32_t c = w & 0xffu;
+   if (w != c * 0x01010101u) return false;
+   return g[p - 1] == c && g[p + 4] == c && g[p + 5] == c;
+}
+// ... and the other side of it: a position whose K-gram is K times the byte before it has that position as its nearest earlier occurrence,
+// in the orders or not (distance 1, recorded as 0)
+template <int K>
+__device__ __forceinline__ bool zh_mf_prev_is_neighbour(const uint8_t *g, uint32_t p) {
+   if (p == 0) return false;
+   const uint32_t c = g[p - 1];
+   if (g[p] != c) return false;   // (nearly always)
+   bool same = g[p + 1] == c && g[p + 2] == c;
+   if (K >= 4) same = same && g[p + 3] == c;
+   if (K >= 5) same = same && g[p + 4] == c;
+   return same;
+}
+
 template <int MODE, bool HAVE = false, int NEXT = -1, int PAY = 0, int PREV = 0>
 __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, uint32_t M, const uint32_t *src, uint32_t *dst, uint32_t *hist,
                                        uint32_t *wave_tot, uint32_t W = 0, uint32_t *hist_next = nullptr, uint32_t M_next = 0,
@@ -148,7 +174,7 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
       }                                                                                             \
       else if (MODE == 10) {                                                                        \
          e = (idx) | ((uint32_t)gwin[idx] << 24);                                                   \
-         d = gwin[(idx) + 1];                                                                       \
+         d = zh_mf_run_interior(gwin, (idx), W) ? 0xffffffffu : (uint32_t)gwin[(idx) + 1];          \
       }                                                                                             \
       else if (MODE == 11) {                                                                        \
          e = src[idx];                                                                              \
@@ -185,7 +211,7 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
       else if (MODE == 9)                                                                           \
          d = gwin[aux_rs[e]];                                                                       \
       else if (MODE == 10)                                                                          \
-         d = gwin[(idx) + 1];                                                                       \
+         d = zh_mf_run_interior(gwin, (idx), W) ? 0xffffffffu : (uint32_t)gwin[(idx) + 1];          \
       else if (MODE == 11)                                                                          \
          d = e >> 24;                                                                               \
       else                                                                                          \
@@ -283,7 +309,8 @@ __device__ inline void zh_mf_sort_pass(const uint8_t *win, const uint8_t *gwin, 
                      same = zh_ld32(gwin + q) == zh_ld32(gwin + pos) && (PREV == 4 || gwin[q + 4] == gwin[pos + 4]);
                }
                const uint32_t dist = pos - q;
-               const uint32_t dd = (same && dist <= ZH_MAX_DIST) ? dist - 1u : 0xffffu;
+               uint32_t dd = (same && dist <= ZH_MAX_DIST) ? dist - 1u : 0xffffu;
+               if (zh_mf_prev_is_neighbour<PREV>(gwin, pos)) dd = 0;   // (the position before it: in the order or not, zh_mf_run_interior)
                if (PREV == 3) p4[u] = dd | 0xffff0000u;
                if (PREV == 4) p4[u] = (p4[u] & 0xffffu) | (dd << 16);
                if (PREV == 5) q4[u] = dd;

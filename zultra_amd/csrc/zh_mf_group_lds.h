@@ -81,7 +81,7 @@ __device__ __forceinline__ zh_mfl_t zh_mfl_layout(uint32_t *dyn_lds, uint32_t W,
 // zh_mf_sort_pass). Wave w takes the w-th stretch of IN; the lanes of a 64-element step with the same digit find each other with eight
 // ballots and the first of them counts them all (no atomics), a 256-thread scan turns the counts into places.
 template <int K, int PREVK>
-__device__ inline uint32_t zh_mfl_pass(const zh_mfl_t &L, const uint32_t *lwin32, uint32_t W, uint32_t n, const uint32_t *IN, uint32_t *OUT, uint2 *tail, uint64_t &mfg_t_) {
+__device__ inline uint32_t zh_mfl_pass(const zh_mfl_t &L, const uint32_t *lwin32, uint32_t W, uint32_t n, const uint32_t *IN, uint32_t *OUT, uint2 *tail, bool excl, uint64_t &mfg_t_) {
    const uint8_t *gwin = (const uint8_t *)lwin32;
    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
    const uint32_t stretch = (((n + ZH_MF_WAVES - 1u) / ZH_MF_WAVES) + 63u) & ~63u;   // <= 256
@@ -118,6 +118,7 @@ __device__ inline uint32_t zh_mfl_pass(const zh_mfl_t &L, const uint32_t *lwin32
                   const uint32_t dist = pos - q;
                   if (same && dist <= ZH_MAX_DIST) dd = dist - 1u;
                }
+               if (excl && zh_mf_prev_is_neighbour<PREVK>(gwin, pos)) dd = 0;   // (the position before it may not be in the order: zh_mf_run_interior; `excl`: this window has such positions)
                uint32_t both = dd | 0xffff0000u;
                if (PREVK == 3) L.D34[id] = both;
                if (PREVK == 4) {
@@ -211,11 +212,11 @@ __device__ inline uint32_t zh_mfl_pass(const zh_mfl_t &L, const uint32_t *lwin32
 
 // The chunk X[0 .. n) — whole bigram classes, each ascending in position — to its part of the 6-gram order: S_out / P_out point at the
 // chunk's first entry of the segment's order. Returns the number of entries written.
-__device__ inline uint32_t zh_mfl_refine(const zh_mfl_t &L, const uint32_t *lwin32, uint32_t W, uint32_t n, uint32_t *S_out, uint2 *P_out, uint2 *tail, uint64_t &mfg_t_) {
-   const uint32_t n1 = zh_mfl_pass<2, 0>(L, lwin32, W, n, L.X, L.Y, tail, mfg_t_);
-   const uint32_t n2 = zh_mfl_pass<3, 3>(L, lwin32, W, n1, L.Y, L.X, tail, mfg_t_);
-   const uint32_t n3 = zh_mfl_pass<4, 4>(L, lwin32, W, n2, L.X, L.Y, tail, mfg_t_);
-   const uint32_t n4 = zh_mfl_pass<5, 5>(L, lwin32, W, n3, L.Y, L.X, tail, mfg_t_);
+__device__ inline uint32_t zh_mfl_refine(const zh_mfl_t &L, const uint32_t *lwin32, uint32_t W, uint32_t n, uint32_t *S_out, uint2 *P_out, uint2 *tail, bool excl, uint64_t &mfg_t_) {
+   const uint32_t n1 = zh_mfl_pass<2, 0>(L, lwin32, W, n, L.X, L.Y, tail, excl, mfg_t_);
+   const uint32_t n2 = zh_mfl_pass<3, 3>(L, lwin32, W, n1, L.Y, L.X, tail, excl, mfg_t_);
+   const uint32_t n3 = zh_mfl_pass<4, 4>(L, lwin32, W, n2, L.X, L.Y, tail, excl, mfg_t_);
+   const uint32_t n4 = zh_mfl_pass<5, 5>(L, lwin32, W, n3, L.Y, L.X, tail, excl, mfg_t_);
    ZH_MFG_LAP(3);
    for (uint32_t idx = threadIdx.x; idx < n4; idx += ZH_MF_THREADS) {
       const uint32_t e = L.X[idx], pos = e & ZH_MFL_POS_MASK, id = e >> ZH_MFL_ID_SHIFT;
@@ -277,14 +278,17 @@ __device__ inline void zh_mf_group_body_lds(const uint8_t *win, uint32_t *dyn_ld
       // the whole window is one chunk: the bigram order is two more passes in LDS
       for (uint32_t k = tid; k < M3; k += ZH_MF_THREADS) L.X[k] = k | (k << ZH_MFL_ID_SHIFT);
       zh_sync_lds();
-      zh_mfl_pass<1, 0>(L, lwin32, W, M3, L.X, L.Y, prev, mfg_t_);
-      zh_mfl_pass<0, 0>(L, lwin32, W, M3, L.Y, L.X, prev, mfg_t_);
-      zh_mfl_refine(L, lwin32, W, M3, SA, prev, prev, mfg_t_);
+      zh_mfl_pass<1, 0>(L, lwin32, W, M3, L.X, L.Y, prev, false, mfg_t_);
+      zh_mfl_pass<0, 0>(L, lwin32, W, M3, L.Y, L.X, prev, false, mfg_t_);
+      zh_mfl_refine(L, lwin32, W, M3, SA, prev, prev, false, mfg_t_);
    }
    else if (M3 != 0) {
       uint32_t *hist2 = hist + ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1;
+      // (run-interior positions get no digit in the first pass and drop out: zh_mf_run_interior)
       zh_mf_sort_pass<10, false, 11>(gwin, gwin, M3, nullptr, SA, hist, wave_tot, W, hist2, M3);   // by byte 1; elements position | byte 0 << 24
-      zh_mf_sort_pass<11, true>(gwin, gwin, M3, SA, SB, hist2, wave_tot, W);                        // by byte 0: SB = the bigram order
+      const uint32_t Mb = (wave_tot + ZH_MF_WAVES + 1 + ZH_MF_WAVES * 256)[255];                  // what it wrote (the end of the last digit's run: cursor[255])
+      const bool excl = Mb != M3;                                                                // this window has run-interior positions
+      zh_mf_sort_pass<11, true>(gwin, gwin, Mb, SA, SB, hist2, wave_tot, W);                        // by byte 0: SB = the bigram order, Mb entries
       if (stop == 2) return;
       ZH_MFG_LAP(1);
       uint32_t s = 0, out_base = 0;
@@ -293,12 +297,12 @@ __device__ inline void zh_mf_group_body_lds(const uint8_t *win, uint32_t *dyn_ld
    do {                                                                               \
       _Pragma("unroll") for (uint32_t j = 0; j < 4; j++) {                            \
          const uint32_t k_ = tid + j * ZH_MF_THREADS;                                 \
-         en[j] = (k_ < L.cap && (from_) + k_ < M3) ? SB[(from_) + k_] : 0u;           \
+         en[j] = (k_ < L.cap && (from_) + k_ < Mb) ? SB[(from_) + k_] : 0u;           \
       }                                                                               \
    } while (0)
       ZH_MFL_REQUEST(0u);
-      while (s < M3) {
-         const uint32_t nload = min(L.cap, M3 - s);
+      while (s < Mb) {
+         const uint32_t nload = min(L.cap, Mb - s);
 #pragma unroll
          for (uint32_t j = 0; j < 4; j++) {
             const uint32_t k = tid + j * ZH_MF_THREADS;
@@ -319,12 +323,12 @@ __device__ inline void zh_mf_group_body_lds(const uint8_t *win, uint32_t *dyn_ld
             }
          }
          zh_sync_lds();
-         const uint32_t n = (s + nload == M3) ? nload : L.misc[0];
+         const uint32_t n = (s + nload == Mb) ? nload : L.misc[0];
          if (n == 0) {
             ZH_MFG_LAP(2);
             // one class fills the chunk and goes on: its end is the first entry of another bigram, found in two rounds of probes
             const uint32_t big0 = zh_load32_at(lwin32, L.X[0] & ZH_MFL_POS_MASK) & 0xffffu;
-            const uint32_t rem = M3 - s;
+            const uint32_t rem = Mb - s;
             const uint32_t step = (rem + ZH_MF_THREADS - 1u) / ZH_MF_THREADS;
             {
                const uint32_t i = min((tid + 1u) * step, rem);
@@ -354,10 +358,31 @@ __device__ inline void zh_mf_group_body_lds(const uint8_t *win, uint32_t *dyn_ld
          ZH_MFL_REQUEST(s + n);   // the next chunk's elements are on their way while this one is refined
          ZH_MFG_LAP(2);
          ZH_MFG_COUNT(12, 1);
-         out_base += zh_mfl_refine(L, lwin32, W, n, SA + out_base, prev + out_base, prev, mfg_t_);
+         out_base += zh_mfl_refine(L, lwin32, W, n, SA + out_base, prev + out_base, prev, excl, mfg_t_);
          s += n;
       }
 #undef ZH_MFL_REQUEST
+      // the run-interior positions: entries of their own at the top of the order (the sorted part ends exactly where they begin: together
+      // they are the M6 positions with six bytes ahead), each marked as a class head — nothing walks into them, zh_mf_frontier takes their
+      // frontier from the run table — with the position before them as the nearest earlier occurrence of their 3-, 4- and 5-gram
+      if (excl) {
+         const uint32_t M6 = min(Qn, W >= 6 ? W - 5 : 0u);
+         if (tid == 0) L.misc[3] = 0;
+         zh_sync_lds();
+         for (uint32_t base = 0; base < M6; base += ZH_MF_THREADS) {
+            const uint32_t pi = base + tid;
+            const bool inter = pi < M6 && zh_mf_run_interior(gwin, pi, W);
+            const uint64_t m = zh_ballot(inter);
+            uint32_t at = 0;
+            if (m && (tid & 63u) == 0) at = zh_atomic_add_lds(&L.misc[3], (uint32_t)zh_popc64(m));
+            at = zh_readfirstlane(at);
+            if (inter) {
+               const uint32_t slot = M6 - 1u - (at + zh_rank_below(m));
+               SA[slot] = pi | ZH_MF_HEAD;
+               prev[slot] = make_uint2(0u, 0u);
+            }
+         }
+      }
    }
    if (stop == 5) return;
    __threadfence_block();

@@ -34,16 +34,17 @@
 #define ZH_OWN_OCC 3
 #endif
 
-// grid = the run's sub-blocks
+// grid = the run's sub-blocks; WAVES = waves per workgroup (4 for max-blocks; 1 in files mode, where a sub-block is a 4 KiB input of two tasks)
 // (waves per SIMD the compiler allocates registers for: at four — the quad kernel's own occupancy — it spills 24 registers; 40 KB of LDS per
 // workgroup would let four workgroups onto a CU)
-__global__ void __launch_bounds__(64 * ZH_OWN_WAVES, ZH_OWN_OCC)
+template <uint32_t WAVES>
+__global__ void __launch_bounds__(64 * WAVES, ZH_OWN_OCC)
 zh_parse_own(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
              const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
              zh_sbstate_t *states, uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all, uint32_t *hist_part, const uint2 *__restrict__ taskinfo,
              uint8_t *payload, const uint32_t *__restrict__ sbflags, uint32_t nsubs) {
    __shared__ union {
-      zh_lp_ws_t lp[ZH_OWN_WAVES];   // a workspace per wave while they parse ...
+      zh_lp_ws_t lp[WAVES];   // a workspace per wave while they parse ...
       zh_sb_ws_t sb;                 // ... the code builder's between the passes
    } ws;
    __shared__ uint32_t stop;
@@ -55,7 +56,7 @@ zh_parse_own(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ bl
    const bool dynamic = st->is_dynamic != 0;
    const uint32_t wave = threadIdx.x >> 6;
    // the wave's share of the tasks: contiguous, so that its groups of eight are the same groups a wave of zh_parse_lanes would form
-   const uint32_t t_lo = wk.task_base + (uint32_t)((uint64_t)wk.ntasks * wave / ZH_OWN_WAVES), t_hi = wk.task_base + (uint32_t)((uint64_t)wk.ntasks * (wave + 1u) / ZH_OWN_WAVES);
+   const uint32_t t_lo = wk.task_base + (uint32_t)((uint64_t)wk.ntasks * wave / WAVES), t_hi = wk.task_base + (uint32_t)((uint64_t)wk.ntasks * (wave + 1u) / WAVES);
    for (int pass = 0; pass <= 3; pass++) {
       for (uint32_t g = t_lo; g < t_hi; g += ZH_LP_TASKS)
          zh_lp_group(ws.lp[wave], g, min(t_hi, g + ZH_LP_TASKS), data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, cost_all,

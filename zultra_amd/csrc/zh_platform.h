@@ -135,6 +135,18 @@ __device__ __forceinline__ uint32_t zh_wave_excl_sum(uint32_t v) {
    return x - v;
 }
 
+// inclusive running maximum over the 64 lanes (unsigned values; 0 is the identity): the same ten DPP steps with max
+__device__ __forceinline__ uint32_t zh_wave_incl_max(uint32_t v) {
+   uint32_t x = v;
+   x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true));
+   x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true));
+   x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true));
+   x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true));
+   x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));
+   x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));
+   return x;
+}
+
 // issue priority of the calling wave (0..3): the SIMD's arbiter serves the highest priority first, then the oldest wave. A wave that
 // carries a serial dependency chain next to throughput waves of other kernels needs it: at equal priority it gets one issue
 // slot in as many as there are ready waves on its SIMD.

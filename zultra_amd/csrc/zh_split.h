@@ -37,17 +37,6 @@ __device__ inline uint64_t zh_chain_mask(uint32_t len, uint32_t &carry, uint32_t
    return mask;
 }
 
-// inclusive running maximum over the 64 lanes
-__device__ inline uint32_t zh_wave_incl_max(uint32_t v) {
-   const int lane = (int)zh_lane();
-#pragma unroll
-   for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t y = zh_shfl(v, (lane - d) & 63);
-      if (lane >= d) v = max(v, y);
-   }
-   return v;
-}
-
 // first barrier at or after block-relative position r, limited to rend (returns rend if there is none before it)
 __device__ inline uint32_t zh_first_barrier(const uint64_t *bar, uint32_t r, uint32_t rend) {
    if (r >= rend) return rend;
@@ -103,7 +92,7 @@ zh_barriers(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ 
          const uint32_t len = pm[u] & 0xffffu;
          pm[u] = r + 256 < hi ? rows[4u * (r + 256)] : 0u;
          const uint32_t incl = zh_wave_incl_max(r < hi ? r + max(len, 1u) : 0u);
-         const uint32_t up = zh_shfl(incl, (int)((lane - 1) & 63));
+         const uint32_t up = zh_wave_shr1(incl, 0u);   // (lane 0's is not used)
          const uint32_t excl = lane ? max(reach_before, up) : reach_before;
          const uint64_t bm = zh_ballot(r < hi && excl <= r);
          if (lane == 0) bar[base >> 6] = bm;
