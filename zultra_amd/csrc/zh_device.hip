@@ -147,7 +147,7 @@ struct zultra_hip_ctx_s {
    uint32_t *d_sbflags;                      // per sub-block: bit 0 = has a chain task (zh_list_huge)
    int use_loop;                             // ZULTRA_HIP_PARSE_LOOP (default 0)
    int own_after;                            // ZULTRA_HIP_OWN_AFTER
-   int files_own;                            // files mode: inputs without a chain task through zh_parse_own<1> (ZULTRA_HIP_FILES_OWN, default 1)
+   int files_own;                            // files mode: inputs without a chain task through zh_parse_own<1> (ZULTRA_HIP_FILES_OWN, default 0)
    bool loop_had[ZH_MAX_RUNS];               // the last batch launched zh_parse_loop for this run
    hipStream_t seg_stream[ZH_MAX_RUNS];      // per run: zh_parse_segments, likewise
    hipEvent_t seg_ev[ZH_MAX_RUNS][4];        // per pass: join
@@ -587,7 +587,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       const char *pl2 = getenv("ZULTRA_HIP_PARSE_LOOP");   // 1: sub-blocks without a chain task go through their passes on their own (zh_parse_own); 0: every sub-block pass by pass
       c->use_loop = pl2 ? atoi(pl2) : 0;   // (off: measured on the 100 MB step, 40.4 ms with it against 37.9 — zh_parse_loop.h)
       const char *fo = getenv("ZULTRA_HIP_FILES_OWN");
-      c->files_own = (c->files_mode && c->parse_lanes) ? (fo ? atoi(fo) : 1) : 0;
+      c->files_own = (c->files_mode && c->parse_lanes) ? (fo ? atoi(fo) : 0) : 0;   // (off: measured 717 k files/s with it against 795 k, 262 144 inputs)
       const char *oa = getenv("ZULTRA_HIP_OWN_AFTER");   // zh_parse_own starts after this stage of the batch's LAST run: 0 at once, 1 its upload, 2 zh_mf_group, 3 zh_mf_frontier
       c->own_after = oa ? atoi(oa) : 0;
       const char *lt = getenv("ZULTRA_HIP_LANE_TASKS");   // tasks per wave of zh_parse_lanes (tuning experiments); not set: by the size of the run
