@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Prints registers / LDS / occupancy of every kernel in zh_device.hip as reported by the compiler (no GPU needed)."""
+"""Prints registers / LDS / occupancy of every kernel in zh_device.hip as reported by the compiler (no GPU needed); exits 1 when a kernel
+uses scratch memory (spilled registers, arrays indexed at run time, out-of-line calls): none of the product's kernels may."""
 import os
 import re
 import subprocess
@@ -27,3 +28,7 @@ print("%-34s %6s %6s %8s %9s %6s" % ("kernel", "VGPRs", "SGPRs", "scratch", "LDS
 for k, r in rows.items():
     print("%-34s %6s %6s %8s %9s %6s" % (k[:34], r.get("VGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize [bytes/lane]"), r.get("LDS Size [bytes/block]"),
                                        r.get("Occupancy [waves/SIMD]")))
+bad = [k for k, r in rows.items() if r.get("ScratchSize [bytes/lane]", "0") != "0"]
+if bad:
+    print("kernels with scratch memory: %s" % ", ".join(bad))
+    sys.exit(1)

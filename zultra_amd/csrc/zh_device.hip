@@ -552,6 +552,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       // the matchfinder kernels take all their LDS dynamically (zh_matchfinder.h): more than the 64 KiB default limit
       ZH_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&zh_mf_group<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ZH_MF_GROUP_LDS));
       ZH_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&zh_mf_frontier<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ZH_MF_FRONTIER_LDS));
+      ZH_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&zh_mf_group_big), hipFuncAttributeMaxDynamicSharedMemorySize, ZH_MF_GROUP_LDS));
    }
    ZH_CHECK(c, hipStreamCreate(&c->stream));
    for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->ev[i]));
@@ -667,7 +668,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) || zh_alloc(c, &c->d_taskinfo, c->max_tasks) ||
        zh_alloc(c, &c->d_sbflags, B * c->max_subs) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
-       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 16) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, 3 * c->max_tasks) ||
+       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 3 * ZH_MAX_RUNS) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, 3 * c->max_tasks) ||
        zh_alloc(c, &c->d_segtasks, B * c->seg_tasks_per_block) || zh_alloc(c, &c->d_segwaves, B * c->seg_items_per_block) || zh_alloc(c, &c->d_segitems, B * c->seg_items_per_block) ||
        zh_alloc(c, &c->d_vecs, B * c->seg_items_per_block * 2 * ZH_VEC) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
@@ -895,7 +896,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    const uint32_t mf_grid = min(nb, c->num_cus);   // persistent workgroups, one per CU (zh_matchfinder.h)
    const uint64_t tasks_per_block = c->max_tasks / c->max_blocks;
    const uint64_t t0 = (uint64_t)b0 * tasks_per_block;
-   uint32_t *ctr = c->d_chunk_ctr + (size_t)b0 * 2 + 2 * (size_t)k;   // this run's counters: 2 per segment (= input) + the two tickets
+   uint32_t *ctr = c->d_chunk_ctr + (size_t)b0 * 2 + 3 * (size_t)k;   // this run's counters: 2 per segment (= input) + the three tickets
    uint32_t *sa = c->d_sort_a + (uint64_t)b0 * c->sort_stride, *sb = c->d_sort_b + (uint64_t)b0 * c->sort_stride;
    uint2 *p3 = c->d_prev3 + (uint64_t)b0 * c->sort_stride;
    uint32_t *rn = c->d_runs + (uint64_t)b0 * c->run_stride;
@@ -911,6 +912,9 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    // (counters, payload slots and the copies of the results are the caller's, on the stream the runs fork from: zh_enqueue_files)
    ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), sa, sb, p3, rn, c->sort_stride, c->run_stride, 0, nb,
              ctr + (size_t)nb * 2 + 1, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride, c->mf_lds_cap);
+   if (c->mf_lds_cap && c->seg_W > ZH_MFL_MAXCAP)   // (inputs of <= 4 KiB are one chunk of zh_mf_group: nothing is ever noted)
+      ZH_LAUNCH_LDS(zh_mf_group_big, min(mf_grid, 32u), ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), sa, sb, p3, (const uint32_t *)rn, c->sort_stride,
+                    c->run_stride, nb, ctr + (size_t)nb * 2 + 2, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride);
    ZH_CHECK(c, hipEventRecord(c->lane_ev[k][2], st));   // the next run's matchfinder starts here
    // (segment descriptors carry batch-wide input indices: the rows go to d_match + input * match_stride)
    ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), (const uint32_t *)sa, (const uint2 *)p3,
@@ -969,7 +973,7 @@ static uint32_t zh_files_run_lo(const zultra_hip_ctx_t *c, uint32_t nblocks, int
 static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nblocks, hipStream_t st0) {
    const int runs = c->last_runs;
    // what the runs need cleared, and (below) the copies of what they produce, on the stream the runs fork from
-   ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr, 0, ((size_t)nblocks * 2 + 2 * (size_t)runs) * sizeof(uint32_t), st0));
+   ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr, 0, ((size_t)nblocks * 2 + 3 * (size_t)runs) * sizeof(uint32_t), st0));
    ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, ZH_NCNT * sizeof(uint32_t), st0));
    ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, (size_t)nblocks * c->slot_stride, st0));
    ZH_CHECK(c, hipEventRecord(c->ev2[1], st0));   // fork
@@ -1181,13 +1185,17 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       uint32_t *sa = c->d_sort_a + (uint64_t)sg0 * c->sort_stride, *sb = c->d_sort_b + (uint64_t)sg0 * c->sort_stride;
       uint2 *p3 = c->d_prev3 + (uint64_t)sg0 * c->sort_stride;
       uint32_t *rn = c->d_runs + (uint64_t)sg0 * c->run_stride;
-      uint32_t *ctr = c->d_chunk_ctr + (size_t)sg0 * 2 + 2 * (size_t)k;   // this run's counters: 2 per segment + the two tickets
+      uint32_t *ctr = c->d_chunk_ctr + (size_t)sg0 * 2 + 3 * (size_t)k;   // this run's counters: 2 per segment + the three tickets
       const uint32_t mf_grid = min(nsg, max(1u, c->num_cus * c->mf_cu_pct / 100u));   // persistent workgroups, one per CU (zh_matchfinder.h)
-      ZH_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nsg * 2 + 2) * sizeof(uint32_t), st));
+      ZH_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nsg * 2 + 3) * sizeof(uint32_t), st));
       // token bits are ORed into the payload slots: cleared here, long before stage 3 needs them (the fill runs next to the matchfinder)
       ZH_CHECK(c, hipMemsetAsync(c->d_payload + (uint64_t)b0 * c->slot_stride, 0, (size_t)nb * c->slot_stride, st));
       ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, rn, c->sort_stride, c->run_stride, mf_stop, nsg,
                 ctr + (size_t)nsg * 2 + 1, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride, c->mf_lds_cap);
+      // the bigram classes that fit no chunk of zh_mf_group, noted by it (zh_mf_group_lds.h): a kernel of their own
+      if (c->mf_lds_cap && !mf_stop && c->seg_W > min((uint32_t)ZH_MFL_MAXCAP, max(c->mf_lds_cap, 16u)))
+         ZH_LAUNCH_LDS(zh_mf_group_big, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, (const uint32_t *)rn, c->sort_stride, c->run_stride, nsg, ctr + (size_t)nsg * 2 + 2,
+                       c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride);
       ZH_CHECK(c, hipEventRecord(ev[2], st));
       if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
       // (segment descriptors carry batch-wide block indices: the rows go to d_match + block * match_stride)

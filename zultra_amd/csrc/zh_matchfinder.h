@@ -649,11 +649,53 @@ zh_mf_group(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs,
    }
 #ifdef ZH_MF_GROUP_HBM   // A/B builds (tools/build_variant.sh): rounds 1-3's six passes through HBM when the host passes lds_cap = 0 (ZULTRA_HIP_MF_CAP=0)
    if (!LDS_WIN || !lds_cap)
+   {
       zh_mf_group_body(win, gwin, W, blk.prev + blk.n, blk.prev, A, B, prev3, pay_all + (uint64_t)blockIdx.x * 3u * sort_stride, sort_stride, runs, hist, wave_tot,
                        stop);
+      if (threadIdx.x == 0) runs[run_stride - ZH_MFL_NOTE_WORDS] = 0;   // (nothing for zh_mf_group_big)
+   }
    else
 #endif
-      zh_mf_group_body_lds(win, dyn_lds, W, blk.prev + blk.n, A, B, prev3, pay_all + (uint64_t)blockIdx.x * 3u * sort_stride, sort_stride, runs, hist, wave_tot, stop, lds_cap, mfg_t_);
+      zh_mf_group_body_lds(win, dyn_lds, W, blk.prev + blk.n, A, B, prev3, pay_all + (uint64_t)blockIdx.x * 3u * sort_stride, sort_stride, runs, runs + run_stride - ZH_MFL_NOTE_WORDS, hist, wave_tot, stop,
+                           lds_cap, mfg_t_);
+   }
+}
+
+// The bigram classes that fit no chunk of zh_mf_group (zh_mf_group_lds.h: byte runs of a few bytes each, alphabets of two or three symbols):
+// noted there, refined here by the generic passes through HBM — a kernel of its own so that zh_mf_group keeps its registers. Persistent
+// workgroups take the segments from a ticket; a segment without notes costs a load.
+__global__ void __launch_bounds__(ZH_MF_THREADS)
+zh_mf_group_big(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ segs, uint32_t *sort_a, uint32_t *sort_b, uint2 *prev_all, const uint32_t *__restrict__ runs_all,
+                uint64_t sort_stride, uint64_t run_stride, uint32_t nsegs, uint32_t *ticket, uint32_t *pay_all) {
+   ZH_DYN_LDS(dyn_lds);
+   uint32_t *lwin32 = dyn_lds;
+   uint32_t *hist = dyn_lds + ZH_MF_LDS_WINDOW / 4 + 4;
+   uint32_t *wave_tot = hist + ZH_MF_WAVES * 256;
+   uint32_t &cur_seg = wave_tot[ZH_MF_WAVES];
+   for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) {
+         // (the next segment that has notes: thread 0 skips the others)
+         uint32_t sg;
+         do {
+            sg = atomicAdd(ticket, 1u);
+         } while (sg < nsegs && (runs_all + (uint64_t)sg * run_stride + run_stride - ZH_MFL_NOTE_WORDS)[0] == 0);
+         cur_seg = sg;
+      }
+      __syncthreads();
+      const uint32_t seg = cur_seg;
+      if (seg >= nsegs) return;
+      const zh_seg_t blk = segs[seg];
+      const uint32_t W = blk.prev + blk.n + blk.tail;
+      const uint32_t *notes = runs_all + (uint64_t)seg * run_stride + run_stride - ZH_MFL_NOTE_WORDS;
+      zh_stage_window(lwin32, data + blk.win_off, W);
+      const uint32_t nn = notes[0];
+      for (uint32_t k = 0; k < nn; k++) {
+         const uint32_t a = notes[1u + 2u * k], b = notes[2u + 2u * k];
+         const uint32_t cs = a & 0x1ffffu, cob = b & 0x1ffffu, cn = (a >> 17) | ((b >> 17) << 15);
+         (void)zh_mfl_oversized((const uint8_t *)lwin32, W, cn, sort_b + (uint64_t)seg * sort_stride + cs, sort_a + (uint64_t)seg * sort_stride + cob,
+                                prev_all + (uint64_t)seg * sort_stride + cob, prev_all + (uint64_t)seg * sort_stride, pay_all + (uint64_t)blockIdx.x * 3u * sort_stride, hist, wave_tot);
+      }
    }
 }
 

@@ -31,6 +31,8 @@
 #ifndef ZH_MFL_DEBUG
 #define ZH_MFL_DEBUG 0   // timing experiments (wrong output; with ZH_MF_STOP=5): 1 no distances, 2 no ranks, 4 no digit gather
 #endif
+#define ZH_MFL_NOTE_WORDS 59u        // the run table's slack: run_stride = sort_stride + 576 words, zh_mf_build_runs writes at most W + 517
+#define ZH_MFL_MAX_NOTES ((ZH_MFL_NOTE_WORDS - 1u) / 2u)   // 29: a class above `cap` (~3900 of at most 98304 entries) happens at most 25 times
 #define ZH_MF_LDS_TOTAL 163840u    // all of a CU's LDS: one workgroup per CU anyway (1024 threads)
 static_assert(ZH_SEG_WINDOW <= (1u << ZH_MFL_ID_SHIFT), "window positions must fit the element's position field");
 static_assert(ZH_MFL_MAXCAP <= (1u << (32 - ZH_MFL_ID_SHIFT)), "chunk ids must fit the element's id field");
@@ -233,19 +235,22 @@ __device__ inline uint32_t zh_mfl_refine(const zh_mfl_t &L, const uint32_t *lwin
    return n4;
 }
 
-// A class too large for a chunk: the entries [0, n0) of SBc (its range of the bigram order) through the generic passes in HBM, SAc
-// (the same range of the other array) as the pong. Returns the number of entries written to S_out / P_out.
-__device__ inline uint32_t zh_mfl_oversized(const uint8_t *gwin, uint32_t W, uint32_t n0, uint32_t *SAc, uint32_t *SBc, uint32_t *S_out, uint2 *P_out, uint2 *tail,
-                                            uint32_t *pay, uint64_t pay_stride, uint32_t *hist, uint32_t *wave_tot) {
-   uint32_t *Pa = pay, *Pb = pay + pay_stride;
-   uint2 *P2 = (uint2 *)(pay + pay_stride);   // the last pass reads Pa: Pb and the third part are free by then
+// A class too large for a chunk (zh_mf_group_big): the entries [0, n0) of SBc (its range of the bigram order) through the generic passes in
+// HBM. Returns the number of entries written to S_out / P_out.
+__device__ inline uint32_t zh_mfl_oversized(const uint8_t *gwin, uint32_t W, uint32_t n0, uint32_t *SBc, uint32_t *S_out, uint2 *P_out, uint2 *tail, uint32_t *pay,
+                                            uint32_t *hist, uint32_t *wave_tot) {
+   // scratch, all in the workgroup's `pay` (3 x sort_stride words; n0 <= 0.72 W: a class of a bigram of two different bytes holds at most every
+   // other position, one of two equal bytes lost its run-interior positions): the pong T, the payload Pa, and the final pairs P2 — whose
+   // first half serves as the payload Pb before
+   uint32_t *T = pay, *Pa = pay + n0, *Pb = pay + 2u * n0;
+   uint2 *P2 = (uint2 *)(pay + 2u * n0);
    const uint32_t *cursor = wave_tot + ZH_MF_WAVES + 1 + ZH_MF_WAVES * 256;   // zh_mf_sort_pass leaves the end of digit d's run in cursor[d]
-   zh_mf_sort_pass<4>(gwin, gwin, n0, SBc, SAc, hist, wave_tot, W);
-   zh_mf_sort_pass<5, false, -1, 1, 3>(gwin, gwin, n0, SAc, SBc, hist, wave_tot, W, nullptr, 0, nullptr, nullptr, nullptr, Pb, nullptr, nullptr, tail);
+   zh_mf_sort_pass<4>(gwin, gwin, n0, SBc, T, hist, wave_tot, W);
+   zh_mf_sort_pass<5, false, -1, 1, 3>(gwin, gwin, n0, T, SBc, hist, wave_tot, W, nullptr, 0, nullptr, nullptr, nullptr, Pb, nullptr, nullptr, tail);
    const uint32_t n2 = cursor[255];
-   zh_mf_sort_pass<6, false, -1, 1, 4>(gwin, gwin, n2, SBc, SAc, hist, wave_tot, W, nullptr, 0, nullptr, nullptr, Pb, Pa, nullptr, nullptr, tail);
+   zh_mf_sort_pass<6, false, -1, 1, 4>(gwin, gwin, n2, SBc, T, hist, wave_tot, W, nullptr, 0, nullptr, nullptr, Pb, Pa, nullptr, nullptr, tail);
    const uint32_t n3 = cursor[255];
-   zh_mf_sort_pass<7, false, -1, 2, 5>(gwin, gwin, n3, SAc, SBc, hist, wave_tot, W, nullptr, 0, nullptr, nullptr, Pa, nullptr, nullptr, P2, tail);
+   zh_mf_sort_pass<7, false, -1, 2, 5>(gwin, gwin, n3, T, SBc, hist, wave_tot, W, nullptr, 0, nullptr, nullptr, Pa, nullptr, nullptr, P2, tail);
    const uint32_t n4 = cursor[255];
    const uint32_t *lwin32 = (const uint32_t *)gwin;
    for (uint32_t idx = threadIdx.x; idx < n4; idx += ZH_MF_THREADS) {
@@ -265,12 +270,13 @@ __device__ inline uint32_t zh_mfl_oversized(const uint8_t *gwin, uint32_t W, uin
 
 // the window is staged in LDS at dyn_lds (W bytes); SA receives the 6-gram order, prev the distances next to it
 __device__ inline void zh_mf_group_body_lds(const uint8_t *win, uint32_t *dyn_lds, uint32_t W, uint32_t Qn, uint32_t *SA, uint32_t *SB, uint2 *prev, uint32_t *pay,
-                                            uint64_t pay_stride, uint32_t *runs, uint32_t *hist, uint32_t *wave_tot, int stop, uint32_t cap_limit, uint64_t &mfg_t_) {
+                                            uint64_t pay_stride, uint32_t *runs, uint32_t *notes /* ZH_MFL_NOTE_WORDS words behind the run table */, uint32_t *hist, uint32_t *wave_tot, int stop, uint32_t cap_limit, uint64_t &mfg_t_) {
    const uint32_t *lwin32 = dyn_lds;
    const uint8_t *gwin = (const uint8_t *)dyn_lds;
    const uint32_t tid = threadIdx.x;
    const uint32_t M3 = min(Qn, W >= 3 ? W - 2 : 0u);   // positions that start a trigram
    const zh_mfl_t L = zh_mfl_layout(dyn_lds, W, cap_limit);
+   uint32_t nover = 0;   // classes too large for a chunk, noted for zh_mf_group_big
    if (stop == 1) return;
    ZH_MFG_LAP(0);
    ZH_MFG_COUNT(15, 1);
@@ -345,8 +351,19 @@ __device__ inline void zh_mf_group_body_lds(const uint8_t *win, uint32_t *dyn_ld
             }
             zh_sync_lds();
             const uint32_t n0 = L.misc[1];
-            __syncthreads();
-            const uint32_t nv = zh_mfl_oversized(gwin, W, n0, SA + s, SB + s, SA + out_base, prev + out_base, prev, pay, pay_stride, hist, wave_tot);
+            zh_sync_lds();   // (everybody has read it before the next round resets it)
+            // The class is refined through HBM by a kernel of its own after this one (zh_mf_group_big: its four generic passes in here cost this
+            // kernel its registers, 76 bytes of scratch per lane): it is noted — start, size, where its entries go — and its part of the order is
+            // left free. How many entries that is: all but those of the last five window positions (the 6-gram order has none of them).
+            uint32_t nv = n0;
+            for (uint32_t pl = (W >= 5 ? W - 5 : 0u); pl < min(W, Qn); pl++)
+               if (pl + 2u < W && (zh_load32_at(lwin32, pl) & 0xffffu) == big0 && !zh_mf_run_interior(gwin, pl, W)) nv--;
+            if (tid == 0 && nover < ZH_MFL_MAX_NOTES) {
+               uint32_t *note = notes + 1u + 2u * nover;
+               note[0] = s | (n0 << 17);            // start (17 bits) | low 15 bits of the size
+               note[1] = out_base | ((n0 >> 15) << 17);   // where its entries go | the size's high bits
+            }
+            nover++;
             out_base += nv;
             s += n0;
             ZH_MFG_LAP(5);
@@ -362,6 +379,7 @@ __device__ inline void zh_mf_group_body_lds(const uint8_t *win, uint32_t *dyn_ld
          s += n;
       }
 #undef ZH_MFL_REQUEST
+      ZH_MFG_LAP(5);
       // the run-interior positions: entries of their own at the top of the order (the sorted part ends exactly where they begin: together
       // they are the M6 positions with six bytes ahead), each marked as a class head — nothing walks into them, zh_mf_frontier takes their
       // frontier from the run table — with the position before them as the nearest earlier occurrence of their 3-, 4- and 5-gram
@@ -387,5 +405,6 @@ __device__ inline void zh_mf_group_body_lds(const uint8_t *win, uint32_t *dyn_ld
    if (stop == 5) return;
    __threadfence_block();
    __syncthreads();
-   zh_mf_build_runs(win, gwin, W, Qn, SB, runs, hist, wave_tot, mfg_t_);   // SB is free again: scratch for the run starts
+   zh_mf_build_runs(win, gwin, W, Qn, pay, runs, hist, wave_tot, mfg_t_);   // (scratch for the run starts: the workgroup's `pay` — SB still holds the bigram order of the classes noted for zh_mf_group_big)
+   if (tid == 0) notes[0] = min(nover, (uint32_t)ZH_MFL_MAX_NOTES);   // (behind what zh_mf_build_runs writes)
 }
