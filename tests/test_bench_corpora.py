@@ -60,3 +60,43 @@ def test_frame_and_inflate_check():
     assert bench.inflate_check(1, zz, d, len(d))
     assert not bench.inflate_check(2, gz[:-8] + b"\0" * 8, d, len(d))       # wrong CRC: zlib refuses
     assert not bench.inflate_check(0, body, d[:-1], len(d) - 1)            # wrong length
+
+
+def test_strong_scaling_shards_are_one_stream_cut_at_max_blocks():
+    """bench.py --scaling strong (and the strong leg beside the weak line at N > 1): the configuration's ONE stream is cut over the
+    ranks at max-block boundaries (zultra_amd.sharded.shard_range); the ranks' shards concatenate to the stream, every lead is the
+    32 KiB in front of its shard, ranks behind the last max-block are empty."""
+    import argparse
+
+    import bench
+    from zultra_amd.sharded import shard_range
+    base = corpus.text_like(250000, 4)
+    cyc = bench.CyclicCorpus("t", base)
+    lead, body = cyc.range(131072 + 777, 50000)
+    whole = bench._cyclic(base, 0, 1_100_000)
+    assert np.array_equal(body, whole[131072 + 777: 131072 + 777 + 50000]) and np.array_equal(lead, whole[131072 + 777 - 32768: 131072 + 777])
+    m4 = bench.MixedConfig4()
+    lead, body = m4.range((3 << 20) + 65536 * 5, (2 << 20) + 4096)
+    ref = corpus.mixed_config4(2, 5)   # segments 2..6
+    lo = (1 << 20) + 65536 * 5
+    assert np.array_equal(body, ref[lo: lo + (2 << 20) + 4096]) and np.array_equal(lead, ref[lo - 32768: lo])
+    # the cut bench.py makes: prepare_stream_config with a corpus of our own (no files of the image needed)
+    orig = bench.text_corpus
+    bench.text_corpus = lambda world, size: (cyc, "test corpus")
+    try:
+        size, bs = 1_000_000, 65536
+        nb_total = (size + bs - 1) // bs
+        for world in (1, 2, 5, 8, 20):
+            parts = []
+            for rank in range(world):
+                args = argparse.Namespace(config=2, scaling="strong", block=bs, size=size, cpu_sample=1 << 20, no_cpu_baseline=True, profile_run=False)
+                p = bench.prepare_stream_config(args, rank, world)
+                lo, hi = shard_range(nb_total, rank, world)
+                assert len(p["shard"]) == max(0, min(size, hi * bs) - lo * bs)
+                if len(p["shard"]) and lo:
+                    assert np.array_equal(p["lead"], whole[lo * bs - 32768: lo * bs])
+                assert p["last_rank"] == max(r for r in range(world) if shard_range(nb_total, r, world)[1] > shard_range(nb_total, r, world)[0])
+                parts.append(p["shard"])
+            assert np.array_equal(np.concatenate(parts), whole[:size])
+    finally:
+        bench.text_corpus = orig
