@@ -53,6 +53,9 @@
 #define ZH_MF_GROUP_LDS 163840u        // dynamic LDS bytes of zh_mf_group: all of the CU's. Window, two counter tables, small variables, 256 cursors for the
                                       // passes through HBM ((ZH_MF_LDS_WINDOW / 4 + 4 + 2 * ZH_MF_WAVES * 256 + ZH_MF_WAVES + 1 + 256) * 4 bytes); the rest for the chunks of zh_mf_group_lds.h
 #define ZH_MF_FRONTIER_LDS ((ZH_MF_LDS_WINDOW / 4 + 4 + 8 * ZH_MF_THREADS + 1) * 4)              // ... of zh_mf_frontier
+#ifndef ZH_MF_EXT_TO
+#define ZH_MF_EXT_TO 80u             // zh_mf_length_past16: the lanes extend their own matches up to here (32 + a multiple of 16), the whole wave beyond
+#endif
 #define ZH_MF_HELP_WINDOW 4096u       // zh_mf_frontier: a workgroup out of tickets looks at the last 4096 segments for one to help
 #ifndef ZH_MF_HELP_MIN
 #define ZH_MF_HELP_MIN 32u           // ... and joins only for at least this many 64-entry chunks per workgroup
@@ -816,7 +819,23 @@ __device__ __forceinline__ uint32_t zh_mf_length_past16(const uint32_t *lwin32, 
    zh_load128_at(lwin32, need ? q + 16u : 0u, g);
    const uint32_t m = zh_mf_len16(g, own32);
    if (need) l = 16u + m;
-   return zh_mf_extend_wave<32u>(lwin32, need && m == 16u && maxlen > 32u, q, i, maxlen, l);
+   bool more = need && m == 16u && maxlen > 32u;
+   // Bytes 32..79 by the lanes themselves, sixteen at a time and all that need it at once (round 4): on source code two lanes of a step
+   // go past 32 on average and most of them end before 80 — handing each of them to the whole wave in turn (zh_mf_extend_wave: ~350 cycles
+   // per lane) was a fifth of this kernel there. What still agrees at 80 goes to the whole wave.
+#pragma unroll
+   for (uint32_t off = 32u; off < ZH_MF_EXT_TO; off += 16u) {
+      if (!zh_ballot(more)) return l;   // (wave-uniform)
+      uint32_t a[4], b[4];
+      zh_load128_at(lwin32, more ? q + off : 0u, a);
+      zh_load128_at(lwin32, more ? i + off : 0u, b);
+      const uint32_t mm = zh_mf_len16(a, b);
+      if (more) {
+         l = off + mm;
+         more = mm == 16u && l < maxlen;
+      }
+   }
+   return zh_mf_extend_wave<ZH_MF_EXT_TO>(lwin32, more, q, i, maxlen, l);
 }
 
 template <bool LDS_WIN>
