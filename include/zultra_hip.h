@@ -119,6 +119,9 @@ typedef struct zultra_hip_stats_s {
    uint32_t cut_tasks, cut_segments;   /* chain tasks parsed as speculative segments, and their segments */
    uint32_t cut_redone;                /* segments whose speculated costs did not match and were parsed again (sum over the passes) */
    uint32_t runs;                      /* staggered runs the batch was cut into (ZULTRA_HIP_STREAMS, fewer for small batches) */
+   uint32_t settled_passes;            /* (sub-block, parse pass) pairs not run: the sub-block's code lengths had reached a fixed point of the loop at
+                                          blockdeflate.c:874-901, every further pass would have reproduced the parse it has */
+   uint32_t settled_kib;               /* ... the input they cover, in KiB (of 4 x positions / 1024 for the four passes of everything) */
 } zultra_hip_stats_t;
 void zultra_hip_last_stats(const zultra_hip_ctx_t *ctx, zultra_hip_stats_t *out);
 

@@ -67,6 +67,23 @@ def test_matchfinder_chunks_and_oversized_classes(emu, oracle, monkeypatch, case
     check_window(emu, oracle, gen(), prev, n, tag=name + "/cap" + cap)
 
 
+@pytest.mark.parametrize("case", [
+    ("zeros", lambda: corpus.constant(3000), 500, 2500, 3),
+    ("noise", lambda: corpus.noise(3000, 1), 0, 3000, 2),
+    ("selftest", lambda: corpus.selftest_data(6000, 77, 15, 0.5), 1000, 5000, 1),
+    ("text", lambda: corpus.text_like(9000, 3), 1000, 8000, 0),
+], ids=lambda c: c[0])
+def test_settled_subblocks_keep_their_parse(emu, oracle, case):
+    """A sub-block whose rebuilt code lengths (unused symbols at 9 / 6 bits) equal the ones its parse pass priced with has reached a
+    fixed point of the reference's loop (blockdeflate.c:874-901): the remaining passes would reproduce the parse, so the parse
+    kernels skip it (zh_sb_build_one, st->settled) and only the code builds run. One max-block each that settles after pass 0, 1,
+    2 and never: the stages still equal the oracle's, and the number of passes not run is what the fixed point implies."""
+    name, gen, prev, n, skipped = case
+    st = {}
+    check_window(emu, oracle, gen(), prev, n, tag=name, stats_out=st)
+    assert st["subblocks"] == 1 and st["settled_passes"] == skipped, st
+
+
 @pytest.mark.parametrize("wide", ["1", "1000000", "whole"], ids=["as_waves_of_zh_parse_segments", "as_jobs_of_zh_parse_chain", "few_and_short_stay_whole"])
 def test_chain_segments_are_both_accepted_and_redone(emu, oracle, monkeypatch, wide):
     """The speculative segments of long barrier-free tasks (zh_parse.h; the emulator build cuts every 512 positions with a

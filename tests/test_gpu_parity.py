@@ -60,6 +60,28 @@ def test_stages_vs_oracle(gpu, oracle, case):
     check_window(gpu, oracle, gen(), prev, n, max_block=bs, tag=name)
 
 
+def test_settled_subblocks_keep_their_parse(gpu, oracle):
+    """Sub-blocks whose code lengths have reached a fixed point of the reference's four-pass loop (blockdeflate.c:874-901) are not parsed
+    again (zh_sb_build_one, st->settled): whole-block chains of a constant byte settle after the first pass, noise after the second, and in
+    a batch of the mixed corpus some sub-blocks settle and others never do. Stages and stream are the oracle's either way."""
+    st = {}
+    check_window(gpu, oracle, corpus.constant(70000), 4464, 65536, max_block=65536, tag="zeros", stats_out=st)
+    assert st["settled_passes"] == 3 * st["subblocks"], st
+    st = {}
+    check_window(gpu, oracle, corpus.noise(40000, 1), 0, 40000, max_block=65536, tag="noise", stats_out=st)
+    assert st["settled_passes"] >= 1, st
+    d = corpus.mixed_config4(0, 6)
+    ctx = gpu.context(65536, len(d) // 65536)
+    try:
+        ctx.compress_blocks(d, [(65536 * b - (32768 if b else 0), 32768 if b else 0, 65536) for b in range(len(d) // 65536)])
+        st = ctx.stats()
+    finally:
+        ctx.close()
+    assert 0 < st["settled_passes"] < 3 * st["subblocks"], st
+    got = gpu.memory_compress(d, 2, 65536)
+    assert got == oracle.memory_compress(d, 2, 65536)
+
+
 @pytest.mark.parametrize("wide", ["1", "1000000", "whole"], ids=["as_waves_of_zh_parse_segments", "as_jobs_of_zh_parse_chain", "few_and_short_stay_whole"])
 def test_chain_tasks_are_cut_into_speculative_segments(gpu, oracle, monkeypatch, wide):
     """zh_parse.h: barrier-free runs of table-like text are parsed as segments started 1024 positions early — as waves of

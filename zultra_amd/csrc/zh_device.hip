@@ -937,7 +937,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    // max-blocks that lost to the pass-by-pass kernels; here a pass over an input is two tasks, and eight launches per batch wait for each other)
    if (sbflags)
       ZH_LAUNCH(zh_parse_own<1u>, nb, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, states, best,
-                c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, (const uint2 *)(c->d_taskinfo + t0), payload, (const uint32_t *)sbflags, nb);
+                c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, (const uint2 *)(c->d_taskinfo + t0), payload, (const uint32_t *)sbflags, nb, cnt);
    for (int pass = 0; pass <= 3; pass++) {
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
@@ -954,7 +954,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
       ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
                 (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
       ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
-      ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, (const uint32_t *)sbflags);
+      ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, (const uint32_t *)sbflags, cnt);
    }
    ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt,
              (const zh_sbstate_t *)states, best, c->best_stride, task_bits, (const uint2 *)(c->d_taskinfo + t0));
@@ -1291,7 +1291,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          // them — they start when the batch's last matchfinder kernel has started / ended: ZULTRA_HIP_OWN_AFTER)
          if (c->own_after && c->own_after <= 3) ZH_CHECK(c, hipStreamWaitEvent(ls, c->lane_ev[lanes - 1][c->own_after], 0));
          ZH_LAUNCH(zh_parse_own<ZH_OWN_WAVES>, ns, 64 * ZH_OWN_WAVES, ls, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, states, best,
-                   c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, (const uint2 *)(c->d_taskinfo + t0), payload, (const uint32_t *)sbflags, ns);
+                   c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, (const uint2 *)(c->d_taskinfo + t0), payload, (const uint32_t *)sbflags, ns, ntasks);
          ZH_CHECK(c, hipEventRecord(c->loop_ev[k][1], ls));
       }
       // Does this run have chains at all? With none (text without long repeats) zh_parse_tasks gets the whole chip; with chains it
@@ -1359,7 +1359,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          if (seg_wide) ZH_CHECK(c, hipStreamWaitEvent(st, c->seg_ev[k][pass], 0));
          if (nchains && !(dbg_skip & 1)) ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
          ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));
-         if (by_pass) ZH_LAUNCH(zh_sb_build, ns, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, pass_flags);
+         if (by_pass) ZH_LAUNCH(zh_sb_build, ns, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, pass_flags, ntasks);
          ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));
       }
       if (c->use_loop) ZH_CHECK(c, hipStreamWaitEvent(st, c->loop_ev[k][1], 0));   // every sub-block is through its passes
@@ -1607,6 +1607,8 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
       out->cut_tasks += cnt[ZH_CNT_SEGTASKS];
       out->cut_segments += cnt[ZH_CNT_SEGITEMS];
       out->cut_redone += cnt[ZH_CNT_SEG_FAILED];   // over the four passes
+      out->settled_passes += cnt[ZH_CNT_SETTLED];
+      out->settled_kib += cnt[ZH_CNT_SETTLED_POS];
    }
    for (uint32_t b = 0; b < c->nblocks; b++) out->positions += c->blocks[b].n;
    out->runs = (uint32_t)c->last_runs;

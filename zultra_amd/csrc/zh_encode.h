@@ -151,6 +151,7 @@ zh_sb_init(const uint16_t *__restrict__ tok_info, uint64_t tok_stride, const zh_
    if (lane == 0) {
       st->is_dynamic = is_dynamic;
       st->failed = failed;
+      st->settled = 0;
       st->hdr_bits = 0;
       st->static_cost = static_cost;
       st->dynamic_cost = dynamic_cost;
@@ -187,7 +188,7 @@ struct zh_cl_write_sink {
 // ---- zh_sb_build: blockdeflate.c:887-919 for pass 0..3; after pass 3 also :925-992 -----------------------------------
 // One sub-block by one wave (all 64 lanes call; the syncs are the wave's: it may be one of several of a workgroup, zh_parse_own); `ws` is the
 // wave's own workspace in LDS. Returns (in every lane) whether the sub-block has failed.
-__device__ __forceinline__ uint32_t zh_sb_build_one(zh_sb_ws_t &ws, const zh_work_t wk, zh_sbstate_t *st, const uint32_t *__restrict__ hist_part, uint8_t *payload, int pass) {
+__device__ __forceinline__ uint32_t zh_sb_build_one(zh_sb_ws_t &ws, const zh_work_t wk, zh_sbstate_t *st, const uint32_t *__restrict__ hist_part, uint8_t *payload, int pass, uint32_t *cnt /* the run's counters */) {
    if (st->failed) return 1u;
    if (!st->is_dynamic) return 0u;
    const uint32_t lane = zh_lane();
@@ -221,8 +222,24 @@ __device__ __forceinline__ uint32_t zh_sb_build_one(zh_sb_ws_t &ws, const zh_wor
    if (zh_huff_build_wave(ws.dist_freq, ws.dist_len, ws.dist_code, ZH_NDIST, 15, &ws.sc) < 0) failed = 1;
 
    if (pass < 3) {
+      // A fixed point of the loop at blockdeflate.c:874-901: the next pass prices with these lengths, unused symbols at 9 / 6 bits (:875-878). If
+      // that is what this pass priced with, the next parse is this one again (the parse is a function of the rows and the prices), so is
+      // its histogram, so are the lengths built from it — for every pass left. The parse kernels then skip the sub-block (st->settled) and
+      // leave its parse entries and task histograms alone; the builds still run, on the same sums (pass 3 adds the distance-code fix,
+      // the alternative tables and the header).
+      uint32_t moved = 0;
+      for (uint32_t s = lane; s < ZH_NLIT; s += 64) moved |= (uint32_t)((ws.lit_len[s] ? ws.lit_len[s] : 9) != (st->lit_len[s] ? st->lit_len[s] : 9));
+      if (lane < ZH_NDIST) moved |= (uint32_t)((ws.dist_len[lane] ? ws.dist_len[lane] : 6) != (st->dist_len[lane] ? st->dist_len[lane] : 6));
+      moved = zh_wave_sum(moved);
       zh_store_codes_wave(st, &ws);
-      if (failed && lane == 0) st->failed = 1;
+      if (lane == 0) {
+         if (failed) st->failed = 1;
+         if (!moved && !failed && !st->settled) {
+            st->settled = 1;
+            atomicAdd(&cnt[ZH_CNT_SETTLED], (uint32_t)(3 - pass));
+            atomicAdd(&cnt[ZH_CNT_SETTLED_POS], (uint32_t)(3 - pass) * ((wk.size + 512u) >> 10));
+         }
+      }
       return failed;
    }
 
@@ -321,10 +338,11 @@ __device__ __forceinline__ uint32_t zh_sb_build_one(zh_sb_ws_t &ws, const zh_wor
 // sbflags != NULL: only the sub-blocks with a chain task (bit 0; zh_list_huge) — the others are rebuilt by the wave of zh_parse_loop that
 // finishes their pass (zh_parse_loop.h)
 __global__ void __launch_bounds__(64)
-zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint32_t *__restrict__ hist_part, uint8_t *payload, int pass, const uint32_t *__restrict__ sbflags) {
+zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint32_t *__restrict__ hist_part, uint8_t *payload, int pass, const uint32_t *__restrict__ sbflags,
+            uint32_t *cnt) {
    __shared__ zh_sb_ws_t ws;
    if (sbflags && !(sbflags[blockIdx.x] & 1u)) return;
-   (void)zh_sb_build_one(ws, work[blockIdx.x], states + blockIdx.x, hist_part, payload, pass);
+   (void)zh_sb_build_one(ws, work[blockIdx.x], states + blockIdx.x, hist_part, payload, pass, cnt);
 }
 
 // ---- prices / sizes of the codes in a sub-block state, staged in LDS by the task kernels -------------------------

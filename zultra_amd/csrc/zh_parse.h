@@ -94,7 +94,8 @@ __device__ __forceinline__ uint32_t zh_ring_wrap(uint32_t x) { return min(x, x -
 // Counters of a run (device: uint32 per field; one block of ZH_CNT_STRIDE words per run)
 enum {
    ZH_CNT_TASKS = 0, ZH_CNT_VLONG, ZH_CNT_LONG, ZH_CNT_SHORT, ZH_CNT_HUGE_POS, ZH_CNT_SEGTASKS, ZH_CNT_SEGITEMS, ZH_CNT_SEG_FAILED,
-   ZH_CNT_CHAIN_TICKET = 8, ZH_CNT_TASK_TICKET = 12, ZH_CNT_FIX_TICKET = 16, ZH_CNT_SEGWAVES = 20, ZH_CNT_STRIDE = 32
+   ZH_CNT_CHAIN_TICKET = 8, ZH_CNT_TASK_TICKET = 12, ZH_CNT_FIX_TICKET = 16, ZH_CNT_SEGWAVES = 20,
+   ZH_CNT_SETTLED = 21 /* parse passes not run because the sub-block's prices had stopped moving (zh_sb_build_one) */, ZH_CNT_SETTLED_POS = 22 /* ... in KiB of input */, ZH_CNT_STRIDE = 32
 };
 
 // sub-block work item produced by zh_plan_subblocks
@@ -116,7 +117,9 @@ struct zh_sbstate_t {
                                                            // alternative: the prices literalisation uses (:923 vs :926-945)
    uint32_t is_dynamic, failed, hdr_bits;
    int32_t static_cost, dynamic_cost;
-   uint32_t pad[3];
+   uint32_t settled;        // the prices the next parse pass would use are those of the last one: its parse, and every later one, would come out the same
+                            // (zh_sb_build_one); the parse kernels leave the sub-block's parse entries and task histograms as they are
+   uint32_t pad[2];
 };
 
 // boundary j of a sub-block's task list (window positions): 0 -> start, ntasks -> end
@@ -307,6 +310,7 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
    const zh_sbstate_t *st = states + tm.x;
    if (st->failed) return;
    if (!st->is_dynamic && pass > 0) return;   // static sub-blocks are parsed once (blockdeflate.c:836-858)
+   if (st->settled) return;                   // same prices as in the last pass: same parse, same histogram (zh_sb_build_one)
 
    const zh_block_t blk = blocks[wk.block];
    const uint8_t *win = data + blk.win_off;

@@ -504,7 +504,7 @@ __device__ __forceinline__ zh_chain_task_t zh_chain_task(uint32_t gt, const uint
    const uint2 tm = taskmap[gt];
    const zh_work_t wk = work[tm.x];
    T.st = states + tm.x;
-   T.skip = T.st->failed || (!T.st->is_dynamic && pass > 0);   // static sub-blocks are parsed once (blockdeflate.c:836-858)
+   T.skip = T.st->failed || (!T.st->is_dynamic && pass > 0) || T.st->settled;   // static sub-blocks are parsed once (blockdeflate.c:836-858); settled ones keep the parse they have (zh_sb_build_one)
    const zh_block_t blk = blocks[wk.block];
    T.win = data + blk.win_off;
    T.prev = blk.prev;

@@ -116,6 +116,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    if (st->failed) return;
    const bool sb_dynamic = st->is_dynamic != 0;
    if (!sb_dynamic && pass > 0) return;   // static sub-blocks are parsed once (blockdeflate.c:836-858)
+   if (st->settled) return;               // same prices as in the last pass: same parse, same histogram (zh_sb_build_one)
    const zh_block_t blk = blocks[wk.block];
    const uint8_t *win = data + blk.win_off;
    const uint32_t prev = blk.prev;

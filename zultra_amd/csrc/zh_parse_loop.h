@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(64 * WAVES, ZH_OWN_OCC)
 zh_parse_own(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
              const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
              zh_sbstate_t *states, uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all, uint32_t *hist_part, const uint2 *__restrict__ taskinfo,
-             uint8_t *payload, const uint32_t *__restrict__ sbflags, uint32_t nsubs) {
+             uint8_t *payload, const uint32_t *__restrict__ sbflags, uint32_t nsubs, uint32_t *cnt /* the run's counters (ZH_CNT_*) */) {
    __shared__ union {
       zh_lp_ws_t lp[WAVES];   // a workspace per wave while they parse ...
       zh_sb_ws_t sb;                 // ... the code builder's between the passes
@@ -65,7 +65,7 @@ zh_parse_own(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ bl
       zh_stores_done();       // this wave's histograms (and its parse) are out ...
       __syncthreads();        // ... and so are the other waves'
       if (wave == 0) {
-         const uint32_t failed = zh_sb_build_one(ws.sb, wk, st, hist_part, payload, pass);
+         const uint32_t failed = zh_sb_build_one(ws.sb, wk, st, hist_part, payload, pass, cnt);
          zh_stores_done();
          if (threadIdx.x == 0) stop = failed;
       }
