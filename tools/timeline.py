@@ -11,6 +11,6 @@ out=open(sys.argv[2],"w")
 for r in last:
     s=int(r["Start_Timestamp"]);e=int(r["End_Timestamp"])
     n=r["Kernel_Name"].replace("void ","").split("(")[0][:22]
-    if n.startswith("__amd"): continue
+    if n.startswith("__amd") and len(sys.argv) < 4: continue   # a third argument: the runtime's copy / fill kernels too
     out.write("%9.3f %9.3f %8.3f %s q=%s\n"%((s-t0)/1e6,(e-t0)/1e6,(e-s)/1e6,n,r.get("Queue_Id","?")))
 out.close()

@@ -289,7 +289,7 @@ class HipContext:
             raise ZultraError("zultra_hip_create failed: no usable HIP device (there is no CPU fallback)")
         self.max_block = max_block
         self._data = None
-        self._blocks = None
+        self._block_n = None   # sizes of the last batch's blocks (list or uint32 array)
         self._blocks_src = self._blocks_arr = None
 
     def close(self):
@@ -310,7 +310,7 @@ class HipContext:
         else:
             arr = (Block * len(blocks))(*[Block(int(o), int(p), int(n)) for (o, p, n) in blocks])
             self._blocks_src, self._blocks_arr = blocks, arr
-            self._blocks = list(blocks)
+            self._block_n = [int(b[2]) for b in blocks]
         if data_on_device:
             ptr, size = int(data), int(data_size)
         else:
@@ -325,7 +325,7 @@ class HipContext:
         """Each (offset, size) is an independent input; -> uint64 array file_off[n+1] into the device stream buffer."""
         offs = np.ascontiguousarray(offsets, dtype=np.uint64)
         szs = np.ascontiguousarray(sizes, dtype=np.uint32)
-        self._blocks = [(int(o), 0, int(n)) for o, n in zip(offs, szs)]
+        self._block_n = szs
         out = np.zeros(len(offs) + 1, dtype=np.uint64)
         if data_on_device:
             ptr, size = int(data), int(data_size)
@@ -369,7 +369,7 @@ class HipContext:
         return {k: getattr(st, k) for k, _ in Stats._fields_}
 
     def matches(self, block):
-        n = self._blocks[block][2]
+        n = int(self._block_n[block])
         m = np.zeros((n, 8, 2), dtype=np.uint16)
         if self.lib.L.zultra_hip_get_matches(self.h, block, m.ctypes.data) != 0:
             raise ZultraError("get_matches")
@@ -383,7 +383,7 @@ class HipContext:
         return list(out[:k])
 
     def parse(self, block):
-        n = self._blocks[block][2]
+        n = int(self._block_n[block])
         m = np.zeros((n, 2), dtype=np.uint16)
         if self.lib.L.zultra_hip_get_parse(self.h, block, m.ctypes.data) != 0:
             raise ZultraError("get_parse")
@@ -413,7 +413,7 @@ class HipContext:
         return out
 
     def block_crc32(self):
-        n = len(self._blocks)
+        n = len(self._block_n)
         out = np.zeros(n, dtype=np.uint32)
         self.lib.L.zultra_hip_block_crc32.argtypes = [C.c_void_p, C.c_void_p]
         self.lib.L.zultra_hip_block_crc32(self.h, out.ctypes.data)

@@ -76,21 +76,28 @@ __global__ void zh_plan_subblocks(const zh_block_t *__restrict__ blocks, uint32_
 }
 
 // ---- LDS workspace of the per-sub-block kernels -----------------------------------------------------------------
+// 8 KB: twenty one-wave workgroups of zh_sb_init / zh_sb_build per CU. The kernels are chains of dependent LDS round trips on one wave (or one
+// lane), their throughput is the number of them a CU holds; with every array laid side by side (15 KB) it held ten. What is never live at the same
+// time shares its bytes: the histograms, the alternative's tables and the sort scratch are dead once the alternative is decided, which is when the
+// twenty header candidates start.
 struct zh_sb_ws_t {
-   int32_t lit_freq[ZH_NLIT], dist_freq[ZH_NDIST];
    uint8_t lit_len[ZH_NLIT], dist_len[ZH_NDIST];
    uint16_t lit_code[ZH_NLIT], dist_code[ZH_NDIST];
-   int32_t alt_lit_freq[ZH_NLIT], alt_dist_freq[ZH_NDIST];
-   uint8_t alt_lit_len[ZH_NLIT], alt_dist_len[ZH_NDIST];
-   uint16_t alt_lit_code[ZH_NLIT], alt_dist_code[ZH_NDIST];
    uint8_t lens[ZH_NLIT + ZH_NDIST];
-   uint8_t keep[ZH_NLIT];
-   zh_huff_scratch_t sc;
    zh_cl_t cl;
-   zh_cl_t cl_work[20];
    uint16_t runs[ZH_NLIT + ZH_NDIST];   // run list of the header's code lengths, shared by the 20 mask candidates
    int32_t tmp;
+   union {
+      struct {
+         int32_t lit_freq[ZH_NLIT], dist_freq[ZH_NDIST];   // after pass 3: smoothed in place for the RLE-friendly alternative (:925-945)
+         uint8_t alt_lit_len[ZH_NLIT], alt_dist_len[ZH_NDIST];
+         uint16_t alt_lit_code[ZH_NLIT], alt_dist_code[ZH_NDIST];
+         zh_huff_scratch_t sc;                              // (sc.sorted doubles as the smoothing's `keep` flags: no build is in flight then)
+      };
+      zh_cl_t cl_work[20];                                  // the header candidates (:947-992)
+   };
 };
+static_assert(sizeof(zh_sb_ws_t) <= 8192, "twenty workgroups of zh_sb_build per CU (160 KB of LDS)");
 
 __device__ inline void zh_store_codes_wave(zh_sbstate_t *st, const zh_sb_ws_t *ws) {
    const uint32_t lane = zh_lane();
@@ -251,17 +258,16 @@ __device__ __forceinline__ uint32_t zh_sb_build_one(zh_sb_ws_t &ws, const zh_wor
    {
       const int cur_cost = zh_dynamic_cost_wave(ws.lit_freq, ws.dist_freq, ws.lit_len, ws.dist_len, ws.lens, &ws.cl, &ws.tmp,
                                                 &ws.sc, false);
-      for (uint32_t s = lane; s < ZH_NLIT; s += 64) ws.alt_lit_freq[s] = ws.lit_freq[s];
-      if (lane < ZH_NDIST) ws.alt_dist_freq[lane] = ws.dist_freq[lane];
+      // (the histograms of the last parse have priced the codes in force and are not read again: smoothed where they are)
       zh_wave_sync();
       if (lane == 0) {
-         zh_smooth_for_rle_lane(ZH_NLIT, ws.alt_lit_freq, ws.keep);
-         zh_smooth_for_rle_lane(ZH_NDIST, ws.alt_dist_freq, ws.keep);
+         zh_smooth_for_rle_lane(ZH_NLIT, ws.lit_freq, (uint8_t *)ws.sc.sorted);
+         zh_smooth_for_rle_lane(ZH_NDIST, ws.dist_freq, (uint8_t *)ws.sc.sorted);
       }
       zh_wave_sync();
-      if (zh_huff_build_wave(ws.alt_lit_freq, ws.alt_lit_len, ws.alt_lit_code, ZH_NLIT, 15, &ws.sc) < 0) failed = 1;
-      if (zh_huff_build_wave(ws.alt_dist_freq, ws.alt_dist_len, ws.alt_dist_code, ZH_NDIST, 15, &ws.sc) < 0) failed = 1;
-      const int alt_cost = zh_dynamic_cost_wave(ws.alt_lit_freq, ws.alt_dist_freq, ws.alt_lit_len, ws.alt_dist_len, ws.lens,
+      if (zh_huff_build_wave(ws.lit_freq, ws.alt_lit_len, ws.alt_lit_code, ZH_NLIT, 15, &ws.sc) < 0) failed = 1;
+      if (zh_huff_build_wave(ws.dist_freq, ws.alt_dist_len, ws.alt_dist_code, ZH_NDIST, 15, &ws.sc) < 0) failed = 1;
+      const int alt_cost = zh_dynamic_cost_wave(ws.lit_freq, ws.dist_freq, ws.alt_lit_len, ws.alt_dist_len, ws.lens,
                                                 &ws.cl, &ws.tmp, &ws.sc, false);
       if (alt_cost < cur_cost) {
          for (uint32_t s = lane; s < ZH_NLIT; s += 64) {
