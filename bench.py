@@ -736,6 +736,8 @@ def run_config5(args, env, prep):
     ctx = L.files_context(size, batch, device=env["local_rank"])
     nb = (nfiles + batch - 1) // batch
     sizes_full = np.full(batch, size, dtype=np.uint32)
+    # the batches' output comes back into one pinned buffer (an input deflates to less than its size + 64: reference bound libzultra.c:601-619)
+    pinned = torch.empty(batch * (size + 64), dtype=torch.uint8, pin_memory=True).numpy()
     timings = []
     keep = {}
 
@@ -745,7 +747,7 @@ def run_config5(args, env, prep):
             k = min(batch, nfiles - b * batch)
             offs = (np.arange(k, dtype=np.uint64) + np.uint64(b * batch)) * np.uint64(size)   # absolute: one base pointer -> one captured graph
             fo = ctx.compress_files(d.data_ptr(), offs, sizes_full[:k], data_on_device=True, data_size=d.numel())
-            stream = ctx.stream_read(int(fo[-1]))
+            stream = ctx.stream_read(int(fo[-1]), out=pinned if int(fo[-1]) <= pinned.size else None)
             crcs = ctx.block_crc32()
             out_bytes += int(fo[-1]) + 18 * k
             timings.append(ctx.timing())

@@ -405,8 +405,14 @@ class HipContext:
         self.lib.L.zultra_hip_stream_device.restype = C.c_void_p
         return self.lib.L.zultra_hip_stream_device(self.h)
 
-    def stream_read(self, nbytes, offset=0):
-        out = np.empty(nbytes, dtype=np.uint8)
+    def stream_read(self, nbytes, offset=0, out=None):
+        """-> uint8 array of the stream bytes [offset, offset + nbytes). out: a uint8 array to read into (its first nbytes are returned) — a
+        caller that reads batch after batch hands in one pinned buffer instead of touching fresh pageable memory every time."""
+        if out is None:
+            out = np.empty(nbytes, dtype=np.uint8)
+        else:
+            assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.size >= nbytes
+            out = out[:nbytes]
         self.lib.L.zultra_hip_stream_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         if self.lib.L.zultra_hip_stream_read(self.h, out.ctypes.data, offset, nbytes) != 0:
             raise ZultraError("stream_read")
