@@ -130,6 +130,11 @@ void zultra_hip_last_stats(const zultra_hip_ctx_t *ctx, zultra_hip_stats_t *out)
  * tracing is off. */
 int zultra_hip_chain_trace(zultra_hip_ctx_t *ctx, uint64_t *out, uint32_t *slots);
 
+/* Diagnostics: the tasks of run `run` of the last batch that were cut into speculative segments, four words each: task index in
+ * the run, number of segments K | (segment length / 32) << 12, first cost-vector slot, segment completions | (cuts that failed their check and
+ * were parsed again) << 16, both counted over the four passes. Returns the number of entries written (at most cap), -1 on error. */
+int zultra_hip_cut_tasks(zultra_hip_ctx_t *ctx, uint32_t run, uint32_t *out, uint32_t cap);
+
 /* Stage outputs of the last batch, for parity tests (copied device -> host on request).
  *   matches: n*8 entries {u16 length, u16 offset} of max-block `block`          (match[], private.h:59-62,97)
  *   splits : absolute window offsets of the sub-block ends, last = prev+n; returns the count (nSplitOffset, libzultra.c:299)

@@ -52,6 +52,21 @@ def test_stages_vs_oracle(emu, oracle, case):
 
 
 @pytest.mark.parametrize("case", [
+    ("text", lambda: corpus.text_like(9000, 3), 1000, 8000),
+    ("byte_runs", lambda: corpus.indented(7000, 11), 2000, 5000),
+    ("near_copies", lambda: corpus.duplicated(14000, 3, 1500), 2000, 12000),
+    ("deep_huffman", lambda: corpus.fibonacci_bytes(19), 0, 10945),
+], ids=lambda c: c[0])
+def test_long_pieces_stay_on_the_quads(emu, oracle, monkeypatch, case):
+    """A run of fewer tasks than CUs lists every task with a barrier-free piece of more than 256 positions for the chain kernel
+    (ZULTRA_HIP_COOP_SMALL: one call on a few max-blocks waits for its longest chain of steps); large batches keep pieces of up to
+    ZH_COOP_MIN = 1536 positions on the quads of zh_parse_lanes. The same windows with the large-batch bound."""
+    name, gen, prev, n = case
+    monkeypatch.setenv("ZULTRA_HIP_COOP_SMALL", "1536")
+    check_window(emu, oracle, gen(), prev, n, tag=name + "/coop1536")
+
+
+@pytest.mark.parametrize("case", [
     ("text", "256", lambda: corpus.text_like(9000, 3), 1000, 8000),
     ("binary2", "256", lambda: corpus.selftest_data(5000, 5, 2, 0.3), 0, 5000),
     ("byte_runs", "256", lambda: corpus.indented(7000, 11), 2000, 5000),

@@ -60,6 +60,20 @@ def test_stages_vs_oracle(gpu, oracle, case):
     check_window(gpu, oracle, gen(), prev, n, max_block=bs, tag=name)
 
 
+@pytest.mark.parametrize("case", [
+    ("text_hist", lambda: corpus.text_like(98304, 3), 32768, 65536, 65536),
+    ("byte_runs", lambda: corpus.indented(98304, 11), 32768, 65536, 65536),
+    ("near_copies", lambda: corpus.duplicated(98304, 3), 32768, 65536, 65536),
+    ("table_cut_big", lambda: corpus.table_like(300000, 10), 32768, 267232, 1 << 20),
+], ids=lambda c: c[0])
+def test_long_pieces_stay_on_the_quads(gpu, oracle, monkeypatch, case):
+    """Runs of fewer tasks than CUs send tasks with a barrier-free piece above 256 positions to the chain kernel (ZULTRA_HIP_COOP_SMALL);
+    the same windows with the bound of large batches (pieces of up to 1536 positions on the quads of zh_parse_lanes)."""
+    name, gen, prev, n, bs = case
+    monkeypatch.setenv("ZULTRA_HIP_COOP_SMALL", "1536")
+    check_window(gpu, oracle, gen(), prev, n, max_block=bs, tag=name + "/coop1536")
+
+
 def test_settled_subblocks_keep_their_parse(gpu, oracle):
     """Sub-blocks whose code lengths have reached a fixed point of the reference's four-pass loop (blockdeflate.c:874-901) are not parsed
     again (zh_sb_build_one, st->settled): whole-block chains of a constant byte settle after the first pass, noise after the second, and in

@@ -52,3 +52,20 @@ for run in range(3):
         late = np.argsort(-en)[:3]
         for i in late:
             print("    latest end: ticket %4d: %6d positions  start %8.0f us  end %8.0f us" % (i, pos[i], st[i], en[i]))
+
+# the cut tasks: how many of their cuts failed the check (and were parsed again, one after the other, by the wave that checks the task)
+L.L.zultra_hip_cut_tasks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+for run in range(ctx.stats()["runs"]):
+    buf = np.zeros((1 << 16, 4), dtype=np.uint32)
+    n = L.L.zultra_hip_cut_tasks(ctx.h, run, buf.ctypes.data, len(buf))
+    if n <= 0:
+        continue
+    t = buf[:n]
+    K, S, fails = t[:, 1] & 0xfff, (t[:, 1] >> 12) << 5, t[:, 3] >> 16
+    checks = 4 * (K - 1)
+    print("run %d: %d cut tasks, %d segments, %d failed cuts of %d checks over four passes" % (run, n, K.sum(), fails.sum(), checks.sum()))
+    frac = fails / np.maximum(1, checks)
+    for lo, hi in ((0, 0.0001), (0.0001, 0.1), (0.1, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.01)):
+        m = (frac >= lo) & (frac < hi)
+        print("    failed %3.0f%%..%3.0f%% of their checks: %5d tasks, %7d segments, %6d failures, serial redo positions per pass (worst task) %d"
+              % (100 * lo, 100 * hi, m.sum(), K[m].sum(), fails[m].sum(), int((fails[m] * S[m]).max() / 4) if m.any() else 0))

@@ -106,10 +106,12 @@ struct zultra_hip_ctx_s {
    uint2 *d_segitems;           // their segments, as jobs of zh_parse_chain: per max-block seg_items_per_block entries
    uint2 *d_segwaves;           // ... or as waves of zh_parse_segments (four segments each), likewise
    uint32_t cut_len;            // ... into segments of about this many positions
+   uint32_t coop_small;         // runs of fewer tasks than CUs: tasks with a barrier-free piece longer than this go to the chain kernel (ZULTRA_HIP_COOP_SMALL; ZH_COOP_MIN otherwise)
    uint32_t cut_min;            // tasks of at least this many positions are cut into segments
    uint32_t seg_whole;          // ... with fewer, zh_parse_chain takes the segments — and the cut tasks shorter than this whole (ZULTRA_HIP_SEG_WHOLE)
    int auto_runs;               // ZULTRA_HIP_STREAMS not set: the number of runs follows the batch size
    int last_runs;               // runs the last batch was cut into
+   uint32_t last_run_b0[ZH_MAX_RUNS];   // ... and the first max-block of each (diagnostics: zultra_hip_cut_tasks)
    int always_persistent;       // zh_parse_tasks always runs as persistent waves (ZULTRA_HIP_TASK_WAVES per CU)
    int parse_lanes;             // 1: zh_parse_lanes (a lane per piece) parses the tasks, 0: zh_parse_tasks (a 16-lane row per piece) (ZULTRA_HIP_PARSE_LANES)
    uint32_t lane_waves;         // persistent zh_parse_lanes waves per CU next to chains
@@ -566,6 +568,10 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->cut_len = cl ? (uint32_t)atoi(cl) : (uint32_t)ZH_CUT_LEN;
       if (c->cut_len < ZH_CUT_WARM) c->cut_len = ZH_CUT_WARM;
       if (c->cut_len > ZH_CUT_LEN) c->cut_len = ZH_CUT_LEN;   // (the buffers are sized for ZH_CUT_WARM, the smallest)
+      const char *cs = getenv("ZULTRA_HIP_COOP_SMALL");
+      c->coop_small = cs ? (uint32_t)atoi(cs) : 256u;
+      if (c->coop_small < 64u) c->coop_small = 64u;
+      if (c->coop_small > ZH_COOP_MIN) c->coop_small = ZH_COOP_MIN;
       const char *cm = getenv("ZULTRA_HIP_CUT_MIN");   // tuning experiments: tasks of at least this many positions are cut (>= 2 * ZH_CUT_WARM)
       c->cut_min = cm ? (uint32_t)atoi(cm) : (uint32_t)ZH_CUT_MIN;
       if (c->cut_min < 2u * ZH_CUT_WARM) c->cut_min = 2u * ZH_CUT_WARM;
@@ -932,7 +938,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    if (sbflags) ZH_CHECK(c, hipMemsetAsync(sbflags, 0, (size_t)nb * sizeof(uint32_t), st));
    ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
              (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu,
-             (uint32_t)ZH_CUT_LEN, cnt, c->d_taskinfo + t0, sbflags);
+             (uint32_t)ZH_CUT_LEN, cnt, c->d_taskinfo + t0, sbflags, (uint32_t)ZH_COOP_MIN);
    // An input without a chain task — nearly all of them — goes through its four passes on ONE wave, in one launch (zh_parse_loop.h: for
    // max-blocks that lost to the pass-by-pass kernels; here a pass over an input is two tasks, and eight launches per batch wait for each other)
    if (sbflags)
@@ -1199,7 +1205,10 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_CHECK(c, hipEventRecord(ev[2], st));
       if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
       // (segment descriptors carry batch-wide block indices: the rows go to d_match + block * match_stride)
-      ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint2 *)p3, (const uint32_t *)rn,
+      // a run of fewer segments than CUs (one call on a few max-blocks: latency): the workgroups beyond one per segment find the tickets gone and help —
+      // a segment of a 64 KiB max-block is ~1500 chunks, shared while a helper's share stays above ZH_MF_HELP_MIN of them
+      const uint32_t fr_grid = min(max(1u, c->num_cus * c->mf_cu_pct / 100u), mf_grid * 8u);
+      ZH_LAUNCH_LDS(zh_mf_frontier<true>, fr_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint2 *)p3, (const uint32_t *)rn,
                 c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, ctr, nsg, 1u);
       ZH_CHECK(c, hipEventRecord(ev[3], st));
       if (zh_enqueue_tokenize(c, st, blk, b0, nb) != 0) return -1;
@@ -1258,6 +1267,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       uint2 *taskmap = c->d_taskmap + t0;
       uint32_t *ntasks = c->d_ntasks + (size_t)k * ZH_CNT_STRIDE;   // the run's counters (ZH_CNT_*); [ZH_CNT_TASKS] = its number of tasks
       uint4 *segtasks = c->d_segtasks + (uint64_t)b0 * c->seg_tasks_per_block;
+      c->last_run_b0[k] = b0;
       uint2 *segwaves = c->d_segwaves + (uint64_t)b0 * c->seg_items_per_block;
       uint2 *segitems = c->d_segitems + (uint64_t)b0 * c->seg_items_per_block;
       int16_t *vecs = c->d_vecs + (uint64_t)b0 * c->seg_items_per_block * 2 * ZH_VEC;
@@ -1280,7 +1290,8 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       uint32_t *sbflags = c->d_sbflags + s0;
       ZH_CHECK(c, hipMemsetAsync(sbflags, 0, (size_t)ns * sizeof(uint32_t), st));
       ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, c->cut_len, ntasks, c->d_taskinfo + t0, sbflags);
+                (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, c->cut_len, ntasks, c->d_taskinfo + t0, sbflags,
+                (c->parse_lanes && task_grid <= c->num_cus) ? c->coop_small : (uint32_t)ZH_COOP_MIN);   // fewer tasks than CUs: what counts is the longest chain of steps, and a chain workgroup steps faster
       // The sub-blocks without a chain task go through their four passes on their own, one wave each (zh_parse_loop.h): launched at once, on a
       // stream of its own — nothing about it depends on the counts the host is about to read
       if (c->use_loop) {
@@ -1559,6 +1570,14 @@ extern "C" int zultra_hip_chain_trace(zultra_hip_ctx_t *c, uint64_t *out, uint32
    if (slots) *slots = ZH_TRACE_SLOTS;
    if (out) ZH_CHECK(c, hipMemcpy(out, c->d_chain_trace, (size_t)3 * ZH_TRACE_SLOTS * 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
    return 0;
+}
+
+// diagnostics: the cut tasks of run `run` of the last batch, {task, K | S / 32 << 12, first vector slot, segment completions | failed cuts << 16 (over the four passes)}
+extern "C" int zultra_hip_cut_tasks(zultra_hip_ctx_t *c, uint32_t run, uint32_t *out, uint32_t cap) {
+   if (!c || (int)run >= c->last_runs || c->files_mode) return -1;
+   const uint32_t n = min(cap, c->h_ntasks[(size_t)run * ZH_CNT_STRIDE + ZH_CNT_SEGTASKS]);
+   if (out && n) ZH_CHECK(c, hipMemcpy(out, c->d_segtasks + (uint64_t)c->last_run_b0[run] * c->seg_tasks_per_block, (size_t)n * sizeof(uint4), hipMemcpyDeviceToHost));
+   return (int)n;
 }
 
 #ifdef ZH_MF_PROFILE

@@ -260,10 +260,12 @@ __device__ __forceinline__ uint32_t zh_sb_build_one(zh_sb_ws_t &ws, const zh_wor
                                                 &ws.sc, false);
       // (the histograms of the last parse have priced the codes in force and are not read again: smoothed where they are)
       zh_wave_sync();
+#ifndef ZH_DBG_SKIP_SMOOTH   // (timing experiments with wrong output, tools/build_variant.sh)
       if (lane == 0) {
          zh_smooth_for_rle_lane(ZH_NLIT, ws.lit_freq, (uint8_t *)ws.sc.sorted);
          zh_smooth_for_rle_lane(ZH_NDIST, ws.dist_freq, (uint8_t *)ws.sc.sorted);
       }
+#endif
       zh_wave_sync();
       if (zh_huff_build_wave(ws.lit_freq, ws.alt_lit_len, ws.alt_lit_code, ZH_NLIT, 15, &ws.sc) < 0) failed = 1;
       if (zh_huff_build_wave(ws.dist_freq, ws.alt_dist_len, ws.alt_dist_code, ZH_NDIST, 15, &ws.sc) < 0) failed = 1;
@@ -291,7 +293,11 @@ __device__ __forceinline__ uint32_t zh_sb_build_one(zh_sb_ws_t &ws, const zh_wor
 
    const int nruns = zh_cl_make_runs_wave(ws.lens, nlit + ndist, ws.runs, ws.sc.keys);
    uint32_t mkey = 0xFFFFFFFFu;
+#ifdef ZH_DBG_ONE_MASK
+   if (lane < 1) {
+#else
    if (lane < 20) {
+#endif
       // 20 lanes, one mask each, all walking the same run list: the loop trip counts agree, only the token choice differs
       const unsigned mask = lane < 8 ? lane : 9 + 2 * (lane - 8);   // 0..7, 9, 11, ..., 31 (:959)
       zh_cl_t *h = &ws.cl_work[lane];

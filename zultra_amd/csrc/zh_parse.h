@@ -143,8 +143,10 @@ __device__ inline uint32_t zh_task_pieces(uint32_t *bnd, const uint64_t *bar, ui
 }
 
 // after a wave-level sync: does the task hold a piece of more than ZH_COOP_MIN positions?
-__device__ inline bool zh_task_is_huge(const uint32_t *bnd, uint32_t np, uint32_t lane) {
-   return zh_ballot(lane < np && bnd[lane + 1] - bnd[lane] > ZH_COOP_MIN) != 0;
+// (zh_list_huge may be given a smaller bound for a small batch: a piece is one quad's chain of dependent steps, ~0.2 us each, and a call on one
+// max-block waits for its longest piece in every pass — the chain kernel is three to four times faster per position)
+__device__ inline bool zh_task_is_huge(const uint32_t *bnd, uint32_t np, uint32_t lane, uint32_t coop_min = ZH_COOP_MIN) {
+   return zh_ballot(lane < np && bnd[lane + 1] - bnd[lane] > coop_min) != 0;
 }
 
 // ---- forward walk over the chosen parse of [t0, t1): histogram into LDS counters (blockdeflate.c:371-400) ----------
@@ -506,7 +508,7 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
          uint32_t old = 0;
          if (lane == 0) old = atomicAdd(seg_done, 1u);
          old = zh_readfirstlane(old);
-         if ((old + 1u) % ((seg_K + ZH_CUT_ROWS - 1u) / ZH_CUT_ROWS) != 0u) return;   // (the counter runs on over the passes)
+         if (((old & 0xffffu) + 1u) % ((seg_K + ZH_CUT_ROWS - 1u) / ZH_CUT_ROWS) != 0u) return;   // (the counter runs on over the passes; its high half counts the task's failed cuts)
          __threadfence();   // ... and the other waves' are in
          seg_checker = true;
          seg_exact = seg_K - 1u;   // the last segment started from the task's end: exact
@@ -535,6 +537,7 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
          ws.bnd[24] = 0xFFFFFFFFu;
          ws.bnd[32] = (seg_slot0 + k) | (k ? 0x80000000u : 0u);
          atomicAdd(seg_failed, 1u);   // statistics
+         atomicAdd(seg_done, 0x10000u);
       }
       np = 1;
       seg_import = true;

@@ -422,7 +422,8 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
 __global__ void __launch_bounds__(64)
 zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
              const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ longest, uint64_t longest_stride, uint32_t *hugelist, uint32_t cap, uint4 *segtasks,
-             uint2 *segitems, uint2 *segwaves, uint32_t seg_min, uint32_t cut_len, uint32_t *cnt, uint2 *taskinfo, uint32_t *sbflags /* zeroed; bit 0: the sub-block has a listed task */) {
+             uint2 *segitems, uint2 *segwaves, uint32_t seg_min, uint32_t cut_len, uint32_t *cnt, uint2 *taskinfo, uint32_t *sbflags /* zeroed; bit 0: the sub-block has a listed task */,
+             uint32_t coop_min /* <= ZH_COOP_MIN: tasks with a longer barrier-free piece are listed */) {
    __shared__ uint32_t bnd[ZH_MAXPIECES + 1];
    const uint32_t gt = blockIdx.x;
    if (gt >= cnt[ZH_CNT_TASKS]) return;
@@ -435,7 +436,7 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
    const uint32_t t1 = zh_task_boundary(bar, prev, wk.start, sb_end, tm.y + 1, wk.ntasks);
    const uint32_t np = zh_task_pieces(bnd, bar, prev, t0, t1, lane);
    zh_sync();
-   const bool huge = zh_task_is_huge(bnd, np, lane);
+   const bool huge = zh_task_is_huge(bnd, np, lane, coop_min);
    // the task's range and whether it is listed here, for the four passes of zh_parse_lanes: looking a boundary up means scanning the
    // barrier bitmap, 64 positions per dependent load — on data with few barriers that was a third of that kernel's time
    if (lane == 0) taskinfo[gt] = make_uint2(t0, t1 | (huge ? 0x80000000u : 0u));
@@ -664,7 +665,7 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       // a segment: the task's segments are counted (the counter runs on over the passes), the workgroup that finishes the last one checks them
       __threadfence();   // this segment's parse entries and vectors are out
       __syncthreads();
-      if (tid == 0) s_bad = (atomicAdd(&segtasks[ti].w, 1u) + 1u) % K;
+      if (tid == 0) s_bad = ((atomicAdd(&segtasks[ti].w, 1u) & 0xffffu) + 1u) % K;   // (high half: the task's failed cuts, zh_chain_check_task)
       __syncthreads();
       if (s_bad != 0) continue;
       __threadfence();   // ... and the other segments' are in
