@@ -122,6 +122,7 @@ typedef struct zultra_hip_stats_s {
    uint32_t settled_passes;            /* (sub-block, parse pass) pairs not run: the sub-block's code lengths had reached a fixed point of the loop at
                                           blockdeflate.c:874-901, every further pass would have reproduced the parse it has */
    uint32_t settled_kib;               /* ... the input they cover, in KiB (of 4 x positions / 1024 for the four passes of everything) */
+   uint32_t cut_demoted;               /* cut tasks that had several failed cuts in one pass and were parsed as one chain in the passes left */
 } zultra_hip_stats_t;
 void zultra_hip_last_stats(const zultra_hip_ctx_t *ctx, zultra_hip_stats_t *out);
 

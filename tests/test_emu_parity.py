@@ -117,6 +117,23 @@ def test_chain_segments_are_both_accepted_and_redone(emu, oracle, monkeypatch, w
         assert 0 < st["cut_redone"] < 4 * cuts, st
 
 
+@pytest.mark.parametrize("demote", ["0", "1", "3"])
+def test_cut_tasks_that_keep_failing_become_whole_chains(emu, oracle, monkeypatch, demote):
+    """A cut task with ZULTRA_HIP_DEMOTE (default 2) or more failed cuts in one pass is handed to zh_parse_chain as one chain for the passes
+    left (its checker parses failed segments again one after the other, on one row); zh_parse_segments skips it from then on. With 1 every
+    task with a failed cut goes, with 0 none: the stages are the oracle's each time."""
+    monkeypatch.setenv("ZULTRA_HIP_SEG_WIDE", "1")
+    monkeypatch.setenv("ZULTRA_HIP_SEG_WHOLE", "0")
+    monkeypatch.setenv("ZULTRA_HIP_DEMOTE", demote)
+    st = {}
+    check_window(emu, oracle, corpus.table_like(30000, 9), 0, 30000, tag="table_cut/demote" + demote, stats_out=st)
+    assert st["cut_tasks"] >= 1 and st["cut_redone"] > 0, st
+    if demote == "0":
+        assert st["cut_demoted"] == 0, st
+    elif demote == "1":
+        assert 1 <= st["cut_demoted"] <= st["cut_tasks"], st
+
+
 @pytest.mark.parametrize("block", [65536])
 def test_chain_lists_of_the_three_length_classes_do_not_run_into_each_other(emu, oracle, block):
     """zh_list_huge files whole chain tasks in three length classes. Records of 1800 zeros + 8 random bytes make most task

@@ -106,6 +106,7 @@ struct zultra_hip_ctx_s {
    uint2 *d_segitems;           // their segments, as jobs of zh_parse_chain: per max-block seg_items_per_block entries
    uint2 *d_segwaves;           // ... or as waves of zh_parse_segments (four segments each), likewise
    uint32_t cut_len;            // ... into segments of about this many positions
+   uint32_t demote_min;         // a cut task with this many failed cuts in a pass is parsed as one chain in the passes left (ZULTRA_HIP_DEMOTE; 0: never)
    uint32_t coop_small;         // runs of fewer tasks than CUs: tasks with a barrier-free piece longer than this go to the chain kernel (ZULTRA_HIP_COOP_SMALL; ZH_COOP_MIN otherwise)
    uint32_t cut_min;            // tasks of at least this many positions are cut into segments
    uint32_t seg_whole;          // ... with fewer, zh_parse_chain takes the segments — and the cut tasks shorter than this whole (ZULTRA_HIP_SEG_WHOLE)
@@ -568,6 +569,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->cut_len = cl ? (uint32_t)atoi(cl) : (uint32_t)ZH_CUT_LEN;
       if (c->cut_len < ZH_CUT_WARM) c->cut_len = ZH_CUT_WARM;
       if (c->cut_len > ZH_CUT_LEN) c->cut_len = ZH_CUT_LEN;   // (the buffers are sized for ZH_CUT_WARM, the smallest)
+      const char *dm = getenv("ZULTRA_HIP_DEMOTE");
+      c->demote_min = dm ? (uint32_t)atoi(dm) : 2u;
       const char *cs = getenv("ZULTRA_HIP_COOP_SMALL");
       c->coop_small = cs ? (uint32_t)atoi(cs) : 256u;
       if (c->coop_small < 64u) c->coop_small = 64u;
@@ -674,7 +677,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) || zh_alloc(c, &c->d_taskinfo, c->max_tasks) ||
        zh_alloc(c, &c->d_sbflags, B * c->max_subs) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
-       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 3 * ZH_MAX_RUNS) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, 3 * c->max_tasks) ||
+       zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 3 * ZH_MAX_RUNS) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, 4 * c->max_tasks) ||
        zh_alloc(c, &c->d_segtasks, B * c->seg_tasks_per_block) || zh_alloc(c, &c->d_segwaves, B * c->seg_items_per_block) || zh_alloc(c, &c->d_segitems, B * c->seg_items_per_block) ||
        zh_alloc(c, &c->d_vecs, B * c->seg_items_per_block * 2 * ZH_VEC) || zh_alloc(c, &c->d_hist_part, c->max_tasks * ZH_NSYM) || zh_alloc(c, &c->d_task_bits, c->max_tasks))
       return -1;
@@ -804,7 +807,7 @@ extern "C" size_t zultra_hip_context_bytes_on(int device, uint32_t max_block_siz
    bytes += B * slot_stride;                                         // payload slots
    bytes += (B * (N + 5 * (N / 65535 + 1) + 8) + 80);                // stitched stream
    bytes += subs * (sizeof(zh_sbstate_t) + sizeof(zh_work_t) + 2 * sizeof(zh_subblock_t) + sizeof(zh_stitch_item_t));
-   bytes += tasks * (2 * sizeof(uint2) + 3 * 4 + 4 + ZH_NSYM * 4);   // task map and ranges, chain lists, bit counts, histograms
+   bytes += tasks * (2 * sizeof(uint2) + 4 * 4 + 4 + ZH_NSYM * 4);   // task map and ranges, chain lists, bit counts, histograms
    bytes += B * (S * (sizeof(zh_seg_t) + 8) + sizeof(zh_block_t) + cpb * 12 + (ZH_MAX_SPLITS + 1) * 4 + 6 * 4) + 8192;
    {
       // payload of the matchfinder's refining passes: per run (ZULTRA_HIP_STREAMS) and persistent workgroup (one per CU)
@@ -910,7 +913,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    zh_work_t *work = c->d_work + b0;
    zh_sbstate_t *states = c->d_states + b0;
    uint2 *taskmap = c->d_taskmap + t0;
-   uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM, *hugelist = c->d_hugelist + 3 * t0, *task_bits = c->d_task_bits + t0;
+   uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM, *hugelist = c->d_hugelist + 4 * t0, *task_bits = c->d_task_bits + t0;
    uint8_t *payload = c->d_payload + (uint64_t)b0 * c->slot_stride;
    uint32_t *best = c->d_best + (uint64_t)b0 * c->best_stride;
    const uint64_t *bars = c->d_bars + (uint64_t)b0 * c->bar_stride;
@@ -1273,7 +1276,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       int16_t *vecs = c->d_vecs + (uint64_t)b0 * c->seg_items_per_block * 2 * ZH_VEC;
       uint32_t *h_cnt = c->h_ntasks + ZH_NCNT + (size_t)k * ZH_CNT_STRIDE;   // read back before the passes are launched
       uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM;
-      uint32_t *hugelist = c->d_hugelist + 3 * t0;   // three lists of task_grid entries each (zh_list_huge)
+      uint32_t *hugelist = c->d_hugelist + 4 * t0;   // four lists of task_grid entries each: three by zh_list_huge, the cut tasks given up on by zh_parse_segments
       uint32_t *task_bits = c->d_task_bits + t0;
       uint8_t *payload = c->d_payload + (uint64_t)b0 * c->slot_stride;
       uint32_t *best = c->d_best + b0 * c->best_stride;
@@ -1316,7 +1319,8 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       const bool seg_wide = nsegtasks && nsegs >= c->seg_wide;
       const uint32_t nseg_chain = (nsegtasks && !seg_wide) ? nsegs : 0u;
       const uint32_t nchains = h_cnt[ZH_CNT_VLONG] + h_cnt[ZH_CNT_LONG] + h_cnt[ZH_CNT_SHORT] + nseg_chain;
-      const uint32_t chain_grid = min(nchains, (uint32_t)ZH_CHAIN_GRID);
+      const bool run_chains = nchains || (seg_wide && c->demote_min);   // (a cut task that zh_parse_segments gives up on becomes a chain of the passes left)
+      const uint32_t chain_grid = min(nchains + (seg_wide && c->demote_min ? nsegtasks : 0u), (uint32_t)ZH_CHAIN_GRID);
       const uint32_t persistent_grid = min(task_grid, c->num_cus * c->task_waves);
       const bool by_pass = !c->use_loop || nchains || nsegtasks;   // some sub-block has a chain task: those go pass by pass, as all did before
       const uint32_t *pass_flags = c->use_loop ? (const uint32_t *)sbflags : (const uint32_t *)NULL;
@@ -1329,7 +1333,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
 #else
          const int dbg_skip = 0;
 #endif
-         if (nchains && !(dbg_skip & 1)) {
+         if (run_chains && !(dbg_skip & 1)) {
             ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
             ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
             ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
@@ -1342,10 +1346,10 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
             // single-wave workgroups like zh_parse_tasks', but each carries four segments of thousands of positions — on a stream
             // of their own they start with the pass
             hipStream_t sg = c->seg_stream[k];
-            if (!nchains) ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
+            if (!run_chains || (dbg_skip & 1)) ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
             ZH_CHECK(c, hipStreamWaitEvent(sg, c->side_ev[k][2 * pass], 0));
             ZH_LAUNCH(zh_parse_segments, h_cnt[ZH_CNT_SEGWAVES], 64, sg, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                      (const uint2 *)taskmap, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, segtasks, (const uint2 *)segwaves, vecs, ntasks);
+                      (const uint2 *)taskmap, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, segtasks, (const uint2 *)segwaves, vecs, ntasks, hugelist + 3 * (size_t)task_grid, c->demote_min);
             ZH_CHECK(c, hipEventRecord(c->seg_ev[k][pass], sg));
          }
          if ((dbg_skip & 2) || !by_pass) ;
@@ -1368,7 +1372,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
             ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                       (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
          if (seg_wide) ZH_CHECK(c, hipStreamWaitEvent(st, c->seg_ev[k][pass], 0));
-         if (nchains && !(dbg_skip & 1)) ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
+         if (run_chains && !(dbg_skip & 1)) ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
          ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));
          if (by_pass) ZH_LAUNCH(zh_sb_build, ns, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, pass_flags, ntasks);
          ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));
@@ -1626,6 +1630,7 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
       out->cut_tasks += cnt[ZH_CNT_SEGTASKS];
       out->cut_segments += cnt[ZH_CNT_SEGITEMS];
       out->cut_redone += cnt[ZH_CNT_SEG_FAILED];   // over the four passes
+      out->cut_demoted += cnt[ZH_CNT_DEMOTED];
       out->settled_passes += cnt[ZH_CNT_SETTLED];
       out->settled_kib += cnt[ZH_CNT_SETTLED_POS];
    }

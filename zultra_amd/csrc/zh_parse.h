@@ -83,7 +83,8 @@ __device__ __forceinline__ uint32_t zh_ring_wrap(uint32_t x) { return min(x, x -
 // segtasks[].y: number of segments | their length / 32 << 12
 #define ZH_CUT_PACK(K, S) ((K) | (((S) >> 5) << 12))
 #define ZH_CUT_K(y) ((y) & 0xfffu)
-#define ZH_CUT_S(y) (((y) >> 12) << 5)
+#define ZH_CUT_S(y) ((((y) >> 12) & 0x7ffffu) << 5)
+#define ZH_CUT_DEMOTED 0x80000000u   // in segtasks[].y: the task is no longer parsed as segments (its entry in the fourth chain list says by whom)
 #define ZH_VEC 264u               // int16 entries per cost vector: cost[x + i] - cost[x], i = 0..258 (+ padding)
 #define ZH_VEC_LIVE 259u
 #define ZH_VEC_BIAS 4096          // imported costs are (bias + difference) << 9: differences are below 258 x 15 in magnitude
@@ -95,7 +96,8 @@ __device__ __forceinline__ uint32_t zh_ring_wrap(uint32_t x) { return min(x, x -
 enum {
    ZH_CNT_TASKS = 0, ZH_CNT_VLONG, ZH_CNT_LONG, ZH_CNT_SHORT, ZH_CNT_HUGE_POS, ZH_CNT_SEGTASKS, ZH_CNT_SEGITEMS, ZH_CNT_SEG_FAILED,
    ZH_CNT_CHAIN_TICKET = 8, ZH_CNT_TASK_TICKET = 12, ZH_CNT_FIX_TICKET = 16, ZH_CNT_SEGWAVES = 20,
-   ZH_CNT_SETTLED = 21 /* parse passes not run because the sub-block's prices had stopped moving (zh_sb_build_one) */, ZH_CNT_SETTLED_POS = 22 /* ... in KiB of input */, ZH_CNT_STRIDE = 32
+   ZH_CNT_SETTLED = 21 /* parse passes not run because the sub-block's prices had stopped moving (zh_sb_build_one) */, ZH_CNT_SETTLED_POS = 22 /* ... in KiB of input */,
+   ZH_CNT_DEMOTED = 23 /* cut tasks handed to zh_parse_chain as whole chains for the passes left (zh_parse_one_task) */, ZH_CNT_DEMOTED_PASS = 24 /* .. 27: listed in pass p */, ZH_CNT_STRIDE = 32
 };
 
 // sub-block work item produced by zh_plan_subblocks
@@ -305,7 +307,9 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
                                          const zh_match_t *__restrict__ match, uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride,
                                          const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
                                          uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t seg_KS, uint32_t seg_k0, uint32_t seg_slot0,
-                                         int16_t *vecs, uint32_t *seg_done, uint32_t *seg_failed) {
+                                         int16_t *vecs, uint32_t *seg_done, uint32_t *cnt /* the run's counters */, uint32_t *demote_list, uint32_t demote_min) {
+   uint32_t *seg_failed = SEG ? cnt + ZH_CNT_SEG_FAILED : (uint32_t *)NULL;
+   uint32_t seg_nfail = 0;   // (SEG, checker) cuts of the task that failed in this pass
    const uint32_t seg_K = ZH_CUT_K(seg_KS), seg_S = ZH_CUT_S(seg_KS);
    const uint2 tm = taskmap[gt];
    const zh_work_t wk = work[tm.x];
@@ -539,11 +543,21 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
          atomicAdd(seg_failed, 1u);   // statistics
          atomicAdd(seg_done, 0x10000u);
       }
+      seg_nfail++;
       np = 1;
       seg_import = true;
       zh_sync();
    }
 
+   // A failed cut is parsed again by this one wave on one of its rows, cut after cut: a task with several of them holds its pass up
+   // for milliseconds. Speculation that failed under one pass's prices mostly fails under the next: such a task goes
+   // to zh_parse_chain as ONE chain for the passes left — a workgroup there steps several times faster than a row — by an entry in the
+   // run's fourth chain list; zh_parse_segments skips it from then on.
+   if (SEG && demote_min && seg_nfail >= demote_min && pass < 3 && lane == 0) {
+      atomicOr(seg_done - 2, ZH_CUT_DEMOTED);   // (segtasks[].y; seg_done points at .w, the counter)
+      demote_list[atomicAdd(&cnt[ZH_CNT_DEMOTED], 1u)] = gt;
+      atomicAdd(&cnt[ZH_CNT_DEMOTED_PASS + pass], 1u);
+   }
    // ---- histogram of the task's parse; the per-sub-block sum is taken by zh_sb_build ------------------------------------
    if (st->is_dynamic) {
       __threadfence_block();
@@ -577,7 +591,7 @@ zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       if (gt >= ntasks) return;
       zh_sync();   // (persistent form) the previous task is done with the workspace
       zh_parse_one_task<false>(ws, gt, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, 0u, 0u, 0u,
-                               (int16_t *)NULL, (uint32_t *)NULL, (uint32_t *)NULL);
+                               (int16_t *)NULL, (uint32_t *)NULL, (uint32_t *)NULL, (uint32_t *)NULL, 0u);
       if (!ticket) return;
    }
 }
@@ -588,11 +602,13 @@ __global__ void __launch_bounds__(64)
 zh_parse_segments(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                   const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
                   const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint4 *segtasks,
-                  const uint2 *__restrict__ segwaves, int16_t *vecs, uint32_t *cnt) {
+                  const uint2 *__restrict__ segwaves, int16_t *vecs, uint32_t *cnt, uint32_t *demote_list /* the run's fourth chain list */,
+                  uint32_t demote_min /* a task with this many failed cuts in a pass is a whole chain from the next pass on; 0: never */) {
    __shared__ zh_parse_ws_t ws;
    if (blockIdx.x >= cnt[ZH_CNT_SEGWAVES]) return;
    const uint2 sw = segwaves[blockIdx.x];
    const uint4 stask = segtasks[sw.x];
+   if (stask.y & ZH_CUT_DEMOTED) return;   // (set by the task's checker at the end of an earlier pass: every wave of the task sees it or none)
    zh_parse_one_task<true>(ws, stask.x, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, stask.y, sw.y,
-                           stask.z, vecs, &segtasks[sw.x].w, cnt + ZH_CNT_SEG_FAILED);
+                           stask.z, vecs, &segtasks[sw.x].w, cnt, demote_list, demote_min);
 }

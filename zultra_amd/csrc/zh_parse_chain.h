@@ -601,7 +601,11 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
    __shared__ zh_chain_ws_t ws;
    __shared__ uint32_t s_item, s_bad;
    const uint32_t tid = threadIdx.x;
-   const uint32_t nvlong = cnt[ZH_CNT_VLONG], nlong = cnt[ZH_CNT_LONG], count = nvlong + nlong + nseg + cnt[ZH_CNT_SHORT];
+   // the cut tasks that zh_parse_segments gave up on in the passes before this one (zh_parse_one_task: the fourth list, in the order of the
+   // passes): whole chains, and the longest of the pass — they get the first tickets
+   uint32_t ndem = 0;
+   for (int q = 0; q < pass; q++) ndem += cnt[ZH_CNT_DEMOTED_PASS + q];
+   const uint32_t nvlong = ndem + cnt[ZH_CNT_VLONG], nlong = cnt[ZH_CNT_LONG], count = nvlong + nlong + nseg + cnt[ZH_CNT_SHORT];
    for (;;) {
       __syncthreads();   // the previous task's histogram has left LDS, s_item has been read
       if (tid == 0) s_item = atomicAdd(ticket, 1u);
@@ -622,7 +626,8 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          slot = stask.z + k;
       }
       else
-         gt = item < nvlong ? hugelist[item] : (item < nvlong + nlong ? hugelist[cap + (item - nvlong)] : hugelist[2u * cap + (item - nvlong - nlong - nseg)]);
+         gt = item < ndem ? hugelist[3u * cap + item]
+                          : (item < nvlong ? hugelist[item - ndem] : (item < nvlong + nlong ? hugelist[cap + (item - nvlong)] : hugelist[2u * cap + (item - nvlong - nlong - nseg)]));
       const zh_chain_task_t T = zh_chain_task(gt, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, pass);
       if (T.skip) continue;
       zh_chain_prices(ws, T.st);
