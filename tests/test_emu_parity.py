@@ -108,7 +108,7 @@ def test_chain_segments_are_both_accepted_and_redone(emu, oracle, monkeypatch, w
     monkeypatch.setenv("ZULTRA_HIP_SEG_WIDE", "1000000" if wide == "whole" else wide)
     monkeypatch.setenv("ZULTRA_HIP_SEG_WHOLE", "1000000" if wide == "whole" else "0")
     st = {}
-    check_window(emu, oracle, corpus.table_like(30000, 9), 0, 30000, tag="table_cut/" + wide, stats_out=st)
+    check_window(emu, oracle, corpus.table_like(26000, 9), 0, 26000, tag="table_cut/" + wide, stats_out=st)
     cuts = st["cut_segments"] - st["cut_tasks"]
     assert st["cut_tasks"] >= 1 and cuts >= 8
     if wide == "whole":
@@ -117,7 +117,7 @@ def test_chain_segments_are_both_accepted_and_redone(emu, oracle, monkeypatch, w
         assert 0 < st["cut_redone"] < 4 * cuts, st
 
 
-@pytest.mark.parametrize("demote", ["0", "1", "3"])
+@pytest.mark.parametrize("demote", ["0", "1"])
 def test_cut_tasks_that_keep_failing_become_whole_chains(emu, oracle, monkeypatch, demote):
     """A cut task with ZULTRA_HIP_DEMOTE (default 2) or more failed cuts in one pass is handed to zh_parse_chain as one chain for the passes
     left (its checker parses failed segments again one after the other, on one row); zh_parse_segments skips it from then on. With 1 every
@@ -126,7 +126,7 @@ def test_cut_tasks_that_keep_failing_become_whole_chains(emu, oracle, monkeypatc
     monkeypatch.setenv("ZULTRA_HIP_SEG_WHOLE", "0")
     monkeypatch.setenv("ZULTRA_HIP_DEMOTE", demote)
     st = {}
-    check_window(emu, oracle, corpus.table_like(30000, 9), 0, 30000, tag="table_cut/demote" + demote, stats_out=st)
+    check_window(emu, oracle, corpus.table_like(26000, 9), 0, 26000, tag="table_cut/demote" + demote, stats_out=st)
     assert st["cut_tasks"] >= 1 and st["cut_redone"] > 0, st
     if demote == "0":
         assert st["cut_demoted"] == 0, st
@@ -161,8 +161,9 @@ def test_memory_compress_over_two_device_lanes(emu, oracle, monkeypatch):
     """ZULTRA_HIP_DEVICES=0,0: zultra_memory_compress cuts the input into two shards of max-blocks, a host thread and a device
     context each (here: on the emulator's one device, the kernels taking turns), and stitches the shards in stream order at the
     bit phase the stream has reached — a stored sub-block sits right behind the cut. Same bytes as the one-stream path."""
-    d = corpus.text_like(3 * 32768 + 300, 9)           # four max-blocks: two per lane
-    d[2 * 32768:2 * 32768 + 12000] = corpus.noise(12000, 4)
+    d = corpus.text_like(2 * 32768 + 300, 9)           # three max-blocks: two for the first lane, one for the second
+    d[32768:32768 + 12000] = corpus.noise(12000, 4)
+    d[2 * 32768:] = corpus.noise(300, 5)
     want = oracle.memory_compress(d, 2, 32768)
     monkeypatch.setenv("ZULTRA_HIP_DEVICES", "0,0")
     got = emu.memory_compress(d, 2, 32768)

@@ -38,10 +38,10 @@ nb = (n + bs - 1) // bs
 lo, hi = sharded.shard_range(nb, rank, world)
 ctx = None
 if hi > lo:
-    first = lo * bs - (32768 if lo else 0)
+    first = lo * bs - min(32768, lo * bs)
     blocks = []
     for b in range(lo, hi):
-        prev = 32768 if b else 0
+        prev = min(32768, b * bs)
         blocks.append((b * bs - prev - first, prev, min(bs, n - b * bs)))
     ctx = E.context(bs, hi - lo)
     ctx.compress_blocks(data[first:min(n, hi * bs)], blocks)
@@ -73,16 +73,16 @@ def _run(tmp_path, world, nfull, tail, port):
 
 
 def test_two_rank_assembly_matches_single_stream(tmp_path):
-    _run(tmp_path, 2, 1, 14000, 29533)          # 2 max-blocks, one per rank
+    _run(tmp_path, 2, 1, 5000, 29533)          # 2 max-blocks, one per rank
 
 
 def test_four_rank_assembly_matches_single_stream(tmp_path):
-    out = _run(tmp_path, 4, 3, 14000, 29534)    # 4 max-blocks, one per rank, a stored sub-block behind every cut
+    out = _run(tmp_path, 4, 3, 5000, 29534)    # 4 max-blocks, one per rank, a stored sub-block behind every cut
     assert "SHARDED_OK" in out
 
 
 def test_more_ranks_than_blocks(tmp_path):
-    _run(tmp_path, 3, 1, 14000, 29535)          # 2 max-blocks over 3 ranks: rank 0 (the gather root) has an empty shard
+    _run(tmp_path, 3, 1, 5000, 29535)          # 2 max-blocks over 3 ranks: rank 0 (the gather root) has an empty shard
 
 
 def test_shard_range_partitions_blocks():

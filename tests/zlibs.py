@@ -30,9 +30,13 @@ def _ptr(a, t=_u8p):
 
 def build_oracle():
     """Compile the oracle (and the reference build when /root/reference is present)."""
-    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
-    if os.path.isdir("/root/reference/src"):
-        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "ref"], check=True)
+    import fcntl
+    os.makedirs(os.path.join(ORACLE_DIR, "_build"), exist_ok=True)
+    with open(os.path.join(ORACLE_DIR, "_build", ".lock"), "w") as lock:   # several test processes may get here at once (pytest-xdist)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "oracle"], check=True)
+        if os.path.isdir("/root/reference/src"):
+            subprocess.run(["make", "-s", "-C", ORACLE_DIR, "ref"], check=True)
 
 
 def as_u8(data):
