@@ -507,7 +507,11 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup, last_rank=None):
             "sub_blocks_per_block": round(st["subblocks"] / max(1, st["blocks"]), 3),
             "parse_huge_share_of_positions": round(st["huge_positions"] / max(1, st["positions"]), 4),
             "parse_tasks": st["tasks"], "parse_huge_tasks": st["huge_tasks"],
-            "chain_cut": {"tasks": st["cut_tasks"], "segments": st["cut_segments"], "redone_over_4_passes": st["cut_redone"]},
+            "chain_cut": {"tasks": st["cut_tasks"], "segments": st["cut_segments"], "redone_over_4_passes": st["cut_redone"],
+                          "tasks_handed_to_the_chain_kernel": st["cut_demoted"]},
+            # sub-blocks whose code lengths reached a fixed point of the four-pass loop are not parsed again: the share of the
+            # 4 x positions of parse work that was not run
+            "parse_settled_share": round(st["settled_kib"] * 1024 / max(1, 4 * st["positions"]), 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(launch_ms, 3),
@@ -518,7 +522,7 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup, last_rank=None):
 
 def summarize_leg(r):
     return {k: r[k] for k in ("ms_per_step", "kernel_ms", "device_pipeline_ms", "d2h_ms", "kernel_only_MBps", "sub_blocks_per_block",
-                              "parse_huge_share_of_positions", "parse_tasks", "parse_huge_tasks", "chain_cut", "per_rank")}
+                              "parse_huge_share_of_positions", "parse_settled_share", "parse_tasks", "parse_huge_tasks", "chain_cut", "per_rank")}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -835,7 +839,7 @@ def run_other_configs(args):
             continue
         keep = ("metric", "value", "unit", "ms_per_step", "kernel_ms", "issue", "graph_ms_per_batch", "input_MBps", "ratio", "size_vs_zlib9", "size_vs_zlib9_sample_bytes",
                 "inflate_roundtrip_ok", "gzip_roundtrip_ok_first_files", "bit_exact_vs_cpu_on_sample", "memory_compress_equals_sharded_pipeline", "end_to_end_MBps",
-                "compressed_bytes_total", "sub_blocks_per_block", "parse_huge_share_of_positions", "chain_cut", "readme_size_check")
+                "compressed_bytes_total", "sub_blocks_per_block", "parse_huge_share_of_positions", "parse_settled_share", "chain_cut", "readme_size_check")
         o = {k: d[k] for k in keep if k in d}
         o["workload"] = d["config"]["workload"]
         o["roofline"] = d["roofline"]

@@ -1214,6 +1214,9 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_LAUNCH_LDS(zh_mf_frontier<true>, fr_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint2 *)p3, (const uint32_t *)rn,
                 c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, ctr, nsg, 1u);
       ZH_CHECK(c, hipEventRecord(ev[3], st));
+      // per-max-block CRC-32 (linear part) and Adler-32 for the framing's footer: they need the input only — here, not behind the run's last kernel
+      // where they were the tail of the batch
+      ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
       if (zh_enqueue_tokenize(c, st, blk, b0, nb) != 0) return -1;
 #define ZH_LAUNCH_SPLIT(W_)                                                                                                                                   \
    ZH_LAUNCH(zh_split<W_>, nb, 64 * W_, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), \
@@ -1385,8 +1388,6 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
                 (const uint32_t *)ntasks, (const zh_sbstate_t *)states, (const uint32_t *)best, c->best_stride, (const uint32_t *)task_bits, payload,
                 c->d_results + s0, (const uint2 *)(c->d_taskinfo + t0));
       ZH_CHECK(c, hipEventRecord(ev[15], st));
-      // per-max-block CRC-32 (linear part) for the gzip footer
-      ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
       ZH_CHECK(c, hipMemcpyAsync(c->h_results + lane_sub0[k], c->d_results + s0, ns * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipMemcpyAsync(c->h_crc + b0, c->d_crc + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipMemcpyAsync(c->h_adler + 2 * (size_t)b0, c->d_adler + 2 * (size_t)b0, 2 * nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
