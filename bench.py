@@ -621,14 +621,16 @@ def run_stream_config(args, env, prep):
 
     if rank == 0 and world == 1:
         # whole-input ratio against zlib-9 (README.md:16-46 quotes sizes against zlib/zopfli)
-        t0 = time.perf_counter()
         zs = shard if len(shard) <= (128 << 20) else shard[: 64 << 20]   # (zlib-9 runs at ~20 MB/s: a GiB shard is priced on its first 64 MiB)
-        z9 = len(zlib.compress(zs.tobytes(), 9))
+        zbytes = zs.tobytes()
+        t0 = time.perf_counter()
+        z9 = len(zlib.compress(zbytes, 9))
+        z9_s = time.perf_counter() - t0   # (zlib alone: not the copy to bytes, not our own compress of the sample below)
         ours = len(framed) if zs is shard else len(L.memory_compress(zs, flags, bs))
         line["size_vs_zlib9"] = round(ours / (z9 + (12 if flags == 2 else 0)), 5)
         if zs is not shard:
             line["size_vs_zlib9_sample_bytes"] = len(zs)
-        line["zlib9_MBps_1core"] = round(len(zs) / (time.perf_counter() - t0) / 1e6, 1)
+        line["zlib9_MBps_1core"] = round(len(zs) / z9_s / 1e6, 1)
         # the drop-in entry on a host buffer: H2D, kernels, stitch, D2H, frame (PCIe-inclusive; never `value`)
         # (into a buffer the caller owns and has touched, as lzbench and tool/zultra.c -cbench do: the call itself, not Python's allocation
         # and copy of the result)

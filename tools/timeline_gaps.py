@@ -3,7 +3,8 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 names=[r["Kernel_Name"] for r in rows]
 st=[i for i,n in enumerate(names) if n.startswith("zh_stitch")]
-a=st[-2]+1; b=st[-1]+1
+if not st: sys.exit("no zh_stitch launch in the trace")
+a=st[-2]+1 if len(st)>1 else 0; b=st[-1]+1
 last=rows[a:b]
 t0=int(last[0]["Start_Timestamp"])
 prev_end=t0
