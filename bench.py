@@ -459,7 +459,7 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup, last_rank=None):
 
     if rank == 0 and ctx is None:
         raise RuntimeError("bench.py: rank 0 has no max-block (fewer max-blocks than ranks)")
-    res = {"n": n, "nblocks": nblocks, "dt": dt, "stats": ctx.stats() if ctx is not None else None, "ctx": ctx, "d_data": d_data}
+    res = {"n": n, "nblocks": nblocks, "dt": dt, "stats": ctx.stats() if ctx is not None else None, "ctx": ctx, "d_data": d_data, "blocks": blocks}
     # what every rank spent where: device pipeline (first launch to last completion of a batch), the exchange steps of the assembly
     mine = [float(np.mean([t["total_ms"] for t in timings])) if timings else 0.0, float(np.mean([c[0] for c in colls])), float(colls[-1][1]), float(colls[-1][2]), float(n)]
     per_rank = [mine]
@@ -658,6 +658,46 @@ def run_stream_config(args, env, prep):
             gpu_out = L.memory_compress(sample, flags, bs)
             line["bit_exact_vs_cpu_on_sample"] = bool(gpu_out == ref_out)
             failed |= gpu_out != ref_out
+        if cfg == 2 and not args.leg and not strong:
+            # Not `value`: what a caller gets who keeps three jobs of this size in flight — a context and a host thread each, the same shard, the
+            # same job (kernels, stitch, read-back into a pinned buffer of its own). One job at a time leaves the chip nearly idle for its last
+            # ~3.5 ms (final code build, literalisation, emission, stitch plan on the host, read-back: DESIGN.md 4); other jobs fill that.
+            import threading
+            torch, device = env["torch"], env["device"]
+            K, reps = 3, max(3, min(8, args.steps))
+            blocks_ = head["blocks"]
+            d_data_ = torch.from_numpy(shard if lead is None else np.concatenate([lead, shard])).to(device)   # (world 1: no lead; as run_stream_leg lays it out)
+            ctxs = [L.context(bs, head["nblocks"], device=env["local_rank"]) for _ in range(K)]
+            pins = [torch.empty(len(head["body"]) + (1 << 20), dtype=torch.uint8, pin_memory=True).numpy() for _ in range(K)]
+            outs, errs = [None] * K, []
+
+            def job(i, nrep):
+                try:
+                    for _ in range(nrep):
+                        ctxs[i].compress_blocks(d_data_.data_ptr(), blocks_, data_on_device=True, data_size=d_data_.numel())
+                        end_bit, _ = ctxs[i].stitch_device(head["nblocks"] - 1, phase=0)
+                        outs[i] = ctxs[i].stream_read((end_bit + 7) // 8, out=pins[i])
+                except Exception as e:   # noqa: BLE001 (reported below)
+                    errs.append(repr(e))
+
+            for i in range(K):
+                job(i, 1)   # warm every context
+            torch.cuda.synchronize()
+            ths = [threading.Thread(target=job, args=(i, reps)) for i in range(K)]
+            t0 = time.perf_counter()
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            same3 = not errs and all(o is not None and o.tobytes() == head["body"].tobytes() for o in outs)
+            line["three_jobs_in_flight"] = {"MBps": round(K * reps * head["n"] / dt3 / 1e6, 1), "ms_per_job": round(dt3 / (K * reps) * 1e3, 3), "jobs": K * reps,
+                                            "same_bytes_as_value_run": bool(same3), "note": "not `value`: three contexts, one host thread each, on this one GPU"}
+            failed |= not same3
+            for c_ in ctxs:
+                c_.close()
+            del d_data_
         if cfg == 2 and not args.no_synthetic and not args.leg:
             # round 1's headline corpus, for continuity: Zipf words without repeated phrases (never splits, never hits the chain parse)
             slead, sshard = SyntheticText().shard(0, size)
