@@ -642,51 +642,70 @@ __device__ inline int zh_table_cost_wave(const uint8_t *lens, int n, zh_cl_t *h,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// huffutils.c:34-114 (zopfli's OptimizeHuffmanForRle), single lane, `keep` = scratch of `length` bytes.
+// huffutils.c:34-114 (zopfli's OptimizeHuffmanForRle), single lane, `keep` = scratch of `length` bytes (4-byte aligned).
+// Both walks are sequential in their state (the run so far; stride, limit and sum) but every value they read is an ORIGINAL count — the fills
+// only ever write below the position the walk has reached — so the counts (and the keep flags) are fetched eight positions at a time, the loads
+// of a chunk in flight together, and the eight steps run on registers: a step was three dependent LDS round trips before.
 // ---------------------------------------------------------------------------------------------------------
 __device__ inline void zh_smooth_for_rle_lane(int length, int32_t *counts, uint8_t *keep) {
    while (length > 0 && counts[length - 1] == 0) length--;
    if (length == 0) return;
-   for (int i = 0; i < length; i++) keep[i] = 0;
+   for (int i = 0; i < length; i += 4) *(uint32_t *)(keep + i) = 0u;   // (whole words: the scratch is longer than any alphabet)
    {
       uint32_t symbol = (uint32_t)counts[0];
       int stride = 0;
-      for (int i = 0; i <= length; i++) {
-         if (i == length || (uint32_t)counts[i] != symbol) {
-            if ((symbol == 0 && stride >= 5) || (symbol != 0 && stride >= 7))
-               for (int k = 0; k < stride; k++) keep[i - k - 1] = 1;
-            stride = 1;
-            if (i != length) symbol = (uint32_t)counts[i];
+      for (int base = 0; base <= length; base += 8) {
+         uint32_t c[8];
+#pragma unroll
+         for (int j = 0; j < 8; j++) c[j] = (uint32_t)counts[min(base + j, length - 1)];
+#pragma unroll
+         for (int j = 0; j < 8; j++) {
+            const int i = base + j;
+            if (i <= length) {
+               if (i == length || c[j] != symbol) {
+                  if ((symbol == 0 && stride >= 5) || (symbol != 0 && stride >= 7))
+                     for (int k = 0; k < stride; k++) keep[i - k - 1] = 1;
+                  stride = 1;
+                  if (i != length) symbol = c[j];
+               }
+               else
+                  stride++;
+            }
          }
-         else
-            stride++;
       }
    }
    int stride = 0;
    uint32_t limit = (uint32_t)counts[0], sum = 0;
-   for (int i = 0; i <= length; i++) {
-      bool brk = (i == length) || keep[i];
-      if (!brk) {
-         uint32_t c = (uint32_t)counts[i];
-         brk = (c > limit ? c - limit : limit - c) >= 4;
-      }
-      if (brk) {
-         if (stride >= 4 || (stride >= 3 && sum == 0)) {
-            int count = (int)((sum + (uint32_t)(stride / 2)) / (uint32_t)stride);
-            if (count < 1) count = 1;
-            if (sum == 0) count = 0;
-            for (int k = 0; k < stride; k++) counts[i - k - 1] = count;
+   for (int base = 0; base <= length; base += 8) {
+      uint32_t c[11];
+#pragma unroll
+      for (int j = 0; j < 11; j++) c[j] = (uint32_t)counts[min(base + j, length - 1)];
+      const uint32_t k0 = *(const uint32_t *)(keep + base), k1 = *(const uint32_t *)(keep + base + 4);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+         const int i = base + j;
+         if (i <= length) {
+            bool brk = (i == length) || (((j < 4 ? k0 >> (8 * j) : k1 >> (8 * (j - 4))) & 0xffu) != 0u);
+            if (!brk) brk = (c[j] > limit ? c[j] - limit : limit - c[j]) >= 4;
+            if (brk) {
+               if (stride >= 4 || (stride >= 3 && sum == 0)) {
+                  int count = (int)((sum + (uint32_t)(stride / 2)) / (uint32_t)stride);
+                  if (count < 1) count = 1;
+                  if (sum == 0) count = 0;
+                  for (int k = 0; k < stride; k++) counts[i - k - 1] = count;
+               }
+               stride = 0;
+               sum = 0;
+               if (i < length - 3)
+                  limit = (uint32_t)(((int32_t)c[j] + (int32_t)c[j + 1] + (int32_t)c[j + 2] + (int32_t)c[j + 3] + 2) / 4);
+               else if (i < length)
+                  limit = c[j];
+               else
+                  limit = 0;
+            }
+            stride++;
+            if (i != length) sum += c[j];
          }
-         stride = 0;
-         sum = 0;
-         if (i < length - 3)
-            limit = (uint32_t)((counts[i] + counts[i + 1] + counts[i + 2] + counts[i + 3] + 2) / 4);
-         else if (i < length)
-            limit = (uint32_t)counts[i];
-         else
-            limit = 0;
       }
-      stride++;
-      if (i != length) sum += (uint32_t)counts[i];
    }
 }
