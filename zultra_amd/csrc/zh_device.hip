@@ -107,6 +107,7 @@ struct zultra_hip_ctx_s {
    uint2 *d_segwaves;           // ... or as waves of zh_parse_segments (four segments each), likewise
    uint32_t cut_len;            // ... into segments of about this many positions
    uint32_t demote_min;         // a cut task with this many failed cuts in a pass is parsed as one chain in the passes left (ZULTRA_HIP_DEMOTE; 0: never)
+   uint32_t coop_tasks;         // ... a run of at most this many tasks counts as small (ZULTRA_HIP_COOP_TASKS, default: the number of CUs)
    uint32_t coop_small;         // runs of fewer tasks than CUs: tasks with a barrier-free piece longer than this go to the chain kernel (ZULTRA_HIP_COOP_SMALL; ZH_COOP_MIN otherwise)
    uint32_t cut_min;            // tasks of at least this many positions are cut into segments
    uint32_t seg_whole;          // ... with fewer, zh_parse_chain takes the segments — and the cut tasks shorter than this whole (ZULTRA_HIP_SEG_WHOLE)
@@ -575,6 +576,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->coop_small = cs ? (uint32_t)atoi(cs) : 256u;
       if (c->coop_small < 64u) c->coop_small = 64u;
       if (c->coop_small > ZH_COOP_MIN) c->coop_small = ZH_COOP_MIN;
+      const char *ct = getenv("ZULTRA_HIP_COOP_TASKS");
+      c->coop_tasks = ct ? (uint32_t)atoi(ct) : c->num_cus;
       const char *cm = getenv("ZULTRA_HIP_CUT_MIN");   // tuning experiments: tasks of at least this many positions are cut (>= 2 * ZH_CUT_WARM)
       c->cut_min = cm ? (uint32_t)atoi(cm) : (uint32_t)ZH_CUT_MIN;
       if (c->cut_min < 2u * ZH_CUT_WARM) c->cut_min = 2u * ZH_CUT_WARM;
@@ -1297,7 +1300,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_CHECK(c, hipMemsetAsync(sbflags, 0, (size_t)ns * sizeof(uint32_t), st));
       ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
                 (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, c->cut_len, ntasks, c->d_taskinfo + t0, sbflags,
-                (c->parse_lanes && task_grid <= c->num_cus) ? c->coop_small : (uint32_t)ZH_COOP_MIN);   // fewer tasks than CUs: what counts is the longest chain of steps, and a chain workgroup steps faster
+                (c->parse_lanes && task_grid <= c->coop_tasks) ? c->coop_small : (uint32_t)ZH_COOP_MIN);   // fewer tasks than CUs: what counts is the longest chain of steps, and a chain workgroup steps faster
       // The sub-blocks without a chain task go through their four passes on their own, one wave each (zh_parse_loop.h): launched at once, on a
       // stream of its own — nothing about it depends on the counts the host is about to read
       if (c->use_loop) {
