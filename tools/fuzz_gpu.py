@@ -3,7 +3,7 @@
 noise, constant and periodic stretches, JSON, the mixed stream), random sizes from 1 byte to a few MB, the three framings, 32 KiB / 64 KiB /
 default max-blocks — the product library's zultra_memory_compress against the compiled reference (oracle/_ref, built here and carried over by
 gpurun) byte for byte. The reference outputs come from a pool of processes started BEFORE this process touches the GPU.
-usage: python tools/fuzz_gpu.py [cases] [seed] [max bytes per case]        exit code 1 on the first difference (the case is written to
+usage: python tools/fuzz_gpu.py [cases] [seed] [max bytes per case] | --files [inputs] [seed] | --stream [cases] [seed] [max bytes]     exit code 1 on the first difference (the case is written to
 gpurun_out/fuzz_fail_<seed>_<case>.bin)"""
 import multiprocessing as mp
 import os
@@ -79,7 +79,81 @@ def ref_one(args):
     return k, zlib.crc32(out) if out is not None else None, len(out) if out is not None else -1, d.tobytes(), flags, bs   # (the generators are slow: the input travels back too)
 
 
+def ref_file(args):
+    seed, k = args
+    import zlibs
+    rs = np.random.RandomState((seed * 7919 + k) & 0x7fffffff)
+    n = int(rs.choice([1, 2, 3, 17, 100, 1000, 4095, 4096])) if rs.randint(0, 4) == 0 else int(rs.randint(1, 4097))
+    g = rs.randint(0, 6)
+    s_ = int(rs.randint(1, 1 << 20))
+    d = [corpus.json_like, corpus.text_like, corpus.noise, corpus.indented, corpus.table_like][g % 5](n, s_) if g < 5 else corpus.constant(n, int(rs.randint(0, 256)))
+    d = np.ascontiguousarray(d, dtype=np.uint8)[:n]
+    out = zlibs.Ref().memory_compress(d, 0, 32768)
+    return k, d.tobytes(), out
+
+
+def files_mode(nfiles, seed):
+    """files mode (zultra_hip_compress_files, BASELINE configuration 5): inputs of 1 .. 4096 bytes, one raw deflate stream each, in batches of 4096"""
+    t0 = time.time()
+    with mp.get_context("fork").Pool(min(64, os.cpu_count() or 1)) as pool:
+        refs = dict((r[0], r[1:]) for r in pool.imap_unordered(ref_file, [(seed, k) for k in range(nfiles)], chunksize=64))
+    import zultra_amd
+    L = zultra_amd.lib()
+    batch = 4096
+    ctx = L.files_context(4096, batch)
+    for b0 in range(0, nfiles, batch):
+        ks = list(range(b0, min(nfiles, b0 + batch)))
+        files = [np.frombuffer(refs[k][0], dtype=np.uint8) for k in ks]
+        sizes = [len(f) for f in files]
+        offs = np.cumsum([0] + sizes[:-1])
+        fo = ctx.compress_files(np.concatenate(files), offs, sizes)
+        stream = ctx.stream_read(int(fo[-1]))
+        for i, k in enumerate(ks):
+            got = stream[int(fo[i]):int(fo[i + 1])].tobytes()
+            if got != refs[k][1]:
+                print("DIFFERENT: files mode, seed %d file %d (%d bytes): %d bytes against the reference's %d" % (seed, k, sizes[i], len(got), len(refs[k][1])))
+                sys.exit(1)
+    ctx.close()
+    print("fuzz_gpu --files: %d inputs of 1 .. 4096 bytes (seed %d), every stream identical to the compiled reference's; %.1f s" % (nfiles, seed, time.time() - t0))
+
+
+def stream_mode(ncases, seed, max_bytes):
+    """the streaming API (zultra_stream_compress) fed in random chunks — 1 byte to a few hundred KB, now and then an empty one — against the
+    reference's one-shot output for the same input, flags and max-block size"""
+    t0 = time.time()
+    with mp.get_context("fork").Pool(min(64, os.cpu_count() or 1)) as pool:
+        refs = dict((r[0], r[1:]) for r in pool.imap_unordered(ref_one, [(seed, k, max_bytes) for k in range(ncases)], chunksize=2))
+    import zultra_amd
+    L = zultra_amd.lib()
+    total = 0
+    for k in range(ncases):
+        c, n, raw, flags, bs = refs[k]
+        d = np.frombuffer(raw, dtype=np.uint8)
+        rs = np.random.RandomState(seed * 31 + k)
+        st = L.stream(flags, bs)
+        out, pos = bytearray(), 0
+        while True:
+            m = int(rs.choice([0, 1, 7, 4096, 16384, 65536, 100000, 300000])) if rs.randint(0, 3) else int(rs.randint(1, 70000))
+            chunk = d[pos:pos + m]
+            pos += len(chunk)
+            last = pos >= len(d)
+            rc, o = st.compress(chunk, last, out_chunk=int(rs.choice([1 << 12, 1 << 16, 1 << 20])))
+            out += o
+            if last:
+                break
+        st.end()
+        total += len(d)
+        if len(out) != n or zlib.crc32(bytes(out)) != c:
+            print("DIFFERENT: streaming API, seed %d case %d: %d bytes, flags %d, max block %d: %d bytes against the reference's %d" % (seed, k, len(d), flags, bs, len(out), n))
+            sys.exit(1)
+    print("fuzz_gpu --stream: %d cases (seed %d), %.1f MB fed in random chunks, all byte-identical to the compiled reference; %.1f s" % (ncases, seed, total / 1e6, time.time() - t0))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--files":
+        return files_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 20000, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    if len(sys.argv) > 1 and sys.argv[1] == "--stream":
+        return stream_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 200, int(sys.argv[3]) if len(sys.argv) > 3 else 1, int(sys.argv[4]) if len(sys.argv) > 4 else 1_500_000)
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     max_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 3_000_000
