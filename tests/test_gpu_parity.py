@@ -74,6 +74,23 @@ def test_long_pieces_stay_on_the_quads(gpu, oracle, monkeypatch, case):
     check_window(gpu, oracle, gen(), prev, n, max_block=bs, tag=name + "/coop1536")
 
 
+def test_fuzz_stitched_inputs_vs_oracle(gpu, oracle):
+    """A short run of tools/fuzz_gpu.py's generator (inputs stitched together from the corpora: text, byte runs, near copies, tables, noise,
+    constant and periodic stretches, earlier pieces again), the three framings, 32 KiB / 64 KiB / 128 KiB / default max-blocks: every stream
+    equals the oracle's. (The soak run of that tool against the compiled reference is in profiles/r04_fuzz_gpu.txt.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gpu
+    total = 0
+    for k in range(25):
+        d, flags, bs = fuzz_gpu.make_case(77, k, 400000)
+        got = gpu.memory_compress(d, flags, bs)
+        assert got == oracle.memory_compress(d, flags, bs), (k, len(d), flags, bs)
+        total += len(d)
+    assert total > 500_000
+
+
 def test_settled_subblocks_keep_their_parse(gpu, oracle):
     """Sub-blocks whose code lengths have reached a fixed point of the reference's four-pass loop (blockdeflate.c:874-901) are not parsed
     again (zh_sb_build_one, st->settled): whole-block chains of a constant byte settle after the first pass, noise after the second, and in
