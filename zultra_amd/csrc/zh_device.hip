@@ -882,9 +882,10 @@ static int zh_enqueue_tokenize(zultra_hip_ctx_t *c, hipStream_t st, const zh_blo
    uint32_t *tp = c->d_tok_pos + (uint64_t)b0 * c->tok_stride;
    uint16_t *ti = c->d_tok_info + (uint64_t)b0 * c->tok_stride;
    uint32_t *cmax = c->d_chunkmax + (uint64_t)b0 * cpb, *sstart = c->d_spanstart + (uint64_t)b0 * cpb, *scnt = c->d_spancnt + (uint64_t)b0 * cpb;
-   ZH_LAUNCH(zh_barriers, nb * cpb, 64, st, blk, match, c->match_stride, bars, c->bar_stride, cmax, cpb);
+   uint32_t *slot0 = c->d_best + (uint64_t)b0 * c->best_stride;   // (free until the run's first parse pass: zh_split.h)
+   ZH_LAUNCH(zh_barriers, nb * cpb, 64, st, blk, match, c->match_stride, bars, c->bar_stride, cmax, cpb, slot0, c->best_stride);
    if (cpb > 1) ZH_LAUNCH(zh_barriers_fix, (nb + 63) / 64, 64, st, blk, nb, bars, c->bar_stride, (const uint32_t *)cmax, cpb);
-   ZH_LAUNCH(zh_tokenize_spans, nb * cpb, 64, st, c->cur_data, blk, match, c->match_stride, tp, ti, c->tok_stride, (const uint64_t *)bars, c->bar_stride, sstart, scnt,
+   ZH_LAUNCH(zh_tokenize_spans, nb * cpb, 64, st, c->cur_data, blk, (const uint32_t *)slot0, c->best_stride, tp, ti, c->tok_stride, (const uint64_t *)bars, c->bar_stride, sstart, scnt,
              cpb);
    ZH_LAUNCH(zh_tokens_compact, nb, ZH_COMPACT_THREADS, st, blk, tp, ti, c->tok_stride, (const uint32_t *)sstart, (const uint32_t *)scnt, cpb, c->d_ntok + b0);
    return 0;

@@ -67,7 +67,10 @@ __device__ inline uint32_t zh_first_barrier(const uint64_t *bar, uint32_t r, uin
 
 __global__ void __launch_bounds__(64)
 zh_barriers(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ longest, uint64_t longest_stride, uint64_t *bars, uint64_t bar_stride,
-            uint32_t *chunkmax, uint32_t cpb) {
+            uint32_t *chunkmax, uint32_t cpb, uint32_t *slot0, uint64_t slot0_stride /* slot 0 of every row once more, 4 bytes per block position and
+            dense: this kernel reads the rows in position order — a word out of every 16 bytes — and is the one place where that copy can be
+            written coalesced (the frontier owns entries of the order: its stores to such a plane scattered); zh_tokenize_spans and
+            zh_list_huge read it instead of the rows. It lives in the parse-entry array, which nothing else touches before the first parse pass */) {
    const uint32_t b = blockIdx.x / cpb, c = blockIdx.x - b * cpb;
    const zh_block_t blk = blocks[b];
    const uint32_t n = blk.n, lo = c * ZH_TOK_CHUNK;
@@ -90,6 +93,7 @@ zh_barriers(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ 
          if (base >= hi) break;
          const uint32_t r = base + lane;
          const uint32_t len = pm[u] & 0xffffu;
+         if (r < hi) slot0[(uint64_t)b * slot0_stride + r] = pm[u];
          pm[u] = r + 256 < hi ? rows[4u * (r + 256)] : 0u;
          const uint32_t incl = zh_wave_incl_max(r < hi ? r + max(len, 1u) : 0u);
          const uint32_t up = zh_wave_shr1(incl, 0u);   // (lane 0's is not used)
@@ -139,7 +143,7 @@ zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict
       return;
    }
    const uint8_t *win = data + blk.win_off;
-   const uint32_t *rows = longest + (uint64_t)b * longest_stride;
+   const uint32_t *rows = longest + (uint64_t)b * longest_stride;   // (the dense copy of slot 0 written by zh_barriers: one word per block position)
    uint32_t *tp = tok_pos + (uint64_t)b * tok_stride + s0;    // staged at the span's position offset (tokens <= positions)
    uint16_t *ti = tok_info + (uint64_t)b * tok_stride + s0;
    uint32_t ntok = 0, carry = 0;
@@ -150,7 +154,7 @@ zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict
       pm[u] = 0;
       pb[u] = 0;
       if (r < s1) {
-         pm[u] = rows[4u * r];
+         pm[u] = rows[r];
          pb[u] = win[blk.prev + r];
       }
    }
@@ -165,7 +169,7 @@ zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict
          pm[u] = 0;
          pb[u] = 0;
          if (r + 256 < s1) {
-            pm[u] = rows[4u * (r + 256)];
+            pm[u] = rows[r + 256];
             pb[u] = win[blk.prev + r + 256];
          }
          const uint32_t len = m0 & 0xffffu;
