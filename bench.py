@@ -773,7 +773,7 @@ def prepare_config5(args, rank, world):
 
 
 def run_config5(args, env, prep):
-    """1 000 000 x 4 KiB JSON-like inputs per GPU, each its own gzip stream: files mode, one hipGraph replay per batch."""
+    """1 000 000 x 4 KiB JSON-like inputs per GPU, each its own gzip stream: files mode, captured hipGraphs replayed per batch (one, or two per run of inputs)."""
     L, torch, dist, device, rank, world = env["L"], env["torch"], env["dist"], env["device"], env["rank"], env["world"]
     size, nfiles, batch = 4096, args.files, args.batch
     host, cb, digest, ncpu = prep["host"], prep["cb"], prep["digest"], prep["ncpu"]
@@ -843,7 +843,8 @@ def run_config5(args, env, prep):
         line = {"metric": "files/s, 4 KiB JSON-like inputs, one gzip stream each, bit-exact vs CPU zultra", "value": round(world * nfiles / (dt / args.steps), 1),
                 "unit": "files/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
-                "config": {"workload": "config 5: %d x %d B JSON-like inputs per GPU (tests/gen/zgen.c), each its own gzip stream, batches of %d inputs, one hipGraph replay + one stitch launch per batch" % (nfiles, size, batch)},
+                "config": {"workload": "config 5: %d x %d B JSON-like inputs per GPU (tests/gen/zgen.c), each its own gzip stream, batches of %d inputs, %s + one stitch launch per batch" % (
+                    nfiles, size, batch, "one hipGraph replay" if ctx.stats()["runs"] <= 1 else "%d staggered runs of inputs, each two captured hipGraphs replayed" % ctx.stats()["runs"])},
                 "rccl_ranks_seen": env["ranks_seen"], "input_MBps": round(world * nfiles * size / (dt / args.steps) / 1e6, 2),
                 "ratio": round(out_bytes / (nfiles * size), 4), "graph_ms_per_batch": round(avg_graph, 3), "stitch_ms_per_batch": round(avg_stitch, 3),
                 "gzip_roundtrip_ok_first_files": bool(ok),

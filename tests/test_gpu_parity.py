@@ -310,6 +310,30 @@ def test_files_mode_graph_replay_vs_oracle(gpu, oracle, monkeypatch, runs):
         ctx.close()
 
 
+def test_files_mode_large_batches_are_two_runs_of_graphs(gpu, oracle):
+    """A files batch of 8192 inputs or more runs as two staggered runs, each replayed from two captured graphs (zh_run_files); two sets of
+    graphs are kept, so a caller's full batches and its last, shorter one alternate without re-capturing. Three batches — full, short,
+    full with other contents: every stream inflates to its input, every 40th equals the oracle's."""
+    ctx = gpu.files_context(2048, 9000)
+    try:
+        for batch, nfiles in enumerate((9000, 8500, 9000)):
+            rs = np.random.RandomState(70 + batch)
+            sizes = [int(x) for x in rs.randint(1, 1500, size=nfiles)]
+            blob = corpus.json_like(sum(sizes) + 16, 900 + batch)
+            offs = np.cumsum([0] + sizes[:-1])
+            fo = ctx.compress_files(blob, offs, sizes)
+            assert ctx.stats()["runs"] == 2
+            stream = ctx.stream_read(int(fo[-1]))
+            for k in range(nfiles):
+                got = stream[int(fo[k]):int(fo[k + 1])].tobytes()
+                want = blob[int(offs[k]):int(offs[k]) + sizes[k]]
+                assert zlib.decompress(got, -15) == want.tobytes(), (batch, k)
+                if k % 40 == 0:
+                    assert got == oracle.memory_compress(want, 0, 32768), (batch, k)
+    finally:
+        ctx.close()
+
+
 def _edge_inputs():
     """Every size 1..160 and a spread of larger ones, over alphabets of 1, 2, 3 and 5 symbols and a run-heavy mix: window
     ends, the last five positions of a window (which the 6-gram order does not hold), byte runs of every residue, and

@@ -3,7 +3,7 @@
 noise, constant and periodic stretches, JSON, the mixed stream), random sizes from 1 byte to a few MB, the three framings, 32 KiB / 64 KiB /
 default max-blocks — the product library's zultra_memory_compress against the compiled reference (oracle/_ref, built here and carried over by
 gpurun) byte for byte. The reference outputs come from a pool of processes started BEFORE this process touches the GPU.
-usage: python tools/fuzz_gpu.py [cases] [seed] [max bytes per case] | --files [inputs] [seed] | --stream [cases] [seed] [max bytes]     exit code 1 on the first difference (the case is written to
+usage: python tools/fuzz_gpu.py [cases] [seed] [max bytes per case] | --files [inputs] [seed] [batch] | --stream [cases] [seed] [max bytes]     exit code 1 on the first difference (the case is written to
 gpurun_out/fuzz_fail_<seed>_<case>.bin)"""
 import multiprocessing as mp
 import os
@@ -92,14 +92,13 @@ def ref_file(args):
     return k, d.tobytes(), out
 
 
-def files_mode(nfiles, seed):
+def files_mode(nfiles, seed, batch=4096):
     """files mode (zultra_hip_compress_files, BASELINE configuration 5): inputs of 1 .. 4096 bytes, one raw deflate stream each, in batches of 4096"""
     t0 = time.time()
     with mp.get_context("fork").Pool(min(64, os.cpu_count() or 1)) as pool:
         refs = dict((r[0], r[1:]) for r in pool.imap_unordered(ref_file, [(seed, k) for k in range(nfiles)], chunksize=64))
     import zultra_amd
     L = zultra_amd.lib()
-    batch = 4096
     ctx = L.files_context(4096, batch)
     for b0 in range(0, nfiles, batch):
         ks = list(range(b0, min(nfiles, b0 + batch)))
@@ -114,7 +113,7 @@ def files_mode(nfiles, seed):
                 print("DIFFERENT: files mode, seed %d file %d (%d bytes): %d bytes against the reference's %d" % (seed, k, sizes[i], len(got), len(refs[k][1])))
                 sys.exit(1)
     ctx.close()
-    print("fuzz_gpu --files: %d inputs of 1 .. 4096 bytes (seed %d), every stream identical to the compiled reference's; %.1f s" % (nfiles, seed, time.time() - t0))
+    print("fuzz_gpu --files: %d inputs of 1 .. 4096 bytes (seed %d) in batches of %d, every stream identical to the compiled reference's; %.1f s" % (nfiles, seed, batch, time.time() - t0))
 
 
 def stream_mode(ncases, seed, max_bytes):
@@ -151,7 +150,7 @@ def stream_mode(ncases, seed, max_bytes):
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--files":
-        return files_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 20000, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+        return files_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 20000, int(sys.argv[3]) if len(sys.argv) > 3 else 1, int(sys.argv[4]) if len(sys.argv) > 4 else 4096)
     if len(sys.argv) > 1 and sys.argv[1] == "--stream":
         return stream_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 200, int(sys.argv[3]) if len(sys.argv) > 3 else 1, int(sys.argv[4]) if len(sys.argv) > 4 else 1_500_000)
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 400

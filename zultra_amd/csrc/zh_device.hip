@@ -137,6 +137,19 @@ struct zultra_hip_ctx_s {
    uint32_t max_subs;           // sub-blocks a max-block can have: 64, or 1 in files mode
    hipGraph_t graph;
    hipGraphExec_t graph_exec;
+   // files mode as several runs: two graphs per run — up to the end of its first matchfinder kernel, and the rest — captured on the run's own stream
+   // (zh_run_files). Two sets are kept: a caller's batches are all of one size except the last (1 000 000 inputs in batches of 65 536), and capturing
+   // a set costs several milliseconds.
+   struct zh_run_graphs_t {
+      hipGraph_t graph[2 * ZH_MAX_RUNS];
+      hipGraphExec_t exec[2 * ZH_MAX_RUNS];
+      uint32_t nblocks;
+      int runs;
+      const uint8_t *data;
+      uint64_t used;   // (tick of the last launch: the older set is the one replaced)
+   } rg[2];
+   uint64_t rg_tick;
+   int files_run_graphs;                       // ZULTRA_HIP_FILES_RUN_GRAPHS (default 1): 0 = several runs are launched kernel by kernel, and large batches stay one run
    uint32_t graph_nblocks;
    int graph_runs;
    const uint8_t *graph_data;
@@ -503,6 +516,11 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
       if (c->loop_stream[k]) (void)hipStreamDestroy(c->loop_stream[k]);
    }
    if (c->ev_input) (void)hipEventDestroy(c->ev_input);
+   for (int i = 0; i < 2; i++)
+      for (int k = 0; k < 2 * ZH_MAX_RUNS; k++) {
+         if (c->rg[i].exec[k]) (void)hipGraphExecDestroy(c->rg[i].exec[k]);
+         if (c->rg[i].graph[k]) (void)hipGraphDestroy(c->rg[i].graph[k]);
+      }
    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
    if (c->graph) (void)hipGraphDestroy(c->graph);
    for (int k = 0; k < 2; k++)
@@ -570,6 +588,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->cut_len = cl ? (uint32_t)atoi(cl) : (uint32_t)ZH_CUT_LEN;
       if (c->cut_len < ZH_CUT_WARM) c->cut_len = ZH_CUT_WARM;
       if (c->cut_len > ZH_CUT_LEN) c->cut_len = ZH_CUT_LEN;   // (the buffers are sized for ZH_CUT_WARM, the smallest)
+      const char *frg = getenv("ZULTRA_HIP_FILES_RUN_GRAPHS");
+      c->files_run_graphs = frg ? atoi(frg) : 1;
       const char *dm = getenv("ZULTRA_HIP_DEMOTE");
       c->demote_min = dm ? (uint32_t)atoi(dm) : 2u;
       const char *cs = getenv("ZULTRA_HIP_COOP_SMALL");
@@ -904,7 +924,9 @@ __global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, 
 // The kernel sequence of one run (inputs b0 .. b0 + nb) of a files-mode batch, with no host decision in it: run k on stream st,
 // its chains on `side`. Per-block buffers are addressed as base + block * stride, so a run sees the base pointers advanced to its
 // first input; sub-block indices are local to the run (zh_run_files shifts the descriptors).
-static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, hipStream_t st, hipStream_t side) {
+// part: 0 the whole run; 1 only up to the end of its first matchfinder kernel (where the next run's matchfinder may start), 2 only what follows —
+// the two halves of a run captured as graphs of their own (zh_run_files)
+static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, hipStream_t st, hipStream_t side, int part = 0) {
    const zh_block_t *blk = c->d_blocks + b0;
    const uint32_t mf_grid = min(nb, c->num_cus);   // persistent workgroups, one per CU (zh_matchfinder.h)
    const uint64_t tasks_per_block = c->max_tasks / c->max_blocks;
@@ -923,12 +945,15 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
    const uint64_t *bars = c->d_bars + (uint64_t)b0 * c->bar_stride;
    const zh_match_t *match = c->d_match + (uint64_t)b0 * c->match_stride;
    // (counters, payload slots and the copies of the results are the caller's, on the stream the runs fork from: zh_enqueue_files)
+   if (part != 2) {
    ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), sa, sb, p3, rn, c->sort_stride, c->run_stride, 0, nb,
              ctr + (size_t)nb * 2 + 1, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride, c->mf_lds_cap);
    if (c->mf_lds_cap && c->seg_W > ZH_MFL_MAXCAP)   // (inputs of <= 4 KiB are one chunk of zh_mf_group: nothing is ever noted)
       ZH_LAUNCH_LDS(zh_mf_group_big, min(mf_grid, 32u), ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), sa, sb, p3, (const uint32_t *)rn, c->sort_stride,
                     c->run_stride, nb, ctr + (size_t)nb * 2 + 2, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride);
-   ZH_CHECK(c, hipEventRecord(c->lane_ev[k][2], st));   // the next run's matchfinder starts here
+   }
+   if (part == 1) return 0;
+   if (part == 0) ZH_CHECK(c, hipEventRecord(c->lane_ev[k][2], st));   // the next run's matchfinder starts here (part 2: the caller records it between the two graphs)
    // (segment descriptors carry batch-wide input indices: the rows go to d_match + input * match_stride)
    ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), (const uint32_t *)sa, (const uint2 *)p3,
              (const uint32_t *)rn, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, ctr, nb, 0u);   // small inputs: nothing worth sharing
@@ -1013,11 +1038,74 @@ static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
    {
       // one run — the captured graph — unless ZULTRA_HIP_STREAMS asks for more (down to four inputs per run). Measured, 1 M inputs of
       // 4 KiB in batches of 65 536: 621 k files/s as one run, 582 / 634 / 637 k as 2 / 3 / 4 runs: not worth leaving the graph for.
-      const uint64_t want = c->auto_runs ? 1u : min((uint64_t)c->nlanes, (uint64_t)nblocks / 4u);
+      // End of round 4: with a graph per run (below) a large batch is two runs — the second run's matchfinder fills the ~12 ms the first
+      // spends in its last code build, literalisation and emission: 1 080 k -> 1 167 k files/s.
+      const uint64_t want = c->auto_runs ? ((c->files_run_graphs && nblocks >= 8192u && c->nlanes >= 2) ? 2u : 1u) : min((uint64_t)c->nlanes, (uint64_t)nblocks / 4u);
       c->last_runs = (int)max((uint64_t)1, want);
    }
 #ifndef ZH_EMU
-   if (c->last_runs > 1) {
+   if (c->last_runs > 1 && c->files_run_graphs) {
+      // Several runs, each a captured graph of its own on its own stream (the capture of ONE stream that forks into the runs' streams is what
+      // crashes next to torch's runtime; a run's capture only forks to its chain stream, like the single graph's). What the runs share — clearing
+      // the counters and the payload slots before, the copies of the results after — is launched around them. A run is TWO graphs, cut behind its
+      // first matchfinder kernel: the event the next run's matchfinder waits for (the stagger of DESIGN.md 3.6) is recorded between them, by
+      // the stream — without it the runs march in step, parse on parse, and two runs are no faster than one.
+      const int runs = c->last_runs;
+      zultra_hip_ctx_s::zh_run_graphs_t *G = NULL;
+      for (int i = 0; i < 2; i++)
+         if (c->rg[i].nblocks == nblocks && c->rg[i].data == c->cur_data && c->rg[i].runs == runs) G = &c->rg[i];
+      if (!G) {
+         G = c->rg[0].used <= c->rg[1].used ? &c->rg[0] : &c->rg[1];
+         for (int k = 0; k < 2 * ZH_MAX_RUNS; k++) {
+            if (G->exec[k]) (void)hipGraphExecDestroy(G->exec[k]);
+            if (G->graph[k]) (void)hipGraphDestroy(G->graph[k]);
+            G->exec[k] = NULL;
+            G->graph[k] = NULL;
+         }
+         G->nblocks = 0;
+         ZH_CHECK(c, hipStreamSynchronize(st));   // the input upload is not part of the graphs
+         for (int k = 0; k < runs; k++) {
+            hipStream_t sk = c->lane_stream[k];
+            const uint32_t b0 = zh_files_run_lo(c, nblocks, k), b1 = zh_files_run_lo(c, nblocks, k + 1);
+            ZH_CHECK(c, hipStreamSynchronize(sk));
+            for (int part = 1; part <= 2; part++) {
+               const int g = 2 * k + part - 1;
+               ZH_CHECK(c, hipStreamBeginCapture(sk, hipStreamCaptureModeThreadLocal));
+               const int rc = zh_enqueue_files_run(c, k, b0, b1 - b0, sk, c->side_stream[k], part);
+               const hipError_t e = hipStreamEndCapture(sk, &G->graph[g]);
+               if (rc != 0) return -1;
+               ZH_CHECK(c, e);
+               ZH_CHECK(c, hipGraphInstantiate(&G->exec[g], G->graph[g], NULL, NULL, 0));
+            }
+         }
+         G->nblocks = nblocks;
+         G->data = c->cur_data;
+         G->runs = runs;
+      }
+      G->used = ++c->rg_tick;
+      ZH_CHECK(c, hipEventRecord(c->lane_ev[0][1], st));
+      ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr, 0, ((size_t)nblocks * 2 + 3 * (size_t)runs) * sizeof(uint32_t), st));
+      ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, ZH_NCNT * sizeof(uint32_t), st));
+      ZH_CHECK(c, hipMemsetAsync(c->d_payload, 0, (size_t)nblocks * c->slot_stride, st));
+      ZH_CHECK(c, hipEventRecord(c->ev2[1], st));
+      for (int k = 0; k < runs; k++) {
+         hipStream_t sk = c->lane_stream[k];
+         if (k) {
+            ZH_CHECK(c, hipStreamWaitEvent(sk, c->ev2[1], 0));
+            if (c->stagger_ev) ZH_CHECK(c, hipStreamWaitEvent(sk, c->lane_ev[k - 1][2], 0));   // behind the previous run's first matchfinder kernel
+         }
+         ZH_CHECK(c, hipGraphLaunch(G->exec[2 * k], sk));
+         ZH_CHECK(c, hipEventRecord(c->lane_ev[k][2], sk));
+         ZH_CHECK(c, hipGraphLaunch(G->exec[2 * k + 1], sk));
+         if (k) ZH_CHECK(c, hipEventRecord(c->lane_ev[k][17], sk));
+      }
+      for (int k = 1; k < runs; k++) ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k][17], 0));
+      ZH_CHECK(c, hipMemcpyAsync(c->h_adler, c->d_adler, 2 * (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results, (size_t)nblocks * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks, c->d_ntasks, ZH_NCNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+   }
+   else if (c->last_runs > 1) {
       // Several runs: launched directly, ~35 launches per run and batch. (Forking the runs' streams inside a stream capture crashes in
       // hipStreamEndCapture when another HIP runtime — torch's — lives in the process; the launches of a batch are 0.5 ms of host time.)
       ZH_CHECK(c, hipEventRecord(c->lane_ev[0][1], st));
