@@ -149,6 +149,7 @@ struct zultra_hip_ctx_s {
       uint64_t used;   // (tick of the last launch: the older set is the one replaced)
    } rg[2];
    uint64_t rg_tick;
+   uint32_t files_chain_grid;                  // files mode: workgroups of zh_parse_chain per run and pass (ZULTRA_HIP_FILES_CHAIN_GRID; the count of chain tasks is not known to the host: the graph is fixed)
    int files_run_graphs;                       // ZULTRA_HIP_FILES_RUN_GRAPHS (default 1): 0 = several runs are launched kernel by kernel, and large batches stay one run
    uint32_t graph_nblocks;
    int graph_runs;
@@ -588,6 +589,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->cut_len = cl ? (uint32_t)atoi(cl) : (uint32_t)ZH_CUT_LEN;
       if (c->cut_len < ZH_CUT_WARM) c->cut_len = ZH_CUT_WARM;
       if (c->cut_len > ZH_CUT_LEN) c->cut_len = ZH_CUT_LEN;   // (the buffers are sized for ZH_CUT_WARM, the smallest)
+      const char *fcg = getenv("ZULTRA_HIP_FILES_CHAIN_GRID");
+      c->files_chain_grid = fcg ? (uint32_t)max(1, min((int)ZH_CHAIN_GRID, atoi(fcg))) : (uint32_t)ZH_CHAIN_GRID;
       const char *frg = getenv("ZULTRA_HIP_FILES_RUN_GRAPHS");
       c->files_run_graphs = frg ? atoi(frg) : 1;
       const char *dm = getenv("ZULTRA_HIP_DEMOTE");
@@ -980,7 +983,7 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
       // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
       ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
-      ZH_LAUNCH(zh_parse_chain, min(nb, (uint32_t)ZH_CHAIN_GRID), ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
+      ZH_LAUNCH(zh_parse_chain, min(nb, c->files_chain_grid), ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
                 (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, c->d_segtasks, (const uint2 *)c->d_segitems, c->d_vecs, 0u, 0u, cnt, (const zh_sbstate_t *)states, best,
                 c->best_stride, hist_part, pass, cnt + ZH_CNT_CHAIN_TICKET + pass, (uint64_t *)NULL);
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
