@@ -273,6 +273,39 @@ def cpu_baseline_stream(sample, flags, bs, what):
                 what, len(sample), flags, bs, runs, label)}, out
 
 
+def _reference_check_worker(conn, data, flags, bs):
+    """Child process (forked before the parent touches a GPU): the CPU reference over `data` in ONE call — the stream's bit phases carry from
+    max-block to max-block, so a byte-for-byte comparison needs the whole stream — reported as (length, sha-256, seconds)."""
+    try:
+        impl, kind, label = cpu_impl()
+        t0 = time.perf_counter()
+        out = impl.memory_compress(data, flags, bs)
+        conn.send((len(out), hashlib.sha256(out).hexdigest(), time.perf_counter() - t0, kind))
+    except Exception as e:   # noqa: BLE001 (reported by the parent)
+        conn.send((-1, repr(e), 0.0, "error"))
+    conn.close()
+
+
+def start_reference_check(data, flags, bs):
+    """Starts the CPU reference on ALL of `data` in the background (one host core; the GPU legs run meanwhile). -> handle for finish_reference_check."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    recv, send = ctx.Pipe(False)
+    p = ctx.Process(target=_reference_check_worker, args=(send, data, flags, bs), daemon=True)
+    p.start()
+    send.close()
+    return {"proc": p, "recv": recv, "bytes": len(data)}
+
+
+def finish_reference_check(handle, gpu_stream_bytes):
+    """-> fields for the JSON line: is the GPU's stream over the same bytes identical to the reference's, in full."""
+    n, digest, secs, kind = handle["recv"].recv()
+    handle["proc"].join()
+    same = n == len(gpu_stream_bytes) and digest == hashlib.sha256(gpu_stream_bytes).hexdigest()
+    return {"bit_exact_vs_reference_full": bool(same), "bit_exact_checked_input_bytes": handle["bytes"], "bit_exact_stream_bytes": int(n), "bit_exact_checker": kind,
+            "reference_seconds_one_core": round(secs, 1)}, bool(same)
+
+
 def _files_worker(job):
     data, size, flags = job
     impl, _, _ = cpu_impl()
@@ -283,22 +316,25 @@ def _files_worker(job):
     return time.perf_counter() - t0, h.hexdigest()
 
 
-def cpu_baseline_files(sample, size, flags):
-    """Config 5: the reference on a bounded sample of files — one thread, then nproc processes over file shards (independent
-    inputs: still the reference's exact output). Must run before this process initialises the GPU (it forks)."""
+def cpu_baseline_files(sample, size, flags, ntimed):
+    """Config 5: the reference over a bounded sample of files — one thread on the first `ntimed` of them (the baseline's value), then nproc processes over
+    shards of ALL the sample's files (independent inputs: still the reference's exact output; the all-cores rate, and the digests the GPU's streams are
+    compared with). Must run before this process initialises the GPU (it forks). -> (cpu_baseline object, [digest per shard], files per shard)"""
     import multiprocessing as mp
     _, kind, label = cpu_impl()
     nfiles = len(sample) // size
-    t1, digest = _files_worker((sample, size, flags))
+    ntimed = min(ntimed, nfiles)
+    t1, _ = _files_worker((sample[: ntimed * size], size, flags))
     nproc = os.cpu_count() or 1
     per = (nfiles + nproc - 1) // nproc
     jobs = [(sample[i * per * size:min(nfiles, (i + 1) * per) * size], size, flags) for i in range(nproc) if i * per < nfiles]
     with mp.get_context("fork").Pool(len(jobs)) as pool:
-        tn = max(t for t, _ in pool.map(_files_worker, jobs))   # the slowest worker's own clock: process start-up is not compression time
-    return {"value": round(nfiles / t1, 1), "unit": "files/s", "cores": 1, "kind": kind, "nproc": nproc, "cpu_model": cpu_model(),
+        res = pool.map(_files_worker, jobs)
+    tn = max(t for t, _ in res)   # the slowest worker's own clock: process start-up is not compression time
+    return {"value": round(ntimed / t1, 1), "unit": "files/s", "cores": 1, "kind": kind, "nproc": nproc, "cpu_model": cpu_model(),
             "all_cores_value": round(nfiles / tn, 1), "all_cores_processes": len(jobs),
-            "sample": "first %d files of rank 0's shard, one zultra_memory_compress (gzip) per file, 1 thread; then %d processes over file shards; %s" % (
-                nfiles, len(jobs), label)}, digest
+            "sample": "first %d files of rank 0's shard, one zultra_memory_compress (gzip) per file, 1 thread; then %d processes over shards of its first %d files; %s" % (
+                ntimed, len(jobs), nfiles, label)}, [d for _, d in res], per
 
 
 def frame(L, flags, body, checksum, total_in):
@@ -328,41 +364,50 @@ def inflate_check(flags, framed, first_shard, total_in):
     return bool(ok and d.eof and got == total_in)
 
 
+def _csrc_digest():
+    import zultra_amd
+    return zultra_amd.csrc_digest()
+
+
 def committed_traffic(kernel, config):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this configuration (profiles/*_traffic_c<N>.json,
     or an older *_traffic.json that names the configuration; written by tools/pmc_traffic.py from separate --pmc FETCH_SIZE /
-    WRITE_SIZE runs of this same command), or None."""
+    WRITE_SIZE runs of this same command) -> (bytes or None, file name or None, stale): stale = the file was measured on other sources than the
+    ones in the tree now (its csrc_digest differs or is missing): the figure is quoted, but flagged."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic_c%s.json" % config)))
     if not files:
         files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))) if json.load(open(f)).get("config") == config]
     if not files:
-        return None, None
+        return None, None, None
     with open(files[-1]) as f:
         t = json.load(f)
+    stale = t.get("csrc_digest") != _csrc_digest()
     ks = t.get("kernels", {})
     k = ks.get(kernel) or ks.get(kernel.split("+")[0]) or ks.get(kernel.split("+")[-1])   # a timed group is priced by its main kernel
     if kernel.startswith("zh_parse") and "zh_parse_lanes" in ks:   # the parse group: its kernels run side by side
         tot = sum(ks[n]["hbm_bytes_per_launch"] * ks[n]["launches"] for n in ("zh_parse_lanes", "zh_parse_chain", "zh_parse_segments", "zh_parse_tasks") if n in ks)
-        return int(tot / max(1, ks["zh_parse_lanes"]["launches"])), os.path.basename(files[-1])
+        return int(tot / max(1, ks["zh_parse_lanes"]["launches"])), os.path.basename(files[-1]), stale
     if not k:
-        return None, os.path.basename(files[-1])
-    return int(k["hbm_bytes_per_launch"]), os.path.basename(files[-1])
+        return None, os.path.basename(files[-1]), stale
+    return int(k["hbm_bytes_per_launch"]), os.path.basename(files[-1]), stale
 
 
 def committed_sq(config, ms_per_step):
     """Issue and residency figures from the committed SQ-counter pass of this configuration (profiles/*_sq_c<N>.json, tools/sq_profile.py):
-    valu_issue_frac = the step's vector instructions x 2 cycles / (1024 SIMDs x the cycles of THIS run's step at 2.4 GHz), and the average
-    number of resident waves of every kernel while it ran. None when no pass is committed."""
+    valu_issue_frac = the PROFILED step's vector instructions x 2 cycles / (1024 SIMDs x the cycles of the PROFILED step at 2.4 GHz) — numerator and
+    denominator from the same pass — and the average number of resident waves of every kernel while it ran. `stale`: measured on other sources
+    than the tree's. None when no pass is committed."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_c%s.json" % config)))
     if not files:
         return None
     with open(files[-1]) as f:
         t = json.load(f)
     issue_ms = float(t.get("valu_issue_ms_per_step", 0.0))
-    return {"valu_issue_frac": round(issue_ms / ms_per_step, 4) if ms_per_step > 0 else None, "valu_issue_ms_per_step": issue_ms,
+    step_ms = float(t.get("step_ms_profiled", 0.0)) or ms_per_step   # (files of round 4 did not record their own step: this run's, flagged stale anyway)
+    return {"valu_issue_frac": round(issue_ms / step_ms, 4) if step_ms > 0 else None, "valu_issue_ms_per_step": issue_ms, "step_ms_profiled": t.get("step_ms_profiled"),
             "valu_insts_per_step": t.get("valu_insts_per_step"),
             "resident_waves_avg": {k: v.get("resident_waves_avg") for k, v in t.get("kernels", {}).items() if v.get("resident_waves_avg") is not None},
-            "source": os.path.basename(files[-1])}
+            "source": os.path.basename(files[-1]), "stale": bool(t.get("csrc_digest") != _csrc_digest())}
 
 
 class OneRank:   # N == 1: same code path without a process group
@@ -497,13 +542,15 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup, last_rank=None):
         alg_bytes = (n + out_bytes) / (runs if dom != "zh_stitch" else 1)
         launch_ms = kernels[dom] / launches[dom]
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_src = committed_traffic(dom, env.get("config"))
+        traffic, traffic_src, traffic_stale = committed_traffic(dom, env.get("config"))
         st = res["stats"]
         res.update({
             "body": body, "checksum": chk, "total_in": total_in, "ms_per_step": dt / steps * 1e3,
-            "MBps": total_in / (dt / steps) / 1e6, "kernel_ms": {k: round(v, 3) for k, v in kernels.items()},
+            "MBps": total_in / (dt / steps) / 1e6,
+            # HIP-event intervals on the library's streams, SUMMED over the batch's staggered runs: the runs overlap in wall time, so these add up to more
+            # than the step (each is the sum of a kernel group's launch durations, what the roofline's launch_ms divides)
+            "kernel_stream_interval_sums_ms": {k: round(v, 3) for k, v in kernels.items()},
             "device_pipeline_ms": round(avg["total_ms"], 3), "d2h_ms": round(avg["d2h_ms"], 3),
-            "kernel_only_MBps": round(n / (sum(kernels.values()) * 1e-3) / 1e6, 3),
             "sub_blocks_per_block": round(st["subblocks"] / max(1, st["blocks"]), 3),
             "parse_huge_share_of_positions": round(st["huge_positions"] / max(1, st["positions"]), 4),
             "parse_tasks": st["tasks"], "parse_huge_tasks": st["huge_tasks"],
@@ -513,7 +560,7 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup, last_rank=None):
             # 4 x positions of parse work that was not run
             "parse_settled_share": round(st["settled_kib"] * 1024 / max(1, 4 * st["positions"]), 4),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(launch_ms, 3),
                          "launches_per_step": launches[dom]},
         })
@@ -521,7 +568,7 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup, last_rank=None):
 
 
 def summarize_leg(r):
-    return {k: r[k] for k in ("ms_per_step", "kernel_ms", "device_pipeline_ms", "d2h_ms", "kernel_only_MBps", "sub_blocks_per_block",
+    return {k: r[k] for k in ("ms_per_step", "kernel_stream_interval_sums_ms", "device_pipeline_ms", "d2h_ms", "sub_blocks_per_block",
                               "parse_huge_share_of_positions", "parse_settled_share", "parse_tasks", "parse_huge_tasks", "chain_cut", "per_rank")}
 
 
@@ -554,12 +601,17 @@ def prepare_stream_config(args, rank, world):
             lead, shard = None, np.zeros(0, dtype=np.uint8)
     else:
         lead, shard = corp.shard(rank, size)
-    cb = ref_out = None
+    cb = ref_out = check = None
     sample = shard[: min(args.cpu_sample, len(shard))]
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.profile_run:
+        # what is checked against the reference, byte for byte: the WHOLE shard for configurations 2 and 3 (the stream the timed steps produce), the first
+        # 64 MiB of configuration 4's GiB (its reference run would take three minutes of one core) — in a child process, next to everything else; the
+        # reference's SPEED is taken on the first --cpu-sample bytes, best of three, with nothing else running
         cb, ref_out = cpu_baseline_stream(sample, flags, bs, corp.name)
+        nchk = len(shard) if (args.cpu_check == 0 and cfg != 4) else min(len(shard), args.cpu_check or (64 << 20))
+        check = start_reference_check(shard[:nchk], flags, bs)
     return dict(cfg=cfg, flags=flags, bs=bs, size=size, corp=corp, data_note=data_note, metric=metric, lead=lead, shard=shard, sample=sample, cb=cb,
-                ref_out=ref_out, last_rank=last_rank)
+                ref_out=ref_out, last_rank=last_rank, check=check)
 
 
 def run_stream_config(args, env, prep):
@@ -655,9 +707,12 @@ def run_stream_config(args, env, prep):
             line["readme_size_check"] = {"readme_bytes": readme, "raw_deflate_default_block_bytes": len(raw), "equal": bool(len(raw) == readme)}
         if cb is not None:
             line["cpu_baseline"] = cb
-            gpu_out = L.memory_compress(sample, flags, bs)
-            line["bit_exact_vs_cpu_on_sample"] = bool(gpu_out == ref_out)
-            failed |= gpu_out != ref_out
+            chk = prep["check"]
+            # the stream the timed steps produced when the check covers the whole shard; else the drop-in call on the checked prefix
+            gpu_stream = framed if chk["bytes"] == len(shard) else L.memory_compress(shard[: chk["bytes"]], flags, bs)
+            fields, same = finish_reference_check(chk, gpu_stream)
+            line.update(fields)
+            failed |= not same
         if cfg == 2 and not args.leg and not strong:
             # Not `value`: what a caller gets who keeps three jobs of this size in flight — a context and a host thread each, the same shard, the
             # same job (kernels, stitch, read-back into a pinned buffer of its own). One job at a time leaves the chip nearly idle for its last
@@ -766,10 +821,10 @@ def prepare_config5(args, rank, world):
     size, nfiles = 4096, args.files
     host = corpus.json_files(rank * nfiles, nfiles, size)
     cb = digest = None
-    ncpu = min(nfiles, args.cpu_files)
+    ncpu, per = min(nfiles, args.batch, args.cpu_check_files), 0   # files compared with the reference: inside the first device batch
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.profile_run:
-        cb, digest = cpu_baseline_files(host[: ncpu * size], size, 2)   # forks: must precede any GPU call of this process
-    return dict(host=host, cb=cb, digest=digest, ncpu=ncpu)
+        cb, digest, per = cpu_baseline_files(host[: ncpu * size], size, 2, args.cpu_files)   # forks: must precede any GPU call of this process
+    return dict(host=host, cb=cb, digest=digest, ncpu=ncpu, per=per)
 
 
 def run_config5(args, env, prep):
@@ -826,14 +881,15 @@ def run_config5(args, env, prep):
         fo, stream, crcs = keep["fo"], keep["stream"], keep["crcs"]
         k0 = min(batch, nfiles)
         hdr = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 2, 255])
-        h = hashlib.sha256()
+        per = prep["per"] or ncpu or 1
+        hs = [hashlib.sha256() for _ in range((ncpu + per - 1) // per)]   # one digest per shard of the reference's worker pool (cpu_baseline_files)
         ok = True
         for k in range(min(k0, max(ncpu, 2048))):
             raw = stream[int(fo[k]):int(fo[k + 1])].tobytes()
             gz = hdr + raw + int(L.crc32_append(0, crcs[k], size)).to_bytes(4, "little") + int(size).to_bytes(4, "little")
             if k < ncpu:
-                h.update(gz)
-            if zlib.decompress(gz, 31) != host[k * size:(k + 1) * size].tobytes():
+                hs[k // per].update(gz)
+            if k < 2048 and zlib.decompress(gz, 31) != host[k * size:(k + 1) * size].tobytes():
                 ok = False
         failed |= not ok
         avg_graph = float(np.mean([t["encode_ms"] for t in timings]))
@@ -849,14 +905,17 @@ def run_config5(args, env, prep):
                 "ratio": round(out_bytes / (nfiles * size), 4), "graph_ms_per_batch": round(avg_graph, 3), "stitch_ms_per_batch": round(avg_stitch, 3),
                 "gzip_roundtrip_ok_first_files": bool(ok),
                 "roofline": {"bound": "hbm", "kernel": "hipGraph of stages 1-3 (one replay per batch)", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": committed_traffic("graph", 5)[0], "traffic_source": committed_traffic("graph", 5)[1],
+                             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": committed_traffic("graph", 5)[0], "traffic_source": committed_traffic("graph", 5)[1], "traffic_stale": committed_traffic("graph", 5)[2],
                              "algorithmic_bytes_per_launch": int(in_b + out_b), "launch_ms": round(avg_graph, 3), "launches_per_step": nb}}
         if args.profile_run:
             L.traffic_probe(256 << 20)
         elif cb is not None:
             line["cpu_baseline"] = cb
-            line["bit_exact_vs_cpu_on_sample"] = bool(h.hexdigest() == digest)
-            failed |= h.hexdigest() != digest
+            same = [h.hexdigest() for h in hs] == digest
+            line["bit_exact_vs_reference_full"] = bool(same)   # every compared file's gzip stream, byte for byte
+            line["bit_exact_checked_files"] = ncpu
+            line["bit_exact_checker"] = cb["kind"]
+            failed |= not same
     ctx.close()
     return line, failed
 
@@ -865,7 +924,9 @@ def run_config5(args, env, prep):
 def run_other_configs(args):
     """The default run (configuration 2 on one GPU) also measures configurations 3, 4 and 5, bounded so that the whole command stays
     within a few minutes: each as a child process of its own (started before this process touches the GPU), its JSON line condensed."""
-    legs = {3: ["--cpu-sample", str(8 << 20)], 4: ["--cpu-sample", str(4 << 20)], 5: ["--files", "1000000", "--cpu-files", "2048"]}   # (the full configuration: ~20 s of the run)
+    # (each leg compares its stream with the CPU reference's in full — configuration 4: the first 64 MiB of its GiB, configuration 5: its first 65 536 files —
+    # and times the reference on a smaller sample: ~25 s each)
+    legs = {3: ["--cpu-sample", str(8 << 20)], 4: ["--cpu-sample", str(4 << 20)], 5: ["--files", "1000000", "--cpu-files", "2048"]}
     out = {}
     for cfg, extra in legs.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--gpus", "1", "--steps", "2", "--warmup", "1", "--leg"] + extra
@@ -880,8 +941,9 @@ def run_other_configs(args):
         if d is None:
             out[str(cfg)] = {"error": "no line (rc %s)" % rc, "wall_s": round(time.perf_counter() - t0, 1)}
             continue
-        keep = ("metric", "value", "unit", "ms_per_step", "kernel_ms", "issue", "graph_ms_per_batch", "input_MBps", "ratio", "size_vs_zlib9", "size_vs_zlib9_sample_bytes",
-                "inflate_roundtrip_ok", "gzip_roundtrip_ok_first_files", "bit_exact_vs_cpu_on_sample", "memory_compress_equals_sharded_pipeline", "end_to_end_MBps",
+        keep = ("metric", "value", "unit", "ms_per_step", "kernel_stream_interval_sums_ms", "issue", "graph_ms_per_batch", "input_MBps", "ratio", "size_vs_zlib9", "size_vs_zlib9_sample_bytes",
+                "inflate_roundtrip_ok", "gzip_roundtrip_ok_first_files", "bit_exact_vs_reference_full", "bit_exact_checked_input_bytes", "bit_exact_checked_files", "bit_exact_checker",
+                "memory_compress_equals_sharded_pipeline", "end_to_end_MBps",
                 "compressed_bytes_total", "sub_blocks_per_block", "parse_huge_share_of_positions", "parse_settled_share", "chain_cut", "readme_size_check")
         o = {k: d[k] for k in keep if k in d}
         o["workload"] = d["config"]["workload"]
@@ -909,8 +971,10 @@ def main():
     ap.add_argument("--block", type=int, default=0, help="nMaxBlockSize (default: the configuration's own)")
     ap.add_argument("--files", type=int, default=1_000_000, help="config 5: inputs per GPU")
     ap.add_argument("--batch", type=int, default=1 << 16, help="config 5: inputs per device batch")
-    ap.add_argument("--cpu-sample", type=int, default=32 << 20, help="bytes of the shard the CPU reference is timed on")
-    ap.add_argument("--cpu-files", type=int, default=4096, help="config 5: files the CPU reference is timed on")
+    ap.add_argument("--cpu-sample", type=int, default=32 << 20, help="bytes of the shard the CPU reference is TIMED on (one core, best of three)")
+    ap.add_argument("--cpu-check", type=int, default=0, help="bytes of the shard whose stream is COMPARED with the CPU reference's (0: all of it; configuration 4: 64 MiB)")
+    ap.add_argument("--cpu-files", type=int, default=4096, help="config 5: files the CPU reference is timed on (one core)")
+    ap.add_argument("--cpu-check-files", type=int, default=65536, help="config 5: files compared with the CPU reference (all host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-synthetic", action="store_true", help="config 2: skip the synthetic-text leg")
     ap.add_argument("--no-other-configs", action="store_true", help="default run (config 2, one GPU): skip the legs of configurations 3, 4 and 5")

@@ -168,14 +168,22 @@ size_t zultra_hip_stitch(zultra_hip_bitstate_t *state, const zultra_hip_subblock
 size_t zultra_hip_stitch_finish(zultra_hip_bitstate_t *state, uint8_t *out, size_t out_cap);
 
 /*
- * Stitcher (device): same result as zultra_hip_stitch for the last batch, but the phase-dependent decisions are planned
- * on the host from the 48-byte descriptors only and the bits are moved by a kernel; the stream stays in HBM.
+ * Stitcher (device): same result as zultra_hip_stitch for the last batch, with nothing on the host: a scan kernel takes the
+ * phase-dependent decisions of libzultra.c:327-398 from the 48-byte descriptors (a transfer table bit phase -> bits added
+ * per run of max-blocks, composed across the batch), a second kernel moves the bits; the stream stays in HBM.
  *   state->nacc : pending bits (0..7) before the batch; updated to the pending bits after it (state->acc is not used:
  *                 the caller ORs its pending bits into byte 0 of the result, and reads the new partial byte back).
  *   *end_bit    : bits from the start of byte 0 to the end of the batch; the buffer holds ceil(end_bit/8) bytes.
  * Returns 0, -2 where the reference fails with ZULTRA_ERROR_DST, -1 on HIP errors.
  */
 int zultra_hip_stitch_device(zultra_hip_ctx_t *ctx, zultra_hip_bitstate_t *state, int final_block, uint64_t *end_bit);
+/*
+ * Where the last batch would end for each of the eight bit phases it could start at (the same scan, nothing written):
+ * end_bits[p] counts from the start of the byte that holds the p pending bits; bit p of *failed_mask is set where the
+ * reference would fail with ZULTRA_ERROR_DST from that phase. What a device hands its neighbours when one stream
+ * (libzultra.c:601-619) is cut over several of them: a shard's bit length depends on the phase it starts at.
+ */
+int zultra_hip_stitch_phase_table(zultra_hip_ctx_t *ctx, uint64_t *end_bits /* 8 */, uint32_t *failed_mask);
 const void *zultra_hip_stream_device(const zultra_hip_ctx_t *ctx);
 int zultra_hip_stream_read(zultra_hip_ctx_t *ctx, void *out, size_t offset, size_t nbytes);
 

@@ -186,6 +186,51 @@ def test_multiblock_stream_bit_carry_and_stored_fallback(emu, oracle):
     assert zlib.decompress(got, 31) == d.tobytes()
 
 
+def _scan_vs_planner(lib):
+    """The device scan of the stitcher (zh_stitch_scan: transfer tables bit phase -> bits added, composed over the batch) against the serial
+    host planner (zh_stitch_plan, behind zultra_hip_stitch), at every one of the eight start phases: same bytes, same end bit, same new phase;
+    and the eight-entry phase table a rank hands its neighbours (zultra_hip_stitch_phase_table) = the eight end bits."""
+    import ctypes as C
+    bs = 32768
+    t = corpus.text_like(3 * bs, 11)
+    d = t.copy()
+    d[bs + 100: bs + 9000] = corpus.noise(8900, 1)        # a stored sub-block inside the second max-block
+    d[2 * bs: 2 * bs + 700] = corpus.noise(700, 2)        # ... at the head of the third
+    d = np.concatenate([d, corpus.noise(333, 3)])         # a short stored max-block at the end
+    nb = (len(d) + bs - 1) // bs
+    blocks = [(b * bs - (bs if b else 0), bs if b else 0, min(bs, len(d) - b * bs)) for b in range(nb)]
+    ctx = lib.context(bs, nb)
+    try:
+        ctx.compress_blocks(d, blocks)
+        subs, _, cnt = ctx.subblocks()
+        assert cnt > nb   # the splitter cut at least one max-block
+        offs = [b * bs for b in range(nb)]
+        ends = (C.c_uint64 * 8)()
+        failed = C.c_uint32(7)
+        lib.L.zultra_hip_stitch_phase_table.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+        assert lib.L.zultra_hip_stitch_phase_table(ctx.h, ends, C.byref(failed)) == 0 and failed.value == 0
+        stored = set()
+        for ph in range(8):
+            from zultra_amd._ffi import BitState
+            want, st = ctx.stitch(d, offs, bs, nb - 1, state=BitState(0, ph), finish=False)
+            end_bit, nacc = ctx.stitch_device(nb - 1, phase=ph)
+            assert nacc == st.nacc and (end_bit + 7) // 8 == len(want) + (1 if st.nacc else 0), (ph, end_bit, len(want), st.nacc)
+            got = ctx.stream_read((end_bit + 7) // 8)
+            full = len(want)
+            assert got[:full].tobytes() == want[:full], "phase %d" % ph
+            if st.nacc:
+                assert int(got[full]) == st.acc & 0xff, "phase %d partial byte" % ph
+            assert int(ends[ph]) == end_bit, (ph, int(ends[ph]), end_bit)
+            stored.add(end_bit - ph)
+        assert len(stored) > 1   # the shard's bit length does depend on the phase it starts at (stored sub-blocks pad to a byte)
+    finally:
+        ctx.close()
+
+
+def test_device_scan_equals_the_host_planner_at_every_phase(emu):
+    _scan_vs_planner(emu)
+
+
 def test_dictionary_stream(emu, oracle):
     t = corpus.text_like(12000, 8)
     got = emu.memory_compress(t[4000:], 1, 32768, t[:4000])

@@ -211,15 +211,24 @@ def test_streaming_api_chunking(gpu, oracle):
         assert bytes(out) == want
 
 
-def test_sub_blocks_on_their_own(gpu, oracle, monkeypatch):
-    """ZULTRA_HIP_PARSE_LOOP=1: the sub-blocks without a chain task are taken through their four parse passes by a workgroup of their
-    own (zh_parse_own, zh_parse_loop.h) while those with chains go pass by pass — off by default (it is slower on the 100 MB step), same
-    bytes: text that splits, and near-copies whose sub-blocks have chains."""
-    monkeypatch.setenv("ZULTRA_HIP_PARSE_LOOP", "1")
-    check_window(gpu, oracle, corpus.text_like(60000, 21), 0, 60000, max_block=65536, tag="own/text")
-    check_window(gpu, oracle, corpus.duplicated(50000, 3, 1500), 2000, 48000, max_block=65536, tag="own/near_copies")
-    d = np.concatenate([corpus.text_like(300000, 4), corpus.duplicated(200000, 5, 3000), corpus.noise(40000, 2), corpus.indented(200000, 6)])
-    assert gpu.memory_compress(d, 2, 65536) == oracle.memory_compress(d, 2, 65536)
+def test_device_scan_equals_the_host_planner_at_every_phase(gpu):
+    """The stitcher's device scan (zh_stitch_scan) against the serial host planner at all eight start phases, and the phase table a rank
+    hands its neighbours: the emulator suite's check (test_emu_parity._scan_vs_planner) on the real kernels."""
+    from test_emu_parity import _scan_vs_planner
+    _scan_vs_planner(gpu)
+
+
+def test_a_run_needs_no_host_decision(gpu, oracle):
+    """Sub-block counts, task counts, chains and cut tasks are summed up on the device (zh_plan_subblocks, zh_list_huge) and every later kernel takes
+    its bounds from the run's counters; the host sizes grids from the input bytes alone. A batch whose max-blocks split very unevenly — one max-block of
+    forty short stretches of different statistics next to max-blocks that do not split at all — over one, two and three runs: the bytes are the oracle's."""
+    parts = [corpus.text_like(65536, 3)]
+    rng = np.random.default_rng(5)
+    many = np.concatenate([corpus.selftest_data(1600, 100 + k, int(rng.integers(2, 200)), float(rng.uniform(0.0, 0.9))) for k in range(41)])[:65536]
+    parts += [many, corpus.constant(65536, 7), corpus.duplicated(65536, 4, 900), corpus.noise(65536, 9), corpus.indented(65536, 2)] * 2
+    d = np.concatenate(parts)
+    want = oracle.memory_compress(d, 2, 65536)
+    assert gpu.memory_compress(d, 2, 65536) == want
 
 
 def test_streaming_output_cadence(gpu, oracle, monkeypatch):

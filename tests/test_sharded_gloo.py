@@ -1,4 +1,4 @@
-"""CPU, gloo, world_size 2 / 3 / 4: the N>1 path of bench.py / zultra_amd.sharded — max-blocks sharded over ranks, phase-table
+"""CPU, gloo, world_size 2 / 3 / 4 / 8: the N>1 path of bench.py / zultra_amd.sharded — max-blocks sharded over ranks, phase-table
 all-gather, per-rank stitch at the true bit phase, exact-length transfers to rank 0 — must reproduce the single-stream
 bytes. Compute runs on the CPU emulator build of the kernels (tests/emu); the collectives are real torch.distributed calls.
 
@@ -83,6 +83,13 @@ def test_four_rank_assembly_matches_single_stream(tmp_path):
 
 def test_more_ranks_than_blocks(tmp_path):
     _run(tmp_path, 3, 1, 5000, 29535)          # 2 max-blocks over 3 ranks: rank 0 (the gather root) has an empty shard
+
+
+def test_eight_rank_assembly_matches_single_stream(tmp_path):
+    """The size of the node BASELINE.json's metric is quoted on: nine max-blocks over eight ranks (one rank takes two), a stored sub-block behind every
+    cut, every rank's shard starting at the bit phase the seven tables before it imply."""
+    out = _run(tmp_path, 8, 8, 5000, 29536)
+    assert "SHARDED_OK" in out
 
 
 def test_shard_range_partitions_blocks():

@@ -8,7 +8,11 @@ usage: python tools/pmc_traffic.py <fetch_results.db> <write_results.db> <probe_
 import json
 import re
 import sqlite3
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import zultra_amd  # noqa: E402  (csrc_digest: the sources this profile was measured on)
 
 
 def per_kernel(path, counter):
@@ -46,6 +50,7 @@ for k in sorted(set(fetch) | set(write)):
 res["kernels"]["graph"] = {"launches": max(1, res["kernels"].get("zh_stitch", {}).get("launches", 1)),
                            "hbm_bytes_per_launch": round(sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in res["kernels"].items() if k != "zh_stitch") /
                                                          max(1, res["kernels"].get("zh_stitch", {}).get("launches", 1)))}
+res["csrc_digest"] = zultra_amd.csrc_digest()
 with open(sys.argv[4], "w") as f:
     json.dump(res, f, indent=1)
 print(json.dumps(res["calibration"]))

@@ -39,8 +39,6 @@ nb = (size + bs - 1) // bs
 blocks = [(b * bs - (32768 if b else 0), 32768 if b else 0, min(bs, size - b * bs)) for b in range(nb)]
 ctx = L.context(bs, nb)
 for it in range(3):
-    if it == 2 and os.environ.get("PE_SKIP"):   # timing experiments: the last (timed) batch without one of the parse kernels
-        os.environ["ZH_DEBUG_SKIP"] = os.environ["PE_SKIP"]   # (needs a -DZH_DEBUG_SKIP_BUILD build of the library)
     ctx.compress_blocks(d, blocks)
 t = ctx.timing()
 subs, _, cnt = ctx.subblocks()

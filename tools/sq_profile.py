@@ -6,11 +6,15 @@ bench.py reads back (profiles/*_sq_c<N>.json):
    resident waves    = SQ_WAVE_CYCLES x 4 / cycles the kernel was running (the counter ticks once per four cycles and wave), per kernel:
                        the average number of its waves on the chip while it ran (16 384 wave slots of 32 per CU; a kernel of 128
                        registers can fill 4096)
-usage: python tools/sq_profile.py <sq_results.db> <out.json> <config> <steps profiled> [source note]"""
+usage: python tools/sq_profile.py <sq_results.db> <out.json> <config> <steps profiled> [source note] [ms per step of the profiled run]"""
 import json
 import re
 import sqlite3
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import zultra_amd  # noqa: E402  (csrc_digest: the sources this profile was measured on)
 
 CLOCK_HZ, SIMDS = 2.4e9, 1024
 db = sqlite3.connect(sys.argv[1])
@@ -52,6 +56,9 @@ for k, c in sorted(counters.items()):
     res["kernels"][k] = e
 res["valu_insts_per_step"] = round(valu / steps)
 res["valu_issue_ms_per_step"] = round(valu / steps * 2.0 / SIMDS / CLOCK_HZ * 1e3, 3)
+if len(sys.argv) > 6 and float(sys.argv[6]) > 0:
+    res["step_ms_profiled"] = round(float(sys.argv[6]), 3)   # the profiled run's own step: the denominator of valu_issue_frac (bench.py)
+res["csrc_digest"] = zultra_amd.csrc_digest()
 with open(sys.argv[2], "w") as f:
     json.dump(res, f, indent=1)
 print("VALU instructions per step %.3e = %.2f ms of issue at 1024 SIMDs x 1/2 per cycle x 2.4 GHz" % (res["valu_insts_per_step"], res["valu_issue_ms_per_step"]))

@@ -14,6 +14,20 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libzultra_a
 _lib = None
 
 
+def csrc_digest():
+    """sha-256 (first 16 hex digits) over the kernel and host sources the library is built from (zultra_amd/csrc, include/): what a committed profile
+    (profiles/*.json, tools/pmc_traffic.py, tools/sq_profile.py) was measured on, and what bench.py compares it with before quoting it."""
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    for d in (os.path.join(root, "csrc"), os.path.join(root, "..", "include")):
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".h", ".hip", ".cpp", ".c")):
+                with open(os.path.join(d, name), "rb") as f:
+                    h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def lib():
     """The loaded product library (zultra_amd/libzultra_amd.so, built in-tree by zultra_amd.build)."""
     global _lib

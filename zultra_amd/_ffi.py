@@ -76,7 +76,7 @@ EXPORTS = [
     "zultra_hip_data_capacity", "zultra_hip_compress_blocks", "zultra_hip_subblocks", "zultra_hip_payload",
     "zultra_hip_last_timing", "zultra_hip_get_matches", "zultra_hip_get_splits", "zultra_hip_get_parse",
     "zultra_hip_stitch", "zultra_hip_stitch_finish",
-    "zultra_hip_stitch_device", "zultra_hip_stream_device", "zultra_hip_stream_read", "zultra_hip_block_crc32", "zultra_crc32_append", "zultra_crc32_append_many",
+    "zultra_hip_stitch_device", "zultra_hip_stitch_phase_table", "zultra_hip_stream_device", "zultra_hip_stream_read", "zultra_hip_block_crc32", "zultra_crc32_append", "zultra_crc32_append_many",
     "zultra_hip_create_files", "zultra_hip_compress_files", "zultra_hip_stitch_files", "zultra_hip_staging",
     "zultra_hip_block_adler32", "zultra_adler32_append", "zultra_hip_copy_bandwidth", "zultra_hip_last_stats",
     "zultra_hip_ctx_info", "zultra_hip_context_bytes", "zultra_hip_context_bytes_on", "zultra_release_cached_contexts", "zultra_hip_chain_trace", "zultra_hip_cut_tasks",

@@ -34,7 +34,6 @@
 #include "zh_parse.h"
 #include "zh_parse_chain.h"
 #include "zh_parse_lanes.h"
-#include "zh_parse_loop.h"
 #include "zh_split.h"
 #include "zh_stitch.h"
 
@@ -57,8 +56,7 @@ static_assert(sizeof(zultra_hip_subblock_t) == sizeof(zh_subblock_t), "ABI");
 struct zultra_hip_ctx_s {
    int device;
    uint32_t num_cus;            // persistent kernels launch one workgroup per CU
-   uint32_t total_cus, chain_cus;   // CUs of the device / kept free of the main streams' kernels (ZULTRA_HIP_CHAIN_CUS)
-   uint32_t task_waves;         // persistent zh_parse_tasks waves per CU next to chains (ZULTRA_HIP_TASK_WAVES)
+   uint32_t total_cus;          // CUs of the device
    uint32_t max_block, max_blocks;
    uint64_t W, sort_stride, match_stride, tok_stride, best_stride, slot_stride;
    size_t data_cap;
@@ -114,9 +112,7 @@ struct zultra_hip_ctx_s {
    int auto_runs;               // ZULTRA_HIP_STREAMS not set: the number of runs follows the batch size
    int last_runs;               // runs the last batch was cut into
    uint32_t last_run_b0[ZH_MAX_RUNS];   // ... and the first max-block of each (diagnostics: zultra_hip_cut_tasks)
-   int always_persistent;       // zh_parse_tasks always runs as persistent waves (ZULTRA_HIP_TASK_WAVES per CU)
-   int parse_lanes;             // 1: zh_parse_lanes (a lane per piece) parses the tasks, 0: zh_parse_tasks (a 16-lane row per piece) (ZULTRA_HIP_PARSE_LANES)
-   uint32_t lane_waves;         // persistent zh_parse_lanes waves per CU next to chains
+   uint32_t lane_waves;         // zh_parse_lanes waves per CU that stay next to chains (zh_parse_lanes.h)
    uint32_t mf_cu_pct;          // share of the CUs the matchfinder kernels' grids cover, percent
    uint32_t split_waves;        // waves per splitter workgroup, 0 = by max-block size
    int stagger_ev;              // event of the previous run that a run's matchfinder waits for (0: none)
@@ -160,13 +156,6 @@ struct zultra_hip_ctx_s {
    hipEvent_t lane_ev[ZH_MAX_RUNS][24];
    hipStream_t side_stream[ZH_MAX_RUNS];     // per run: zh_parse_chain runs next to zh_parse_tasks
    hipEvent_t side_ev[ZH_MAX_RUNS][8];       // per pass: fork, join
-   hipStream_t loop_stream[ZH_MAX_RUNS];     // per run: zh_parse_own (zh_parse_loop.h), next to the pass-by-pass kernels of the sub-blocks with chains
-   hipEvent_t loop_ev[ZH_MAX_RUNS][2];
-   uint32_t *d_sbflags;                      // per sub-block: bit 0 = has a chain task (zh_list_huge)
-   int use_loop;                             // ZULTRA_HIP_PARSE_LOOP (default 0)
-   int own_after;                            // ZULTRA_HIP_OWN_AFTER
-   int files_own;                            // files mode: inputs without a chain task through zh_parse_own<1> (ZULTRA_HIP_FILES_OWN, default 0)
-   bool loop_had[ZH_MAX_RUNS];               // the last batch launched zh_parse_loop for this run
    hipStream_t seg_stream[ZH_MAX_RUNS];      // per run: zh_parse_segments, likewise
    hipEvent_t seg_ev[ZH_MAX_RUNS][4];        // per pass: join
    hipEvent_t ev_input;
@@ -174,9 +163,14 @@ struct zultra_hip_ctx_s {
    uint8_t *h_stage[2];         // pinned staging for callers that hand over pageable host memory (zultra_hip_staging)
    size_t h_stage_size[2];
    // pinned host mirrors: async copies to pageable memory would block the host and serialise the runs
-   uint32_t *h_split_cnt, *h_sub_base, *h_crc;
+   uint32_t *h_crc;
    zh_subblock_t *h_results;
    zh_stitch_item_t *d_items;
+   // stream assembly on the device (zh_stitch.h): the runs' descriptors laid end to end (d_results_compact, d_nsubs: total and per run), the first
+   // sub-block of every max-block, what the scan reports (pinned mirror: read after the one synchronisation of a stitch)
+   uint32_t *d_nsubs, *h_nsubs, *d_blk_start;
+   zh_scan_out_t *d_scan_out, *h_scan_out;
+   uint64_t *d_file_off;      // files mode: first byte of every input's stream
    uint32_t *d_stream;        // stitched deflate bits of the last batch
    size_t stream_cap;         // bytes
    uint32_t *d_crc, *d_crc_tables, *d_adler;
@@ -188,7 +182,6 @@ struct zultra_hip_ctx_s {
 
    // host mirrors of the last batch
    std::vector<zh_block_t> blocks;
-   std::vector<uint32_t> split_cnt, sub_base;
    std::vector<zh_subblock_t> results;
    uint8_t *h_payload;   // pinned
    size_t payload_size;
@@ -207,6 +200,10 @@ struct zultra_hip_ctx_s {
          return -1;                                                                                      \
       }                                                                                                  \
    } while (0)
+
+// (64-bit min / max by name: hipcc's host-side `min` picks the int overload for two 64-bit arguments — 0xFFFFFFFF became -1)
+static inline uint64_t zh_min64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+static inline uint64_t zh_max64(uint64_t a, uint64_t b) { return a > b ? a : b; }
 
 static uint32_t zh_clamp_block(uint32_t n) {
    if (!n) n = 1048576;   // libzultra.c:87-92
@@ -490,7 +487,12 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_states);
    (void)hipFree(c->d_taskmap);
    (void)hipFree(c->d_taskinfo);
-   (void)hipFree(c->d_sbflags);
+   (void)hipFree(c->d_nsubs);
+   (void)hipFree(c->d_blk_start);
+   (void)hipFree(c->d_scan_out);
+   (void)hipFree(c->d_file_off);
+   if (c->h_nsubs) (void)hipHostFree(c->h_nsubs);
+   if (c->h_scan_out) (void)hipHostFree(c->h_scan_out);
    (void)hipFree(c->d_ntasks);
    (void)hipFree(c->d_hugelist);
    (void)hipFree(c->d_segtasks);
@@ -512,9 +514,6 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
       for (int i = 0; i < 4; i++)
          if (c->seg_ev[k][i]) (void)hipEventDestroy(c->seg_ev[k][i]);
       if (c->seg_stream[k]) (void)hipStreamDestroy(c->seg_stream[k]);
-      for (int i = 0; i < 2; i++)
-         if (c->loop_ev[k][i]) (void)hipEventDestroy(c->loop_ev[k][i]);
-      if (c->loop_stream[k]) (void)hipStreamDestroy(c->loop_stream[k]);
    }
    if (c->ev_input) (void)hipEventDestroy(c->ev_input);
    for (int i = 0; i < 2; i++)
@@ -526,8 +525,6 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    if (c->graph) (void)hipGraphDestroy(c->graph);
    for (int k = 0; k < 2; k++)
       if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
-   if (c->h_split_cnt) (void)hipHostFree(c->h_split_cnt);
-   if (c->h_sub_base) (void)hipHostFree(c->h_sub_base);
    if (c->h_crc) (void)hipHostFree(c->h_crc);
    if (c->h_ntasks) (void)hipHostFree(c->h_ntasks);
    if (c->h_results) (void)hipHostFree(c->h_results);
@@ -543,6 +540,21 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
       if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
    if (c->stream) (void)hipStreamDestroy(c->stream);
    delete c;
+}
+
+// Environment switches. zh_env: part of the shipped library's surface. zh_knob: tuning experiments — compiled to their defaults
+// unless the library is a probe build (-DZH_TUNING_KNOBS): a process environment cannot move the product off its measured settings.
+static int zh_env(const char *name, int dflt) {
+   const char *e = getenv(name);
+   return e ? atoi(e) : dflt;
+}
+static int zh_knob(const char *name, int dflt) {
+#ifdef ZH_TUNING_KNOBS
+   return zh_env(name, dflt);
+#else
+   (void)name;
+   return dflt;
+#endif
 }
 
 static int zh_create_buffers(zultra_hip_ctx_t *c) {
@@ -568,10 +580,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       int n = 0;
       if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || n <= 0) n = 256;
       c->total_cus = (uint32_t)n;
-      const char *cc = getenv("ZULTRA_HIP_CHAIN_CUS");
-      c->chain_cus = cc ? (uint32_t)atoi(cc) : 0u;   // measured on real text: 0 -> 55.1 ms per 100 MB, 8..32 -> 58.1..58.6 ms (the matchfinder loses more than the chains gain)
-      if (c->chain_cus * 4 > c->total_cus) c->chain_cus = c->total_cus / 4;   // (a small device: never more than a quarter)
-      c->num_cus = c->total_cus - c->chain_cus;   // what the main streams' persistent kernels may fill
+      c->num_cus = c->total_cus;   // what the persistent kernels may fill (keeping 8..32 CUs free for the chain kernels was measured in round 3: +3 ms per 100 MB)
       // the matchfinder kernels take all their LDS dynamically (zh_matchfinder.h): more than the 64 KiB default limit
       ZH_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&zh_mf_group<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ZH_MF_GROUP_LDS));
       ZH_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&zh_mf_frontier<true>), hipFuncAttributeMaxDynamicSharedMemorySize, ZH_MF_FRONTIER_LDS));
@@ -581,88 +590,45 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->ev[i]));
    for (int i = 0; i < 16; i++) ZH_CHECK(c, hipEventCreate(&c->ev2[i]));
    {
-      if (getenv("ZULTRA_HIP_CHAIN_TRACE") && atoi(getenv("ZULTRA_HIP_CHAIN_TRACE"))) {
+      // ---- switches of the shipped library (INTEGRATION.md lists them): they pick between product paths that the size and kind of the data
+      //      would otherwise pick, so that tests can force every path on small inputs; and one diagnostic
+      if (zh_env("ZULTRA_HIP_CHAIN_TRACE", 0)) {
          if (zh_alloc(c, &c->d_chain_trace, (size_t)3 * ZH_TRACE_SLOTS * 4 * ZH_MAX_RUNS)) return -1;   // (the getter returns the first four runs)
          ZH_CHECK(c, hipMemset(c->d_chain_trace, 0, (size_t)3 * ZH_TRACE_SLOTS * 4 * ZH_MAX_RUNS * sizeof(uint64_t)));
       }
-      const char *cl = getenv("ZULTRA_HIP_CUT_LEN");   // tuning experiments: positions per segment, about (ZH_CUT_WARM .. ZH_CUT_LEN)
-      c->cut_len = cl ? (uint32_t)atoi(cl) : (uint32_t)ZH_CUT_LEN;
-      if (c->cut_len < ZH_CUT_WARM) c->cut_len = ZH_CUT_WARM;
-      if (c->cut_len > ZH_CUT_LEN) c->cut_len = ZH_CUT_LEN;   // (the buffers are sized for ZH_CUT_WARM, the smallest)
-      const char *fcg = getenv("ZULTRA_HIP_FILES_CHAIN_GRID");
-      c->files_chain_grid = fcg ? (uint32_t)max(1, min((int)ZH_CHAIN_GRID, atoi(fcg))) : (uint32_t)ZH_CHAIN_GRID;
-      const char *frg = getenv("ZULTRA_HIP_FILES_RUN_GRAPHS");
-      c->files_run_graphs = frg ? atoi(frg) : 1;
-      const char *dm = getenv("ZULTRA_HIP_DEMOTE");
-      c->demote_min = dm ? (uint32_t)atoi(dm) : 2u;
-      const char *cs = getenv("ZULTRA_HIP_COOP_SMALL");
-      c->coop_small = cs ? (uint32_t)atoi(cs) : 256u;
+      c->demote_min = (uint32_t)zh_env("ZULTRA_HIP_DEMOTE", 2);        // a cut task with this many failed cuts in a pass becomes one chain (0: never)
+      c->coop_small = (uint32_t)zh_env("ZULTRA_HIP_COOP_SMALL", 256);  // small runs: tasks with a barrier-free piece above this go to the chain kernel
       if (c->coop_small < 64u) c->coop_small = 64u;
       if (c->coop_small > ZH_COOP_MIN) c->coop_small = ZH_COOP_MIN;
-      const char *ct = getenv("ZULTRA_HIP_COOP_TASKS");
-      c->coop_tasks = ct ? (uint32_t)atoi(ct) : c->num_cus;
-      const char *cm = getenv("ZULTRA_HIP_CUT_MIN");   // tuning experiments: tasks of at least this many positions are cut (>= 2 * ZH_CUT_WARM)
-      c->cut_min = cm ? (uint32_t)atoi(cm) : (uint32_t)ZH_CUT_MIN;
-      if (c->cut_min < 2u * ZH_CUT_WARM) c->cut_min = 2u * ZH_CUT_WARM;
-      const char *swh = getenv("ZULTRA_HIP_SEG_WHOLE");   // (tuning experiments)
-      c->seg_whole = swh ? (uint32_t)atoi(swh) : 16384u;
-      const char *sw = getenv("ZULTRA_HIP_SEG_WIDE");
-      c->seg_wide = sw ? (uint32_t)atoi(sw) : 1024u;
-      const char *tw = getenv("ZULTRA_HIP_TASK_WAVES");
-      c->task_waves = tw ? (uint32_t)atoi(tw) : 26u;
-      if (c->task_waves < 1) c->task_waves = 1;
-      if (c->task_waves > 32) c->task_waves = 32;
-      const char *spw = getenv("ZULTRA_HIP_SPLIT_WAVES");   // waves per splitter workgroup (2, 4, 8, 16; default by max-block size)
-      c->split_waves = spw ? (uint32_t)atoi(spw) : 0u;
-      const char *ap = getenv("ZULTRA_HIP_PERSISTENT_TASKS");   // zh_parse_tasks as a bounded number of persistent waves per CU even when a run has no chains
-      c->always_persistent = ap ? atoi(ap) : 0;
-      const char *pl = getenv("ZULTRA_HIP_PARSE_LANES");
-      c->parse_lanes = pl ? atoi(pl) : 1;
-      const char *lw = getenv("ZULTRA_HIP_LANE_WAVES");
-      c->lane_waves = lw ? (uint32_t)max(1, min(16, atoi(lw))) : 12u;
-      const char *pl2 = getenv("ZULTRA_HIP_PARSE_LOOP");   // 1: sub-blocks without a chain task go through their passes on their own (zh_parse_own); 0: every sub-block pass by pass
-      c->use_loop = pl2 ? atoi(pl2) : 0;   // (off: measured on the 100 MB step, 40.4 ms with it against 37.9 — zh_parse_loop.h)
-      const char *fo = getenv("ZULTRA_HIP_FILES_OWN");
-      c->files_own = (c->files_mode && c->parse_lanes) ? (fo ? atoi(fo) : 0) : 0;   // (off: measured 717 k files/s with it against 795 k, 262 144 inputs)
-      const char *oa = getenv("ZULTRA_HIP_OWN_AFTER");   // zh_parse_own starts after this stage of the batch's LAST run: 0 at once, 1 its upload, 2 zh_mf_group, 3 zh_mf_frontier
-      c->own_after = oa ? atoi(oa) : 0;
-      const char *lt = getenv("ZULTRA_HIP_LANE_TASKS");   // tasks per wave of zh_parse_lanes (tuning experiments); not set: by the size of the run
-      c->lane_tasks = lt ? (uint32_t)max(1, min((int)ZH_LP_TASKS, atoi(lt))) : 0u;
-      const char *mfl = getenv("ZULTRA_HIP_MF_CAP");   // elements per chunk of zh_mf_group's refinement in LDS (zh_mf_group_lds.h); 0: rounds 1-3's passes through HBM (A/B runs)
-      c->mf_lds_cap = mfl ? (uint32_t)max(0, atoi(mfl)) : (uint32_t)ZH_MFL_CAP_LIMIT;
-      const char *mfp = getenv("ZULTRA_HIP_MF_CUS");   // share of the CUs the matchfinder's persistent workgroups take, in percent (tuning experiments)
-      c->mf_cu_pct = mfp ? (uint32_t)max(1, min(100, atoi(mfp))) : 100u;
-      const char *sg = getenv("ZULTRA_HIP_STAGGER");   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group (default), 3 zh_mf_frontier, 4 the splitter
-      c->stagger_ev = sg ? atoi(sg) : 2;   // (default 2)   // measured, 2 instead of 3: 100 MB of real text 51.9 -> 49.8 ms, configuration 3 31.6 -> 30.5, configuration 4 972 -> 910
-      if (c->stagger_ev != 0 && (c->stagger_ev < 2 || c->stagger_ev > 4)) c->stagger_ev = 3;
-      const char *fr = getenv("ZULTRA_HIP_FIRST_RUN");   // share of the first run, in percent of an equal share (tuning experiments)
-      c->first_run_pct = fr ? (uint32_t)atoi(fr) : 100u;
-      if (c->first_run_pct < 10u) c->first_run_pct = 10u;
-      if (c->first_run_pct > 100u) c->first_run_pct = 100u;
-      const char *lr = getenv("ZULTRA_HIP_LAST_RUN");   // share of the last run, likewise (three runs and more)
-      c->last_run_pct = lr ? (uint32_t)atoi(lr) : 100u;
-      if (c->last_run_pct < 10u) c->last_run_pct = 10u;
-      if (c->last_run_pct > 100u) c->last_run_pct = 100u;
-      const char *e = getenv("ZULTRA_HIP_STREAMS");
-      c->nlanes = e ? atoi(e) : 4;
-      c->auto_runs = e ? 0 : 1;   // not set: three runs, four for batches of 256 MiB and more (measured with the stagger above, runs = 2 / 3 / 4 / 6: 100 MB
-                                  // of real text 49.8 / 49.6 / 51.2 / - ms; configuration 3 31.0 / 29.1 / 29.5 / -; 1 GiB of configuration 4 910 / 883 / 789 / 812)
+      c->seg_whole = (uint32_t)zh_env("ZULTRA_HIP_SEG_WHOLE", 16384);  // cut tasks shorter than this are parsed whole when zh_parse_chain takes the segments
+      c->seg_wide = (uint32_t)zh_env("ZULTRA_HIP_SEG_WIDE", 1024);     // a run with at least this many segments parses them with zh_parse_segments
+      c->mf_lds_cap = (uint32_t)max(0, zh_env("ZULTRA_HIP_MF_CAP", (int)ZH_MFL_CAP_LIMIT));   // elements per chunk of zh_mf_group's refinement in LDS (zh_mf_group_lds.h)
+      const int streams = zh_env("ZULTRA_HIP_STREAMS", 0);              // staggered runs per batch; not set: three, four for batches of 256 MiB and more
+      c->nlanes = streams ? streams : 4;
+      c->auto_runs = streams ? 0 : 1;   // (measured with the stagger below, runs = 2 / 3 / 4 / 6: 100 MB of real text 49.8 / 49.6 / 51.2 / - ms; configuration 3
+                                        // 31.0 / 29.1 / 29.5 / -; 1 GiB of configuration 4 910 / 883 / 789 / 812)
       if (c->nlanes < 1) c->nlanes = 1;
       if (c->nlanes > ZH_MAX_RUNS) c->nlanes = ZH_MAX_RUNS;
+      c->files_run_graphs = zh_env("ZULTRA_HIP_FILES_RUN_GRAPHS", 1);  // files mode: 0 = several runs are launched kernel by kernel, and large batches stay one run
+      // ---- tuning knobs: read in probe builds only (-DZH_TUNING_KNOBS, tools/build_variant.sh); the shipped library has the defaults compiled in
+      c->cut_len = (uint32_t)zh_knob("ZULTRA_HIP_CUT_LEN", (int)ZH_CUT_LEN);   // positions per segment, about (ZH_CUT_WARM .. ZH_CUT_LEN)
+      if (c->cut_len < ZH_CUT_WARM) c->cut_len = ZH_CUT_WARM;
+      if (c->cut_len > ZH_CUT_LEN) c->cut_len = ZH_CUT_LEN;   // (the buffers are sized for ZH_CUT_WARM, the smallest)
+      c->files_chain_grid = (uint32_t)max(1, min((int)ZH_CHAIN_GRID, zh_knob("ZULTRA_HIP_FILES_CHAIN_GRID", (int)ZH_CHAIN_GRID)));
+      c->coop_tasks = (uint32_t)zh_knob("ZULTRA_HIP_COOP_TASKS", (int)c->num_cus);   // a run of at most this many tasks counts as small
+      c->cut_min = (uint32_t)zh_knob("ZULTRA_HIP_CUT_MIN", (int)ZH_CUT_MIN);         // tasks of at least this many positions are cut (>= 2 * ZH_CUT_WARM)
+      if (c->cut_min < 2u * ZH_CUT_WARM) c->cut_min = 2u * ZH_CUT_WARM;
+      c->split_waves = (uint32_t)zh_knob("ZULTRA_HIP_SPLIT_WAVES", 0);               // waves per splitter workgroup (2, 4, 8, 16; default by max-block size)
+      c->lane_waves = (uint32_t)max(1, min(16, zh_knob("ZULTRA_HIP_LANE_WAVES", 12)));
+      c->lane_tasks = (uint32_t)max(0, min((int)ZH_LP_TASKS, zh_knob("ZULTRA_HIP_LANE_TASKS", 0)));   // tasks per wave of zh_parse_lanes; 0: by the size of the run
+      c->mf_cu_pct = (uint32_t)max(1, min(100, zh_knob("ZULTRA_HIP_MF_CUS", 100)));  // share of the CUs the matchfinder's persistent workgroups take, in percent
+      c->stagger_ev = zh_knob("ZULTRA_HIP_STAGGER", 2);   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group, 3 zh_mf_frontier, 4 the splitter
+                                                          // (measured, 2 instead of 3: 100 MB of real text 51.9 -> 49.8 ms, configuration 3 31.6 -> 30.5, configuration 4 972 -> 910)
+      if (c->stagger_ev != 0 && (c->stagger_ev < 2 || c->stagger_ev > 4)) c->stagger_ev = 3;
+      c->first_run_pct = (uint32_t)max(10, min(100, zh_knob("ZULTRA_HIP_FIRST_RUN", 100)));   // share of the first run, in percent of an equal share
+      c->last_run_pct = (uint32_t)max(10, min(100, zh_knob("ZULTRA_HIP_LAST_RUN", 100)));     // share of the last run, likewise (three runs and more)
       for (int k = 0; k < c->nlanes; k++) {
-         // The run's main stream keeps off the last `chain_cus` CUs: whatever it launches — the matchfinder's one-workgroup-per-CU
-         // kernels, tens of thousands of single-wave task workgroups — those CUs stay free for the kernels of the other streams,
-         // i.e. for the first workgroups of zh_parse_chain (which take the longest chains): a four-wave workgroup otherwise waits
-         // for room until the flood has drained, and the whole pass waits for it.
-         if (c->chain_cus) {
-            uint32_t mask[32];
-            const uint32_t words = (c->total_cus + 31) / 32;
-            for (uint32_t w2 = 0; w2 < words && w2 < 32; w2++) mask[w2] = 0xffffffffu;
-            for (uint32_t b = c->total_cus - c->chain_cus; b < c->total_cus && b < 1024; b++) mask[b / 32] &= ~(1u << (b % 32));
-            ZH_CHECK(c, hipExtStreamCreateWithCUMask(&c->lane_stream[k], words, mask));
-         }
-         else
-            ZH_CHECK(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
+         ZH_CHECK(c, hipStreamCreateWithFlags(&c->lane_stream[k], hipStreamNonBlocking));
          for (int i = 0; i < 24; i++) ZH_CHECK(c, hipEventCreate(&c->lane_ev[k][i]));
          {
             // zh_parse_chain is a few workgroups following long chains: it should never queue behind the wide kernels
@@ -676,19 +642,13 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
             (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
             ZH_CHECK(c, hipStreamCreateWithPriority(&c->seg_stream[k], hipStreamNonBlocking, hi_prio));
             for (int i = 0; i < 4; i++) ZH_CHECK(c, hipEventCreate(&c->seg_ev[k][i]));
-            {
-               int lo_prio = 0, hi_prio = 0;
-               (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
-               const char *op = getenv("ZULTRA_HIP_OWN_PRIO");   // 1: the lowest stream priority for zh_parse_own's stream
-               ZH_CHECK(c, hipStreamCreateWithPriority(&c->loop_stream[k], hipStreamNonBlocking, (op && atoi(op)) ? lo_prio : 0));
-            }
-            for (int i = 0; i < 2; i++) ZH_CHECK(c, hipEventCreate(&c->loop_ev[k][i]));
          }
       }
       ZH_CHECK(c, hipEventCreate(&c->ev_input));
       if (zh_alloc(c, &c->d_results_compact, B * c->max_subs)) return -1;
-      ZH_CHECK(c, hipHostMalloc((void **)&c->h_split_cnt, B * sizeof(uint32_t), 0));
-      ZH_CHECK(c, hipHostMalloc((void **)&c->h_sub_base, B * sizeof(uint32_t), 0));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_nsubs, (1 + ZH_MAX_RUNS) * sizeof(uint32_t), 0));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_scan_out, sizeof(zh_scan_out_t), 0));
+      memset(c->h_nsubs, 0, (1 + ZH_MAX_RUNS) * sizeof(uint32_t));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_crc, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_ntasks, 2 * ZH_NCNT * sizeof(uint32_t), 0));   // a mirror of d_ntasks + per-run readbacks
       memset(c->h_ntasks, 0, 2 * ZH_NCNT * sizeof(uint32_t));
@@ -701,7 +661,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->seg_tasks_per_block = c->files_mode ? 1 : N / (2u * ZH_CUT_WARM) + 1;
    c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_WARM + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;   // a task of len positions has at most len / ZH_CUT_LEN + ZH_CUT_ROWS segments
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) || zh_alloc(c, &c->d_taskinfo, c->max_tasks) ||
-       zh_alloc(c, &c->d_sbflags, B * c->max_subs) ||
+       zh_alloc(c, &c->d_nsubs, 1 + ZH_MAX_RUNS) || zh_alloc(c, &c->d_blk_start, B + 1) || zh_alloc(c, &c->d_scan_out, 1) || (c->files_mode && zh_alloc(c, &c->d_file_off, B + 1)) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
        zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 3 * ZH_MAX_RUNS) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, 4 * c->max_tasks) ||
        zh_alloc(c, &c->d_segtasks, B * c->seg_tasks_per_block) || zh_alloc(c, &c->d_segwaves, B * c->seg_items_per_block) || zh_alloc(c, &c->d_segitems, B * c->seg_items_per_block) ||
@@ -709,7 +669,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       return -1;
    if (zh_alloc(c, &c->d_data, c->data_cap + 64) || zh_alloc(c, &c->d_blocks, B) || zh_alloc(c, &c->d_sort_a, B * c->segs_per_block * c->sort_stride) ||
        zh_alloc(c, &c->d_sort_b, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_match, B * c->match_stride) || zh_alloc(c, &c->d_longest, 64) ||
-       zh_alloc(c, &c->d_pay, (size_t)c->nlanes * min((uint64_t)c->total_cus, B * c->segs_per_block) * 3 * c->sort_stride) ||   // (the runs' kernels may overlap)
+       zh_alloc(c, &c->d_pay, (size_t)c->nlanes * zh_min64(c->total_cus, B * c->segs_per_block) * 3 * c->sort_stride) ||   // (the runs' kernels may overlap)
        zh_alloc(c, &c->d_tok_pos, B * c->tok_stride) || zh_alloc(c, &c->d_tok_info, B * c->tok_stride) ||
        zh_alloc(c, &c->d_ntok, B) || zh_alloc(c, &c->d_chunkmax, B * c->chunks_per_block) || zh_alloc(c, &c->d_spanstart, B * c->chunks_per_block) ||
        zh_alloc(c, &c->d_spancnt, B * c->chunks_per_block) || zh_alloc(c, &c->d_split_tok, B * (ZH_MAX_SPLITS + 1)) || zh_alloc(c, &c->d_split_cnt, B) ||
@@ -717,6 +677,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
        zh_alloc(c, &c->d_results, B * c->max_subs) || zh_alloc(c, &c->d_payload, B * c->slot_stride) ||
        zh_alloc(c, &c->d_items, B * c->max_subs) || zh_alloc(c, &c->d_crc, B) || zh_alloc(c, &c->d_adler, 2 * B) || zh_alloc(c, &c->d_crc_tables, 256 + 1024))
       return -1;
+   ZH_CHECK(c, hipMemset(c->d_ntasks, 0, ZH_NCNT * sizeof(uint32_t)));
    c->stream_cap = (size_t)(B * (N + 5 * (N / 65535 + 1) + 8) + 64) & ~(size_t)3;
    ZH_CHECK(c, hipMalloc((void **)&c->d_stream, c->stream_cap + 16));
    {
@@ -841,7 +802,7 @@ extern "C" size_t zultra_hip_context_bytes_on(int device, uint32_t max_block_siz
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
       const char *e = getenv("ZULTRA_HIP_STREAMS");
       const uint64_t lanes = (uint64_t)max(1, min((int)ZH_MAX_RUNS, e ? atoi(e) : 4));
-      bytes += lanes * min((uint64_t)cus, B * S) * 3 * sort_stride * 4;
+      bytes += lanes * zh_min64((uint64_t)cus, B * S) * 3 * sort_stride * 4;
       // cut tasks (zh_parse.h): lists and two cost vectors per segment
       const uint64_t seg_tasks = N / (2u * ZH_CUT_WARM) + 1, seg_items = N / ZH_CUT_WARM + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;
       bytes += B * (seg_tasks * sizeof(uint4) + seg_items * (2 * sizeof(uint2) + 2 * ZH_VEC * sizeof(int16_t)));
@@ -915,93 +876,170 @@ static int zh_enqueue_tokenize(zultra_hip_ctx_t *c, hipStream_t st, const zh_blo
 }
 
 // files mode: what zh_split would report for an input below its 8192-byte threshold — one sub-block spanning all tokens
-__global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, uint32_t *split_tok, uint32_t *split_cnt, uint32_t *sub_base) {
+__global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, uint32_t *split_tok, uint32_t *split_cnt) {
    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
    if (b >= nblocks) return;
    split_tok[(uint64_t)b * (ZH_MAX_SPLITS + 1)] = 0;
    split_tok[(uint64_t)b * (ZH_MAX_SPLITS + 1) + 1] = ntok[b];
    split_cnt[b] = 1;
-   sub_base[b] = b;
 }
 
-// The kernel sequence of one run (inputs b0 .. b0 + nb) of a files-mode batch, with no host decision in it: run k on stream st,
-// its chains on `side`. Per-block buffers are addressed as base + block * stride, so a run sees the base pointers advanced to its
-// first input; sub-block indices are local to the run (zh_run_files shifts the descriptors).
-// part: 0 the whole run; 1 only up to the end of its first matchfinder kernel (where the next run's matchfinder may start), 2 only what follows —
-// the two halves of a run captured as graphs of their own (zh_run_files)
-static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, hipStream_t st, hipStream_t side, int part = 0) {
+// The kernel sequence of one run of a batch — max-blocks b0 .. b0 + nb with `total_n` input bytes, matchfinder segments sg0 .. sg0 + nsg — with
+// NO HOST DECISION in it: run k on stream st, its chains on `side`, its cut tasks' segments on `segst` (not in files mode: inputs below 8192 bytes
+// are never cut). Everything the splitter decides — how many sub-blocks, hence how many tasks, chains, segments — stays on the device: zh_plan_subblocks
+// sums it up into the run's counters, every later kernel takes its bounds from there, and the grids here are sized from the input bytes alone, as
+// bounded grids that stride over what there is (rounds 1-4 read the counts back twice per run, in the middle of the pipeline: 0.8-2.2 ms each on the
+// 100 MB step, profiles/r04_timeline_c2.txt). Per-block buffers are addressed as base + block * stride, so a run sees the base pointers advanced to its
+// first max-block; sub-block and task indices are local to the run (zh_compact_results shifts the descriptors).
+// part: 0 the whole run; 1 only up to the end of its first matchfinder kernel (where the next run's matchfinder may start), 2 only what follows — the two
+// halves of a files-mode run captured as graphs of their own (zh_run_files).
+// A kernel whose item count only the device knows (sub-blocks, tasks, segment waves of a run): the <false> form over `grid_` workgroups, one item each (what data
+// usually gives; surplus workgroups leave at once), then the <true> form, ZH_MORE_GRID workgroups striding over what lies beyond grid_ — nearly always nothing.
+#define ZH_MORE_GRID 256u
+#define ZH_LAUNCH_BOTH(kernel_, grid_, stream_, ...)                                              \
+   do {                                                                                           \
+      ZH_LAUNCH(kernel_<false>, (grid_), 64, stream_, __VA_ARGS__, 0u);                           \
+      ZH_LAUNCH(kernel_<true>, ZH_MORE_GRID, 64, stream_, __VA_ARGS__, (uint32_t)(grid_));        \
+   } while (0)
+
+static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, uint64_t total_n, uint32_t sg0, uint32_t nsg, hipStream_t st, hipStream_t side, hipStream_t segst, int part) {
+   const bool files = c->files_mode != 0;
+   hipEvent_t *ev = c->lane_ev[k];
    const zh_block_t *blk = c->d_blocks + b0;
-   const uint32_t mf_grid = min(nb, c->num_cus);   // persistent workgroups, one per CU (zh_matchfinder.h)
    const uint64_t tasks_per_block = c->max_tasks / c->max_blocks;
-   const uint64_t t0 = (uint64_t)b0 * tasks_per_block;
-   uint32_t *ctr = c->d_chunk_ctr + (size_t)b0 * 2 + 3 * (size_t)k;   // this run's counters: 2 per segment (= input) + the three tickets
-   uint32_t *sa = c->d_sort_a + (uint64_t)b0 * c->sort_stride, *sb = c->d_sort_b + (uint64_t)b0 * c->sort_stride;
-   uint2 *p3 = c->d_prev3 + (uint64_t)b0 * c->sort_stride;
-   uint32_t *rn = c->d_runs + (uint64_t)b0 * c->run_stride;
-   uint32_t *cnt = c->d_ntasks + (size_t)k * ZH_CNT_STRIDE;
-   zh_work_t *work = c->d_work + b0;
-   zh_sbstate_t *states = c->d_states + b0;
+   const uint64_t s0 = (uint64_t)b0 * c->max_subs, t0 = (uint64_t)b0 * tasks_per_block;   // per-sub-block and per-task buffers of the run start at its worst-case offset
+   const zh_seg_t *sgs = c->d_segs + sg0;
+   uint32_t *sa = c->d_sort_a + (uint64_t)sg0 * c->sort_stride, *sb = c->d_sort_b + (uint64_t)sg0 * c->sort_stride;
+   uint2 *p3 = c->d_prev3 + (uint64_t)sg0 * c->sort_stride;
+   uint32_t *rn = c->d_runs + (uint64_t)sg0 * c->run_stride;
+   uint32_t *ctr = c->d_chunk_ctr + (size_t)sg0 * 2 + 3 * (size_t)k;   // this run's counters: 2 per segment + the three tickets
+   uint32_t *pay = c->d_pay + (size_t)k * zh_min64(c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride;
+   uint32_t *cnt = c->d_ntasks + (size_t)k * ZH_CNT_STRIDE;   // the run's counters (ZH_CNT_*)
+   zh_work_t *work = c->d_work + s0;
+   zh_sbstate_t *states = c->d_states + s0;
    uint2 *taskmap = c->d_taskmap + t0;
-   uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM, *hugelist = c->d_hugelist + 4 * t0, *task_bits = c->d_task_bits + t0;
+   uint2 *taskinfo = c->d_taskinfo + t0;
+   uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM, *task_bits = c->d_task_bits + t0;
+   uint32_t *hugelist = c->d_hugelist + 4 * t0;   // four lists of `cap` entries each: three by zh_list_huge, the cut tasks given up on by zh_parse_segments
+   const uint32_t cap = (uint32_t)zh_min64((uint64_t)nb * tasks_per_block, 0xFFFFFFFFull);
+   uint4 *segtasks = c->d_segtasks + (uint64_t)b0 * c->seg_tasks_per_block;
+   uint2 *segwaves = c->d_segwaves + (uint64_t)b0 * c->seg_items_per_block, *segitems = c->d_segitems + (uint64_t)b0 * c->seg_items_per_block;
+   int16_t *vecs = c->d_vecs + (uint64_t)b0 * c->seg_items_per_block * 2 * ZH_VEC;
    uint8_t *payload = c->d_payload + (uint64_t)b0 * c->slot_stride;
    uint32_t *best = c->d_best + (uint64_t)b0 * c->best_stride;
+   uint16_t *cost = c->d_cost + (uint64_t)b0 * c->best_stride;
    const uint64_t *bars = c->d_bars + (uint64_t)b0 * c->bar_stride;
    const zh_match_t *match = c->d_match + (uint64_t)b0 * c->match_stride;
-   // (counters, payload slots and the copies of the results are the caller's, on the stream the runs fork from: zh_enqueue_files)
+   const uint32_t mf_grid = min(nsg, max(1u, c->num_cus * c->mf_cu_pct / 100u));   // persistent workgroups, one per CU (zh_matchfinder.h)
+   // grids: bounded by what the input bytes allow, sized for what data usually gives; the kernels stride
+   const uint32_t est_tasks = (uint32_t)zh_min64(cap, total_n / ZH_TASK + 2ull * nb);                                   // tasks: ~ bytes / 2048 + one per sub-block
+   const uint32_t task_grid = (uint32_t)zh_min64(cap, total_n / ZH_TASK + 4ull * nb);                                    // one wave per task (zh_list_huge, zh_post_tasks, zh_emit_tasks)
+   const uint32_t sb_grid = (uint32_t)zh_min64((uint64_t)nb * c->max_subs, zh_max64(4ull * nb, zh_min64(1024, (uint64_t)nb * c->max_subs)));   // one wave per sub-block (zh_sb_init, zh_sb_build)
    if (part != 2) {
-   ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), sa, sb, p3, rn, c->sort_stride, c->run_stride, 0, nb,
-             ctr + (size_t)nb * 2 + 1, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride, c->mf_lds_cap);
-   if (c->mf_lds_cap && c->seg_W > ZH_MFL_MAXCAP)   // (inputs of <= 4 KiB are one chunk of zh_mf_group: nothing is ever noted)
-      ZH_LAUNCH_LDS(zh_mf_group_big, min(mf_grid, 32u), ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), sa, sb, p3, (const uint32_t *)rn, c->sort_stride,
-                    c->run_stride, nb, ctr + (size_t)nb * 2 + 2, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride);
+      ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, rn, c->sort_stride, c->run_stride, 0, nsg, ctr + (size_t)nsg * 2 + 1, pay,
+                    c->mf_lds_cap);
+      // the bigram classes that fit no chunk of zh_mf_group, noted by it (zh_mf_group_lds.h): a kernel of their own (inputs of <= 4 KiB are one chunk: nothing is ever noted)
+      if (c->mf_lds_cap && c->seg_W > (files ? (uint32_t)ZH_MFL_MAXCAP : min((uint32_t)ZH_MFL_MAXCAP, max(c->mf_lds_cap, 16u))))
+         ZH_LAUNCH_LDS(zh_mf_group_big, files ? min(mf_grid, 32u) : mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, (const uint32_t *)rn, c->sort_stride, c->run_stride, nsg,
+                       ctr + (size_t)nsg * 2 + 2, pay);
    }
    if (part == 1) return 0;
-   if (part == 0) ZH_CHECK(c, hipEventRecord(c->lane_ev[k][2], st));   // the next run's matchfinder starts here (part 2: the caller records it between the two graphs)
-   // (segment descriptors carry batch-wide input indices: the rows go to d_match + input * match_stride)
-   ZH_LAUNCH_LDS(zh_mf_frontier<true>, mf_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, (const zh_seg_t *)(c->d_segs + b0), (const uint32_t *)sa, (const uint2 *)p3,
-             (const uint32_t *)rn, c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, ctr, nb, 0u);   // small inputs: nothing worth sharing
+   if (part == 0) ZH_CHECK(c, hipEventRecord(ev[2], st));   // the next run's matchfinder starts here (part 2: the caller records it between the two graphs)
+   // (segment descriptors carry batch-wide block indices: the rows go to d_match + block * match_stride)
+   // a run of fewer segments than CUs (one call on a few max-blocks: latency): the workgroups beyond one per segment find the tickets gone and help —
+   // a segment of a 64 KiB max-block is ~1500 chunks, shared while a helper's share stays above ZH_MF_HELP_MIN of them (small inputs: nothing worth sharing)
+   const uint32_t fr_grid = files ? mf_grid : min(max(1u, c->num_cus * c->mf_cu_pct / 100u), mf_grid * 8u);
+   ZH_LAUNCH_LDS(zh_mf_frontier<true>, fr_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint2 *)p3, (const uint32_t *)rn, c->sort_stride,
+                 c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, ctr, nsg, files ? 0u : 1u);
+   if (!files) ZH_CHECK(c, hipEventRecord(ev[3], st));   // (timing marks)
    if (zh_enqueue_tokenize(c, st, blk, b0, nb) != 0) return -1;
-   ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0,
-             c->d_sub_base + b0);
-   ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)(c->d_tok_pos + (uint64_t)b0 * c->tok_stride), c->tok_stride, (const uint32_t *)(c->d_ntok + b0),
-             (const uint32_t *)(c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1)), (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride,
-             work, taskmap, cnt);
-   ZH_LAUNCH(zh_sb_init, nb, 64, st, (const uint16_t *)(c->d_tok_info + (uint64_t)b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
-   const uint32_t task_grid = nb * ((c->max_block + ZH_TASK - 1) / ZH_TASK);   // upper bound, independent of the data: the graph stays valid
-   // (inputs of a files batch are never cut into speculative segments: seg_min = all ones)
-   uint32_t *sbflags = c->files_own ? c->d_sbflags + b0 : (uint32_t *)NULL;   // (one sub-block per input)
-   if (sbflags) ZH_CHECK(c, hipMemsetAsync(sbflags, 0, (size_t)nb * sizeof(uint32_t), st));
-   ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-             (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, c->d_segtasks, c->d_segitems, c->d_segwaves, 0xFFFFFFFFu,
-             (uint32_t)ZH_CUT_LEN, cnt, c->d_taskinfo + t0, sbflags, (uint32_t)ZH_COOP_MIN);
-   // An input without a chain task — nearly all of them — goes through its four passes on ONE wave, in one launch (zh_parse_loop.h: for
-   // max-blocks that lost to the pass-by-pass kernels; here a pass over an input is two tasks, and eight launches per batch wait for each other)
-   if (sbflags)
-      ZH_LAUNCH(zh_parse_own<1u>, nb, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, states, best,
-                c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, (const uint2 *)(c->d_taskinfo + t0), payload, (const uint32_t *)sbflags, nb, cnt);
+   if (files)
+      ZH_LAUNCH(zh_nosplit, (nb + 255) / 256, 256, st, nb, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0);
+   else {
+#define ZH_LAUNCH_SPLIT(W_)                                                                                                                                   \
+   ZH_LAUNCH(zh_split<W_>, nb, 64 * W_, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), \
+             c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0)
+      const uint32_t sw = c->split_waves ? c->split_waves : (c->max_block > 131072 ? 16u : 8u);
+      if (sw >= 16)
+         ZH_LAUNCH_SPLIT(16);
+      else if (sw >= 8)
+         ZH_LAUNCH_SPLIT(8);
+      else if (sw >= 4)
+         ZH_LAUNCH_SPLIT(4);
+      else
+         ZH_LAUNCH_SPLIT(2);
+#undef ZH_LAUNCH_SPLIT
+   }
+   if (!files) ZH_CHECK(c, hipEventRecord(ev[4], st));   // (timing marks)
+   // ---- stage 3: the sub-block coder, one kernel per step over the run (zh_encode.h) -----------------------------------------------------
+#define ZH_LAUNCH_PLAN(T_)                                                                                                                                                               \
+   ZH_LAUNCH(zh_plan_subblocks<T_>, 1, T_, st, blk, nb, (const uint32_t *)(c->d_tok_pos + (uint64_t)b0 * c->tok_stride), c->tok_stride, (const uint32_t *)(c->d_ntok + b0),              \
+             (const uint32_t *)(c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1)), (const uint32_t *)(c->d_split_cnt + b0), c->d_sub_base + b0, c->slot_stride, work, taskmap, cnt)
+   if (nb > 4096u)
+      ZH_LAUNCH_PLAN(1024u);
+   else
+      ZH_LAUNCH_PLAN(256u);
+#undef ZH_LAUNCH_PLAN
+   ZH_LAUNCH_BOTH(zh_sb_init, sb_grid, st, (const uint16_t *)(c->d_tok_info + (uint64_t)b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states, (const uint32_t *)cnt);
+   // (inputs of a files batch are never cut into speculative segments: seg_min = all ones; a run of at most coop_tasks tasks counts as small)
+   ZH_LAUNCH_BOTH(zh_list_huge, task_grid, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride),
+             c->match_stride, hugelist, cap, segtasks, segitems, segwaves, files ? 0xFFFFFFFFu : c->cut_min, files ? (uint32_t)ZH_CUT_LEN : c->cut_len, cnt, taskinfo, (uint32_t)ZH_COOP_MIN,
+             files ? (uint32_t)ZH_COOP_MIN : c->coop_small, files ? 0u : c->coop_tasks);
+   if (!files) ZH_CHECK(c, hipEventRecord(ev[5], st));   // (timing marks)
+   // Persistent workgroups of zh_parse_chain take the listed chains from a ticket (none listed: they leave at once); zh_parse_lanes takes the task
+   // list in groups, as a grid that fills the chip's wave slots — next to chains only `lane_waves` per CU stay, so that the chain workgroups find
+   // room the moment they are launched (the run's counters tell the kernel which); zh_parse_segments takes the cut tasks' segments when there are many.
+   const uint32_t tpw = zh_tasks_per_wave(c, est_tasks);
+   const uint32_t lane_grid = max(1u, min((est_tasks + tpw - 1) / tpw, c->num_cus * 16u));
+   const uint32_t chain_grid = files ? min(nb, c->files_chain_grid) : (uint32_t)zh_min64(ZH_CHAIN_GRID, total_n / 256u + nb);
+   const uint32_t seg_grid = c->num_cus * 8u;
    for (int pass = 0; pass <= 3; pass++) {
-      // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
       ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
-      ZH_LAUNCH(zh_parse_chain, min(nb, c->files_chain_grid), ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, c->d_segtasks, (const uint2 *)c->d_segitems, c->d_vecs, 0u, 0u, cnt, (const zh_sbstate_t *)states, best,
-                c->best_stride, hist_part, pass, cnt + ZH_CNT_CHAIN_TICKET + pass, (uint64_t *)NULL);
+      ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
+                (const uint32_t *)hugelist, cap, segtasks, (const uint2 *)segitems, vecs, c->seg_wide, c->seg_whole, cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
+                cnt + ZH_CNT_CHAIN_TICKET + pass, (c->d_chain_trace && !files) ? c->d_chain_trace + 3 * (uint64_t)ZH_TRACE_SLOTS * (4 * k + pass) : (uint64_t *)NULL);
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
-      const uint32_t tpw = zh_tasks_per_wave(c, task_grid);
-      if (c->parse_lanes)
-         ZH_LAUNCH(zh_parse_lanes, (task_grid + tpw - 1) / tpw, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                   (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + (uint64_t)b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0), tpw, (const uint32_t *)sbflags);
-      else
-      ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
+      if (!files) {
+         ZH_CHECK(c, hipStreamWaitEvent(segst, c->side_ev[k][2 * pass], 0));
+         ZH_LAUNCH_BOTH(zh_parse_segments, seg_grid, segst, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
+                   (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, segtasks, (const uint2 *)segwaves, vecs, cnt, hugelist + 3 * (size_t)cap, c->demote_min, c->seg_wide);
+         ZH_CHECK(c, hipEventRecord(c->seg_ev[k][pass], segst));
+      }
+      ZH_LAUNCH(zh_parse_lanes, lane_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt,
+                (const zh_sbstate_t *)states, best, c->best_stride, cost, hist_part, pass, cnt + ZH_CNT_TASK_TICKET + pass, (const uint2 *)taskinfo, tpw,
+                files ? 0xFFFFFFFFu : c->num_cus * c->lane_waves);
+      if (!files) ZH_CHECK(c, hipStreamWaitEvent(st, c->seg_ev[k][pass], 0));
       ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
-      ZH_LAUNCH(zh_sb_build, nb, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, (const uint32_t *)sbflags, cnt);
+      if (!files) ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));   // (timing marks)
+      ZH_LAUNCH_BOTH(zh_sb_build, sb_grid, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, cnt);
+      if (!files) ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));   // (timing marks)
    }
-   ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt,
-             (const zh_sbstate_t *)states, best, c->best_stride, task_bits, (const uint2 *)(c->d_taskinfo + t0));
-   ZH_LAUNCH(zh_emit_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt,
-             (const zh_sbstate_t *)states, (const uint32_t *)best, c->best_stride, (const uint32_t *)task_bits, payload, c->d_results + b0, (const uint2 *)(c->d_taskinfo + t0));
-   ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
+   ZH_LAUNCH_BOTH(zh_post_tasks, task_grid, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best,
+             c->best_stride, task_bits, (const uint2 *)taskinfo);
+   if (!files) ZH_CHECK(c, hipEventRecord(ev[14], st));   // (timing marks)
+   ZH_LAUNCH_BOTH(zh_emit_tasks, task_grid, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states,
+             (const uint32_t *)best, c->best_stride, (const uint32_t *)task_bits, payload, c->d_results + s0, (const uint2 *)taskinfo);
+   if (!files) ZH_CHECK(c, hipEventRecord(ev[15], st));   // (timing marks)
+   // per-max-block CRC-32 (linear part) and Adler-32 for the framing's footer (a batch of max-blocks computes them next to its matchfinder: zultra_hip_compress_blocks)
+   if (files) ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
+   return 0;
+}
+
+// Behind the last run: the runs' descriptors laid end to end in batch coordinates (zh_compact_results), the totals next to them. On `st`, which has
+// waited for every run.
+static int zh_enqueue_compact(zultra_hip_ctx_t *c, const uint32_t *run_b0, int runs, hipStream_t st) {
+   zh_runs_t R;
+   memset(&R, 0, sizeof(R));
+   R.nruns = (uint32_t)runs;
+   for (int k = 0; k < runs; k++) R.b0[k] = run_b0[k];
+   R.cnt_stride = ZH_CNT_STRIDE;
+   R.nsubs_field = ZH_CNT_NSUBS;
+   R.max_subs = c->max_subs;
+   R.slot_stride = c->slot_stride;
+   ZH_LAUNCH(zh_compact_results, 64, ZH_COMPACT_RESULTS_THREADS, st, R, (const zh_subblock_t *)c->d_results, (const uint32_t *)c->d_ntasks, c->d_results_compact, c->d_nsubs);
+   ZH_CHECK(c, hipMemcpyAsync(c->h_nsubs, c->d_nsubs, (1 + ZH_MAX_RUNS) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+   ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks, c->d_ntasks, ZH_NCNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
    return 0;
 }
 
@@ -1010,6 +1048,17 @@ static int zh_enqueue_files_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_
 // streams forked from it; captured into a hipGraph the first time a (batch size, input pointer) pair is seen and replayed
 // afterwards: one graph launch per batch.
 static uint32_t zh_files_run_lo(const zultra_hip_ctx_t *c, uint32_t nblocks, int k) { return (uint32_t)((uint64_t)nblocks * (uint64_t)k / (uint64_t)c->last_runs); }
+
+// what follows the runs of a files batch, on the stream that has waited for them: the descriptors in batch order, and the copies of what the host reads
+static int zh_enqueue_files_tail(zultra_hip_ctx_t *c, uint32_t nblocks, hipStream_t st0) {
+   uint32_t run_b0[ZH_MAX_RUNS];
+   for (int k = 0; k < c->last_runs; k++) run_b0[k] = zh_files_run_lo(c, nblocks, k);
+   if (zh_enqueue_compact(c, run_b0, c->last_runs, st0) != 0) return -1;
+   ZH_CHECK(c, hipMemcpyAsync(c->h_adler, c->d_adler, 2 * (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));
+   ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results_compact, (size_t)nblocks * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st0));   // (one sub-block per input)
+   ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));
+   return 0;
+}
 
 static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nblocks, hipStream_t st0) {
    const int runs = c->last_runs;
@@ -1025,15 +1074,11 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nblocks, hipStream_t s
          if (c->stagger_ev) ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k - 1][2], 0));
       }
       const uint32_t b0 = zh_files_run_lo(c, nblocks, k), b1 = zh_files_run_lo(c, nblocks, k + 1);
-      if (zh_enqueue_files_run(c, k, b0, b1 - b0, st, c->side_stream[k]) != 0) return -1;
+      if (zh_enqueue_run(c, k, b0, b1 - b0, (uint64_t)(b1 - b0) * c->max_block, b0, b1 - b0, st, c->side_stream[k], NULL, 0) != 0) return -1;
       if (k) ZH_CHECK(c, hipEventRecord(c->lane_ev[k][17], st));
    }
    for (int k = 1; k < runs; k++) ZH_CHECK(c, hipStreamWaitEvent(st0, c->lane_ev[k][17], 0));   // join
-   ZH_CHECK(c, hipMemcpyAsync(c->h_adler, c->d_adler, 2 * (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));
-   ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results, (size_t)nblocks * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st0));
-   ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));
-   ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks, c->d_ntasks, ZH_NCNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));
-   return 0;
+   return zh_enqueue_files_tail(c, nblocks, st0);
 }
 
 static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
@@ -1043,8 +1088,8 @@ static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
       // 4 KiB in batches of 65 536: 621 k files/s as one run, 582 / 634 / 637 k as 2 / 3 / 4 runs: not worth leaving the graph for.
       // End of round 4: with a graph per run (below) a large batch is two runs — the second run's matchfinder fills the ~12 ms the first
       // spends in its last code build, literalisation and emission: 1 080 k -> 1 167 k files/s.
-      const uint64_t want = c->auto_runs ? ((c->files_run_graphs && nblocks >= 8192u && c->nlanes >= 2) ? 2u : 1u) : min((uint64_t)c->nlanes, (uint64_t)nblocks / 4u);
-      c->last_runs = (int)max((uint64_t)1, want);
+      const uint64_t want = c->auto_runs ? ((c->files_run_graphs && nblocks >= 8192u && c->nlanes >= 2) ? 2u : 1u) : zh_min64((uint64_t)c->nlanes, (uint64_t)nblocks / 4u);
+      c->last_runs = (int)zh_max64(1, want);
    }
 #ifndef ZH_EMU
    if (c->last_runs > 1 && c->files_run_graphs) {
@@ -1074,7 +1119,7 @@ static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
             for (int part = 1; part <= 2; part++) {
                const int g = 2 * k + part - 1;
                ZH_CHECK(c, hipStreamBeginCapture(sk, hipStreamCaptureModeThreadLocal));
-               const int rc = zh_enqueue_files_run(c, k, b0, b1 - b0, sk, c->side_stream[k], part);
+               const int rc = zh_enqueue_run(c, k, b0, b1 - b0, (uint64_t)(b1 - b0) * c->max_block, b0, b1 - b0, sk, c->side_stream[k], NULL, part);
                const hipError_t e = hipStreamEndCapture(sk, &G->graph[g]);
                if (rc != 0) return -1;
                ZH_CHECK(c, e);
@@ -1103,10 +1148,7 @@ static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
          if (k) ZH_CHECK(c, hipEventRecord(c->lane_ev[k][17], sk));
       }
       for (int k = 1; k < runs; k++) ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k][17], 0));
-      ZH_CHECK(c, hipMemcpyAsync(c->h_adler, c->d_adler, 2 * (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results, (size_t)nblocks * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
-      ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      ZH_CHECK(c, hipMemcpyAsync(c->h_ntasks, c->d_ntasks, ZH_NCNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      if (zh_enqueue_files_tail(c, nblocks, st) != 0) return -1;
    }
    else if (c->last_runs > 1) {
       // Several runs: launched directly, ~35 launches per run and batch. (Forking the runs' streams inside a stream capture crashes in
@@ -1141,18 +1183,7 @@ static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
    ZH_CHECK(c, hipEventRecord(c->lane_ev[0][16], st));
    ZH_CHECK(c, hipStreamSynchronize(st));
    ZH_CHECK(c, hipGetLastError());
-   for (uint32_t b = 0; b < nblocks; b++) {
-      c->split_cnt[b] = 1;
-      c->sub_base[b] = b;
-   }
-   c->results.assign(c->h_results, c->h_results + nblocks);
-   for (int k = 1; k < c->last_runs; k++) {   // sub-block descriptors in batch coordinates
-      const uint32_t b0 = zh_files_run_lo(c, nblocks, k), b1 = zh_files_run_lo(c, nblocks, k + 1);
-      for (uint32_t b = b0; b < b1; b++) {
-         c->results[b].block += b0;
-         c->results[b].bits_off += (uint64_t)b0 * c->slot_stride;
-      }
-   }
+   c->results.assign(c->h_results, c->h_results + nblocks);   // (batch coordinates: zh_compact_results)
    memcpy(c->crc.data(), c->h_crc, nblocks * sizeof(uint32_t));
    c->adler.assign(c->h_adler, c->h_adler + 2 * (size_t)nblocks);
    c->nsubs = nblocks;
@@ -1184,8 +1215,6 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    c->nblocks = nblocks;
    c->nsubs = 0;
    c->blocks.assign((const zh_block_t *)blocks, (const zh_block_t *)blocks + nblocks);
-   c->split_cnt.resize(nblocks);
-   c->sub_base.resize(nblocks);
    c->crc.resize(nblocks);
    c->payload_size = (size_t)nblocks * c->slot_stride;
    c->payload_on_host = 0;
@@ -1198,8 +1227,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    uint64_t batch_bytes = 0;
    for (uint32_t b = 0; b < nblocks; b++) batch_bytes += blocks[b].n;
    const uint64_t want_runs = c->auto_runs ? (batch_bytes >= (256ull << 20) ? 4u : 3u) : (uint64_t)c->nlanes;
-   const int lanes = c->last_runs = (int)max((uint64_t)1, min(want_runs, min((uint64_t)nblocks / 4u, batch_bytes >> 22)));   // at least four max-blocks and 4 MiB per run
-   const int mf_stop = getenv("ZH_MF_STOP") ? atoi(getenv("ZH_MF_STOP")) : 0;   // timing experiments only
+   const int lanes = c->last_runs = (int)zh_max64(1, zh_min64(want_runs, zh_min64((uint64_t)nblocks / 4u, batch_bytes >> 22)));   // at least four max-blocks and 4 MiB per run
    // run k = blocks [run_lo(k), run_lo(k + 1)): the first run may be given a smaller share (c->first_run_pct of an equal share), so that the
    // other runs' matchfinders start earlier
    auto run_lo = [&](int k) -> uint32_t {
@@ -1207,14 +1235,13 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       if (k >= lanes) return nblocks;
       // (a run is never empty: with ZULTRA_HIP_FIRST_RUN / _LAST_RUN below 25 and four max-blocks per run the shares rounded to 0, and a
       // zero-sized grid fails the batch)
-      const uint64_t first = max((uint64_t)1, (uint64_t)((uint64_t)nblocks * c->first_run_pct / (100ull * (uint64_t)lanes)));
+      const uint64_t first = zh_max64(1, (uint64_t)nblocks * c->first_run_pct / (100ull * (uint64_t)lanes));
       if (lanes < 3) return (uint32_t)(first + ((uint64_t)nblocks - first) * (uint64_t)(k - 1) / (uint64_t)(lanes - 1));
-      const uint64_t last = max((uint64_t)1, (uint64_t)((uint64_t)nblocks * c->last_run_pct / (100ull * (uint64_t)lanes)));   // likewise the last run: its passes are the tail of the batch
+      const uint64_t last = zh_max64(1, (uint64_t)nblocks * c->last_run_pct / (100ull * (uint64_t)lanes));   // likewise the last run: its passes are the tail of the batch
       const uint64_t mid = (uint64_t)nblocks - first - last;
       if (k == lanes - 1) return (uint32_t)(nblocks - last);
       return (uint32_t)(first + mid * (uint64_t)(k - 1) / (uint64_t)(lanes - 2));
    };
-   const uint64_t tasks_per_block = c->max_tasks / c->max_blocks;
    hipStream_t st0 = c->lane_stream[0];
 
    ZH_CHECK(c, hipEventRecord(c->lane_ev[0][0], st0));
@@ -1241,19 +1268,22 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    ZH_CHECK(c, hipEventRecord(c->ev_input, st0));
    if (c->files_mode) return zh_run_files(c, nblocks);
 
-   // ---- stages 1 and 2 of every run: match rows, token chain + barrier bitmap, splitter ----------------------------
+   // ---- every run, start to finish: nothing in it waits for the host (zh_enqueue_run) ---------------------------------------------
+   uint32_t run_b0[ZH_MAX_RUNS];
    for (int k = 0; k < lanes; k++) {
-      hipStream_t st = c->lane_stream[k];
+      hipStream_t st = c->lane_stream[k], side = c->side_stream[k];
       hipEvent_t *ev = c->lane_ev[k];
       const uint32_t b0 = run_lo(k), b1 = run_lo(k + 1);
       const uint32_t nb = b1 - b0;
-      const zh_block_t *blk = c->d_blocks + b0;
+      run_b0[k] = c->last_run_b0[k] = b0;
       if (k) {
          ZH_CHECK(c, hipStreamWaitEvent(st, c->ev_input, 0));
          // stagger the runs by one stage: this run's wide matchfinder kernels start when the previous run reaches its
          // narrow ones (token chain, splitter), so narrow and wide kernels of different runs share the chip
          if (c->stagger_ev) ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k - 1][c->stagger_ev], 0));
       }
+      uint64_t total_n = 0;
+      for (uint32_t b = b0; b < b1; b++) total_n += blocks[b].n;
       if (per_run_stage) {
          // this run's windows: from the first block's history to the last block's end (the 32 KiB in front of the run go up twice,
          // with the run before it: the same bytes)
@@ -1285,224 +1315,34 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       }
       ZH_CHECK(c, hipEventRecord(ev[1], st));
       const uint32_t sg0 = c->seg_base[b0], nsg = c->seg_base[b1] - sg0;   // this run's matchfinder segments
-      const zh_seg_t *sgs = c->d_segs + sg0;
-      uint32_t *sa = c->d_sort_a + (uint64_t)sg0 * c->sort_stride, *sb = c->d_sort_b + (uint64_t)sg0 * c->sort_stride;
-      uint2 *p3 = c->d_prev3 + (uint64_t)sg0 * c->sort_stride;
-      uint32_t *rn = c->d_runs + (uint64_t)sg0 * c->run_stride;
-      uint32_t *ctr = c->d_chunk_ctr + (size_t)sg0 * 2 + 3 * (size_t)k;   // this run's counters: 2 per segment + the three tickets
-      const uint32_t mf_grid = min(nsg, max(1u, c->num_cus * c->mf_cu_pct / 100u));   // persistent workgroups, one per CU (zh_matchfinder.h)
-      ZH_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nsg * 2 + 3) * sizeof(uint32_t), st));
-      // token bits are ORed into the payload slots: cleared here, long before stage 3 needs them (the fill runs next to the matchfinder)
-      ZH_CHECK(c, hipMemsetAsync(c->d_payload + (uint64_t)b0 * c->slot_stride, 0, (size_t)nb * c->slot_stride, st));
-      ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, rn, c->sort_stride, c->run_stride, mf_stop, nsg,
-                ctr + (size_t)nsg * 2 + 1, c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride, c->mf_lds_cap);
-      // the bigram classes that fit no chunk of zh_mf_group, noted by it (zh_mf_group_lds.h): a kernel of their own
-      if (c->mf_lds_cap && !mf_stop && c->seg_W > min((uint32_t)ZH_MFL_MAXCAP, max(c->mf_lds_cap, 16u)))
-         ZH_LAUNCH_LDS(zh_mf_group_big, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, (const uint32_t *)rn, c->sort_stride, c->run_stride, nsg, ctr + (size_t)nsg * 2 + 2,
-                       c->d_pay + (size_t)k * min((uint64_t)c->total_cus, (uint64_t)c->max_blocks * c->segs_per_block) * 3 * c->sort_stride);
-      ZH_CHECK(c, hipEventRecord(ev[2], st));
-      if (mf_stop) continue;   // timing experiment: the sorted arrays are incomplete, nothing downstream may run
-      // (segment descriptors carry batch-wide block indices: the rows go to d_match + block * match_stride)
-      // a run of fewer segments than CUs (one call on a few max-blocks: latency): the workgroups beyond one per segment find the tickets gone and help —
-      // a segment of a 64 KiB max-block is ~1500 chunks, shared while a helper's share stays above ZH_MF_HELP_MIN of them
-      const uint32_t fr_grid = min(max(1u, c->num_cus * c->mf_cu_pct / 100u), mf_grid * 8u);
-      ZH_LAUNCH_LDS(zh_mf_frontier<true>, fr_grid, ZH_MF_THREADS, ZH_MF_FRONTIER_LDS, st, c->cur_data, sgs, (const uint32_t *)sa, (const uint2 *)p3, (const uint32_t *)rn,
-                c->sort_stride, c->run_stride, c->d_match, c->match_stride, c->d_longest, c->tok_stride, ctr, nsg, 1u);
-      ZH_CHECK(c, hipEventRecord(ev[3], st));
-      // per-max-block CRC-32 (linear part) and Adler-32 for the framing's footer: they need the input only — here, not behind the run's last kernel
-      // where they were the tail of the batch
-      ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
-      if (zh_enqueue_tokenize(c, st, blk, b0, nb) != 0) return -1;
-#define ZH_LAUNCH_SPLIT(W_)                                                                                                                                   \
-   ZH_LAUNCH(zh_split<W_>, nb, 64 * W_, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), \
-             c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0)
-      {
-         const uint32_t sw = c->split_waves ? c->split_waves : (c->max_block > 131072 ? 16u : 8u);
-         if (sw >= 16)
-            ZH_LAUNCH_SPLIT(16);
-         else if (sw >= 8)
-            ZH_LAUNCH_SPLIT(8);
-         else if (sw >= 4)
-            ZH_LAUNCH_SPLIT(4);
-         else
-            ZH_LAUNCH_SPLIT(2);
-      }
-#undef ZH_LAUNCH_SPLIT
-      ZH_CHECK(c, hipMemcpyAsync(c->h_split_cnt + b0, c->d_split_cnt + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      ZH_CHECK(c, hipEventRecord(ev[4], st));
-   }
-   if (mf_stop) {
-      for (int k = 0; k < lanes; k++) ZH_CHECK(c, hipStreamSynchronize(c->lane_stream[k]));
-      (void)hipEventElapsedTime(&c->timing.group_ms, c->lane_ev[0][1], c->lane_ev[0][2]);
-      snprintf(c->err, sizeof(c->err), "ZH_MF_STOP set: stopped after zh_mf_group");
-      return -1;
-   }
-
-   // ---- stage 3 of every run: the sub-block coder, one kernel per step over the run (zh_encode.h) -------------------
-   uint32_t nsubs = 0;
-   uint32_t lane_sub0[ZH_MAX_RUNS], lane_nsubs[ZH_MAX_RUNS];
-   ZH_CHECK(c, hipMemsetAsync(c->d_ntasks, 0, ZH_NCNT * sizeof(uint32_t), st0));
-   ZH_CHECK(c, hipEventRecord(c->ev2[0], st0));
-   for (int k = 0; k < lanes; k++) {
-      hipStream_t st = c->lane_stream[k];
-      hipEvent_t *ev = c->lane_ev[k];
-      const uint32_t b0 = run_lo(k), b1 = run_lo(k + 1);
-      const uint32_t nb = b1 - b0;
-      const zh_block_t *blk = c->d_blocks + b0;
-      ZH_CHECK(c, hipEventSynchronize(ev[4]));   // split counts of this run are on the host; later runs keep the GPU busy meanwhile
-      uint32_t ns = 0;
-      uint64_t total_n = 0;
-      for (uint32_t b = b0; b < b1; b++) {
-         c->split_cnt[b] = c->h_split_cnt[b];
-         c->h_sub_base[b] = c->sub_base[b] = ns;   // sub-block indices are local to the run
-         ns += c->split_cnt[b];
-         total_n += blocks[b].n;
-      }
-      lane_sub0[k] = nsubs;
-      lane_nsubs[k] = ns;
-      nsubs += ns;
-      // per-sub-block and per-task buffers of the run start at its worst-case offset
-      const uint64_t s0 = (uint64_t)b0 * c->max_subs, t0 = (uint64_t)b0 * tasks_per_block;
-      zh_work_t *work = c->d_work + s0;
-      zh_sbstate_t *states = c->d_states + s0;
-      uint2 *taskmap = c->d_taskmap + t0;
-      uint32_t *ntasks = c->d_ntasks + (size_t)k * ZH_CNT_STRIDE;   // the run's counters (ZH_CNT_*); [ZH_CNT_TASKS] = its number of tasks
-      uint4 *segtasks = c->d_segtasks + (uint64_t)b0 * c->seg_tasks_per_block;
-      c->last_run_b0[k] = b0;
-      uint2 *segwaves = c->d_segwaves + (uint64_t)b0 * c->seg_items_per_block;
-      uint2 *segitems = c->d_segitems + (uint64_t)b0 * c->seg_items_per_block;
-      int16_t *vecs = c->d_vecs + (uint64_t)b0 * c->seg_items_per_block * 2 * ZH_VEC;
-      uint32_t *h_cnt = c->h_ntasks + ZH_NCNT + (size_t)k * ZH_CNT_STRIDE;   // read back before the passes are launched
-      uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM;
-      uint32_t *hugelist = c->d_hugelist + 4 * t0;   // four lists of task_grid entries each: three by zh_list_huge, the cut tasks given up on by zh_parse_segments
-      uint32_t *task_bits = c->d_task_bits + t0;
-      uint8_t *payload = c->d_payload + (uint64_t)b0 * c->slot_stride;
-      uint32_t *best = c->d_best + b0 * c->best_stride;
-      const uint64_t *bars = c->d_bars + b0 * c->bar_stride;
-      const zh_match_t *match = c->d_match + b0 * c->match_stride;
-      const uint32_t task_grid = (uint32_t)(total_n / ZH_TASK) + ns;   // >= number of tasks; surplus waves exit at once
-
-      if (k) ZH_CHECK(c, hipStreamWaitEvent(st, c->ev2[0], 0));         // task counters cleared
-      ZH_CHECK(c, hipMemcpyAsync(c->d_sub_base + b0, c->h_sub_base + b0, nb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-      ZH_LAUNCH(zh_plan_subblocks, (nb + 63) / 64, 64, st, blk, nb, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), c->tok_stride,
-                (const uint32_t *)(c->d_ntok + b0), (const uint32_t *)(c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1)),
-                (const uint32_t *)(c->d_split_cnt + b0), (const uint32_t *)(c->d_sub_base + b0), c->slot_stride, work, taskmap, ntasks);
-      ZH_LAUNCH(zh_sb_init, ns, 64, st, (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states);
-      uint32_t *sbflags = c->d_sbflags + s0;
-      ZH_CHECK(c, hipMemsetAsync(sbflags, 0, (size_t)ns * sizeof(uint32_t), st));
-      ZH_LAUNCH(zh_list_huge, task_grid, 64, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride), c->match_stride, hugelist, task_grid, segtasks, segitems, segwaves, c->cut_min, c->cut_len, ntasks, c->d_taskinfo + t0, sbflags,
-                (c->parse_lanes && task_grid <= c->coop_tasks) ? c->coop_small : (uint32_t)ZH_COOP_MIN);   // fewer tasks than CUs: what counts is the longest chain of steps, and a chain workgroup steps faster
-      // The sub-blocks without a chain task go through their four passes on their own, one wave each (zh_parse_loop.h): launched at once, on a
-      // stream of its own — nothing about it depends on the counts the host is about to read
-      if (c->use_loop) {
-         hipStream_t ls = c->loop_stream[k];
-         ZH_CHECK(c, hipEventRecord(c->loop_ev[k][0], st));
-         ZH_CHECK(c, hipStreamWaitEvent(ls, c->loop_ev[k][0], 0));
-         // (its workgroups live for milliseconds and hold 40 KB of LDS each: a matchfinder workgroup, which needs a CU to itself, would wait for
-         // them — they start when the batch's last matchfinder kernel has started / ended: ZULTRA_HIP_OWN_AFTER)
-         if (c->own_after && c->own_after <= 3) ZH_CHECK(c, hipStreamWaitEvent(ls, c->lane_ev[lanes - 1][c->own_after], 0));
-         ZH_LAUNCH(zh_parse_own<ZH_OWN_WAVES>, ns, 64 * ZH_OWN_WAVES, ls, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, states, best,
-                   c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, (const uint2 *)(c->d_taskinfo + t0), payload, (const uint32_t *)sbflags, ns, ntasks);
-         ZH_CHECK(c, hipEventRecord(c->loop_ev[k][1], ls));
-      }
-      // Does this run have chains at all? With none (text without long repeats) zh_parse_tasks gets the whole chip; with chains it
-      // runs as a bounded number of persistent waves per CU, so that the chain workgroups find room the moment they are launched.
-      ZH_CHECK(c, hipMemcpyAsync(h_cnt, ntasks, ZH_CNT_STRIDE * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      ZH_CHECK(c, hipEventRecord(ev[5], st));
-      ZH_CHECK(c, hipEventSynchronize(ev[5]));
-      // The cut tasks (zh_parse.h): many segments are throughput — four to a wave of zh_parse_segments, which also checks them; a few
-      // are latency — each one a job of zh_parse_chain (five times faster per position), which checks a task when its last segment is done.
-      const uint32_t nsegtasks = h_cnt[ZH_CNT_SEGTASKS], nsegs = h_cnt[ZH_CNT_SEGITEMS];
-      const bool seg_wide = nsegtasks && nsegs >= c->seg_wide;
-      const uint32_t nseg_chain = (nsegtasks && !seg_wide) ? nsegs : 0u;
-      const uint32_t nchains = h_cnt[ZH_CNT_VLONG] + h_cnt[ZH_CNT_LONG] + h_cnt[ZH_CNT_SHORT] + nseg_chain;
-      const bool run_chains = nchains || (seg_wide && c->demote_min);   // (a cut task that zh_parse_segments gives up on becomes a chain of the passes left)
-      const uint32_t chain_grid = min(nchains + (seg_wide && c->demote_min ? nsegtasks : 0u), (uint32_t)ZH_CHAIN_GRID);
-      const uint32_t persistent_grid = min(task_grid, c->num_cus * c->task_waves);
-      const bool by_pass = !c->use_loop || nchains || nsegtasks;   // some sub-block has a chain task: those go pass by pass, as all did before
-      const uint32_t *pass_flags = c->use_loop ? (const uint32_t *)sbflags : (const uint32_t *)NULL;
-      c->loop_had[k] = c->use_loop != 0;
-      for (int pass = 0; pass <= 3; pass++) {
-         // the tasks with barrier-free runs (zh_parse_chain: few workgroups, long) next to all the others
-         hipStream_t side = c->side_stream[k];
-#ifdef ZH_DEBUG_SKIP_BUILD   // probe builds only (tools/build_variant.sh ... -DZH_DEBUG_SKIP_BUILD): timing experiments with WRONG output — 1 no chain kernel, 2 no lanes kernel
-         const int dbg_skip = getenv("ZH_DEBUG_SKIP") ? atoi(getenv("ZH_DEBUG_SKIP")) : 0;
-#else
-         const int dbg_skip = 0;
-#endif
-         if (run_chains && !(dbg_skip & 1)) {
-            ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
-            ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
-            ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                      (const uint2 *)taskmap, (const uint32_t *)hugelist, task_grid, segtasks, (const uint2 *)segitems, vecs, nseg_chain, c->seg_whole,
-                      ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, ntasks + ZH_CNT_CHAIN_TICKET + pass,
-                      c->d_chain_trace ? c->d_chain_trace + 3 * (uint64_t)ZH_TRACE_SLOTS * (4 * k + pass) : (uint64_t *)NULL);
-            ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
-         }
-         if (seg_wide) {
-            // single-wave workgroups like zh_parse_tasks', but each carries four segments of thousands of positions — on a stream
-            // of their own they start with the pass
-            hipStream_t sg = c->seg_stream[k];
-            if (!run_chains || (dbg_skip & 1)) ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
-            ZH_CHECK(c, hipStreamWaitEvent(sg, c->side_ev[k][2 * pass], 0));
-            ZH_LAUNCH(zh_parse_segments, h_cnt[ZH_CNT_SEGWAVES], 64, sg, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                      (const uint2 *)taskmap, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, segtasks, (const uint2 *)segwaves, vecs, ntasks, hugelist + 3 * (size_t)task_grid, c->demote_min);
-            ZH_CHECK(c, hipEventRecord(c->seg_ev[k][pass], sg));
-         }
-         if ((dbg_skip & 2) || !by_pass) ;
-         else if (c->parse_lanes) {
-            const uint32_t tpw = zh_tasks_per_wave(c, task_grid);
-            const uint32_t lane_grid = (task_grid + tpw - 1) / tpw;
-            if (nchains || seg_wide || c->always_persistent)
-               ZH_LAUNCH(zh_parse_lanes, min(lane_grid, c->num_cus * c->lane_waves), 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass,
-                         ntasks + ZH_CNT_TASK_TICKET + pass, (const uint2 *)(c->d_taskinfo + t0), tpw, pass_flags);
-            else
-               ZH_LAUNCH(zh_parse_lanes, lane_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                         (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, c->d_cost + b0 * c->best_stride, hist_part, pass, (uint32_t *)NULL, (const uint2 *)(c->d_taskinfo + t0), tpw, pass_flags);
-         }
-         else if (nchains || seg_wide || c->always_persistent)
-            ZH_LAUNCH(zh_parse_tasks, persistent_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                      (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
-                      ntasks + ZH_CNT_TASK_TICKET + pass);
-         else
-            ZH_LAUNCH(zh_parse_tasks, task_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work,
-                      (const uint2 *)taskmap, (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, (uint32_t *)NULL);
-         if (seg_wide) ZH_CHECK(c, hipStreamWaitEvent(st, c->seg_ev[k][pass], 0));
-         if (run_chains && !(dbg_skip & 1)) ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
-         ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));
-         if (by_pass) ZH_LAUNCH(zh_sb_build, ns, 64, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, pass_flags, ntasks);
-         ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));
-      }
-      if (c->use_loop) ZH_CHECK(c, hipStreamWaitEvent(st, c->loop_ev[k][1], 0));   // every sub-block is through its passes
-      ZH_LAUNCH(zh_post_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)ntasks, (const zh_sbstate_t *)states, best, c->best_stride, task_bits, (const uint2 *)(c->d_taskinfo + t0));
-      ZH_CHECK(c, hipEventRecord(ev[14], st));
-      ZH_LAUNCH(zh_emit_tasks, task_grid, 64, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)ntasks, (const zh_sbstate_t *)states, (const uint32_t *)best, c->best_stride, (const uint32_t *)task_bits, payload,
-                c->d_results + s0, (const uint2 *)(c->d_taskinfo + t0));
-      ZH_CHECK(c, hipEventRecord(ev[15], st));
-      ZH_CHECK(c, hipMemcpyAsync(c->h_results + lane_sub0[k], c->d_results + s0, ns * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st));
+      ZH_CHECK(c, hipMemsetAsync(c->d_chunk_ctr + (size_t)sg0 * 2 + 3 * (size_t)k, 0, ((size_t)nsg * 2 + 3) * sizeof(uint32_t), st));
+      ZH_CHECK(c, hipMemsetAsync(c->d_ntasks + (size_t)k * ZH_CNT_STRIDE, 0, ZH_CNT_STRIDE * sizeof(uint32_t), st));   // the run's counters and tickets
+      // per-max-block CRC-32 (linear part) and Adler-32 for the framing's footer need the input only: on the run's side stream, next to its matchfinder
+      // (behind the run's last kernel they were the tail of the batch; behind its frontier, round 4, on the path to its first parse pass). The side
+      // stream's later kernels — the chains of every pass — are joined by the run's stream: so is this one.
+      ZH_CHECK(c, hipStreamWaitEvent(side, ev[1], 0));
+      ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, side, c->cur_data, (const zh_block_t *)(c->d_blocks + b0), (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
+      // token bits are ORed into the payload slots: cleared there too, long before stage 3 needs them
+      ZH_CHECK(c, hipMemsetAsync(c->d_payload + (uint64_t)b0 * c->slot_stride, 0, (size_t)nb * c->slot_stride, side));
+      if (zh_enqueue_run(c, k, b0, nb, total_n, sg0, nsg, st, side, c->seg_stream[k], 0) != 0) return -1;
       ZH_CHECK(c, hipMemcpyAsync(c->h_crc + b0, c->d_crc + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipMemcpyAsync(c->h_adler + 2 * (size_t)b0, c->d_adler + 2 * (size_t)b0, 2 * nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipEventRecord(ev[16], st));
    }
-   for (int k = 0; k < lanes; k++) ZH_CHECK(c, hipStreamSynchronize(c->lane_stream[k]));
-   ZH_CHECK(c, hipMemcpy(c->h_ntasks, c->d_ntasks, ZH_NCNT * sizeof(uint32_t), hipMemcpyDeviceToHost));
+   // behind the last run: the descriptors in stream order and batch coordinates, the counts — the first thing the host waits for
+   for (int k = 1; k < lanes; k++) ZH_CHECK(c, hipStreamWaitEvent(st0, c->lane_ev[k][16], 0));
+   if (zh_enqueue_compact(c, run_b0, lanes, st0) != 0) return -1;
+   ZH_CHECK(c, hipStreamSynchronize(st0));
    ZH_CHECK(c, hipGetLastError());
-   // sub-block descriptors in batch coordinates
+   const uint32_t nsubs = c->h_nsubs[0];
+   if (nsubs < nblocks || (uint64_t)nsubs > (uint64_t)nblocks * c->max_subs) {
+      snprintf(c->err, sizeof(c->err), "the device reports %u sub-blocks for %u max-blocks", nsubs, nblocks);
+      return -1;
+   }
+   ZH_CHECK(c, hipMemcpy(c->h_results, c->d_results_compact, (size_t)nsubs * sizeof(zh_subblock_t), hipMemcpyDeviceToHost));
    c->results.assign(c->h_results, c->h_results + nsubs);
    memcpy(c->crc.data(), c->h_crc, nblocks * sizeof(uint32_t));
    c->adler.assign(c->h_adler, c->h_adler + 2 * (size_t)nblocks);
-   for (int k = 0; k < lanes; k++) {
-      const uint32_t b0 = run_lo(k);
-      for (uint32_t i = 0; i < lane_nsubs[k]; i++) {
-         zh_subblock_t &r = c->results[lane_sub0[k] + i];
-         r.block += b0;
-         r.bits_off += (uint64_t)b0 * c->slot_stride;
-      }
-   }
    c->nsubs = nsubs;
 
    // device time per kernel group, summed over the runs (they overlap in wall time); total = first launch to last completion
@@ -1520,7 +1360,6 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          add(c->timing.parse_ms, ev[5 + 2 * pass], ev[6 + 2 * pass]);
          add(c->timing.build_ms, ev[6 + 2 * pass], ev[7 + 2 * pass]);
       }
-      if (c->loop_had[k]) add(c->timing.loop_ms, c->loop_ev[k][0], c->loop_ev[k][1]);
       add(c->timing.post_ms, ev[13], ev[14]);
       add(c->timing.emit_ms, ev[14], ev[15]);
       add(c->timing.d2h_ms, ev[15], ev[16]);
@@ -1562,37 +1401,72 @@ extern "C" int zultra_hip_block_crc32(const zultra_hip_ctx_t *c, uint32_t *out) 
    return (int)c->nblocks;
 }
 
+// The stream assembly of the last batch on the device: the scan that decides where every sub-block goes (zh_stitch_scan), then the kernel that puts
+// it there (zh_stitch). files: every max-block a stream of its own. One synchronisation, at the end, for the 80 bytes the scan reports.
+static int zh_stitch_on_device(zultra_hip_ctx_t *c, uint32_t phase, int final_block, int files, bool scan_only = false) {
+   ZH_CHECK(c, hipSetDevice(c->device));
+   hipStream_t st = c->stream;
+   ZH_CHECK(c, hipEventRecord(c->ev[0], st));
+   if (!scan_only) {
+      // the stream buffer must be zero where bits will be ORed in: everything the batch can fill — no sub-block takes more than its stored form,
+      // size + 5 bytes per 65535 + the three header bits
+      uint64_t bound = 16;
+      for (uint32_t b = 0; b < c->nblocks; b++) bound += (uint64_t)c->blocks[b].n + 5ull * (c->blocks[b].n / 65535u + 1u);
+      bound += 5ull * c->nsubs;
+      const size_t clear = (size_t)zh_min64((uint64_t)c->stream_cap + 16, (bound + 3) & ~3ull);
+      ZH_CHECK(c, hipMemsetAsync(c->d_stream, 0, clear, st));
+   }
+   ZH_LAUNCH(zh_stitch_scan, 1, ZH_SCAN_THREADS, st, (const zh_subblock_t *)c->d_results_compact, (const uint32_t *)c->d_nsubs, c->nblocks, phase,
+             files ? (c->max_block < ZH_MIN_BLOCK ? (uint32_t)ZH_MIN_BLOCK : c->max_block) : c->max_block, final_block, files, c->d_blk_start, c->d_items, c->d_file_off, c->d_scan_out);
+   if (!scan_only)
+      ZH_LAUNCH(zh_stitch, c->nsubs, ZH_STITCH_THREADS, st, (const zh_subblock_t *)c->d_results_compact, (const zh_stitch_item_t *)c->d_items, (const zh_block_t *)c->d_blocks, c->cur_data,
+                (const uint8_t *)c->d_payload, c->d_stream, (const zh_scan_out_t *)c->d_scan_out, (uint64_t)c->stream_cap);
+   ZH_CHECK(c, hipEventRecord(c->ev[1], st));
+   ZH_CHECK(c, hipMemcpyAsync(c->h_scan_out, c->d_scan_out, sizeof(zh_scan_out_t), hipMemcpyDeviceToHost, st));
+   ZH_CHECK(c, hipStreamSynchronize(st));
+   ZH_CHECK(c, hipGetLastError());
+   if (!scan_only) (void)hipEventElapsedTime(&c->timing.stitch_ms, c->ev[0], c->ev[1]);
+   if (c->h_scan_out->nsubs != c->nsubs) {
+      snprintf(c->err, sizeof(c->err), "stream assembly saw %u sub-blocks, the batch has %u", c->h_scan_out->nsubs, c->nsubs);
+      return -1;
+   }
+   if (scan_only) return 0;
+   if (c->h_scan_out->failed) {
+      snprintf(c->err, sizeof(c->err), "stream assembly overflows the per-block buffer bound (ZULTRA_ERROR_DST)");
+      return -2;
+   }
+   if (((c->h_scan_out->end_bit + 7) >> 3) + 8 > c->stream_cap) {
+      snprintf(c->err, sizeof(c->err), "stream buffer too small");
+      return -1;
+   }
+   return 0;
+}
+
 // Device stitch of the last batch. state->nacc = pending bits (phase) before the batch; on return state->nacc = pending
 // bits after it and *end_bit = total bits from the start of the byte that held the pending bits. The stream buffer
 // holds ceil(end_bit / 8) bytes; its first byte carries only this batch's bits (OR the caller's pending bits in).
 extern "C" int zultra_hip_stitch_device(zultra_hip_ctx_t *c, zultra_hip_bitstate_t *state, int final_block, uint64_t *end_bit) {
    ZH_EMU_SERIALIZE();
    if (!c || !state || !end_bit || c->nsubs == 0) return -1;
-   c->items.resize(c->nsubs);
-   uint64_t eb = 0;
-   if (zh_stitch_plan(state->nacc & 7u, c->results.data(), c->nsubs, c->max_block, final_block, c->items.data(), &eb) != 0) {
-      snprintf(c->err, sizeof(c->err), "stream assembly overflows the per-block buffer bound (ZULTRA_ERROR_DST)");
-      return -2;
-   }
-   const size_t nbytes = (size_t)((eb + 7) >> 3);
-   if (nbytes + 8 > c->stream_cap) {
-      snprintf(c->err, sizeof(c->err), "stream buffer too small");
-      return -1;
-   }
-   ZH_CHECK(c, hipSetDevice(c->device));
-   hipStream_t st = c->stream;
-   ZH_CHECK(c, hipEventRecord(c->ev[0], st));
-   ZH_CHECK(c, hipMemsetAsync(c->d_stream, 0, (nbytes + 8 + 3) & ~(size_t)3, st));
-   ZH_CHECK(c, hipMemcpyAsync(c->d_items, c->items.data(), c->nsubs * sizeof(zh_stitch_item_t), hipMemcpyHostToDevice, st));
-   ZH_CHECK(c, hipMemcpyAsync(c->d_results_compact, c->results.data(), c->nsubs * sizeof(zh_subblock_t), hipMemcpyHostToDevice, st));
-   ZH_LAUNCH(zh_stitch, c->nsubs, ZH_STITCH_THREADS, st, (const zh_subblock_t *)c->d_results_compact, (const zh_stitch_item_t *)c->d_items,
-             (const zh_block_t *)c->d_blocks, c->cur_data, (const uint8_t *)c->d_payload, c->d_stream);
-   ZH_CHECK(c, hipEventRecord(c->ev[1], st));
-   ZH_CHECK(c, hipStreamSynchronize(st));
-   ZH_CHECK(c, hipGetLastError());
-   (void)hipEventElapsedTime(&c->timing.stitch_ms, c->ev[0], c->ev[1]);
+   const int rc = zh_stitch_on_device(c, state->nacc & 7u, final_block, 0);
+   if (rc != 0) return rc;
+   const uint64_t eb = c->h_scan_out->end_bit;
    state->nacc = (uint32_t)(eb & 7);
    *end_bit = eb;
+   return 0;
+}
+
+// Where the last batch would end for each of the eight bit phases it could start at: end_bits[p] = its end bit had it started at phase p (origin: the
+// byte holding the p pending bits), failed bit p = that start overflows a max-block buffer (the reference fails with ZULTRA_ERROR_DST there). This is the
+// table a rank hands its neighbours when one stream is cut over several devices (zultra_amd/sharded.py): the bit length of a shard depends on the phase
+// it starts at, and the scan (zh_stitch_scan) computes all eight on the way. Nothing is written to the stream buffer.
+extern "C" int zultra_hip_stitch_phase_table(zultra_hip_ctx_t *c, uint64_t *end_bits /* 8 */, uint32_t *failed_mask) {
+   ZH_EMU_SERIALIZE();
+   if (!c || !end_bits || c->nsubs == 0 || c->files_mode) return -1;
+   const int rc = zh_stitch_on_device(c, 0, -1, 0, true);
+   if (rc != 0) return rc;
+   for (int p = 0; p < 8; p++) end_bits[p] = c->h_scan_out->table_end[p];
+   if (failed_mask) *failed_mask = c->h_scan_out->table_failed;
    return 0;
 }
 
@@ -1600,41 +1474,15 @@ extern "C" int zultra_hip_stitch_device(zultra_hip_ctx_t *c, zultra_hip_bitstate
 // sub-block, padded to a byte, libzultra.c:414-417), laid end to end in the stream buffer; file_off[b]..file_off[b+1]
 // are its bytes. Works for any context, it is what compressing each max-block with its own zultra_memory_compress gives.
 extern "C" int zultra_hip_stitch_files(zultra_hip_ctx_t *c, uint64_t *file_off /* nblocks + 1 */) {
+   ZH_EMU_SERIALIZE();
    if (!c || !file_off || c->nsubs == 0) return -1;
-   c->items.resize(c->nsubs);
-   uint64_t bit = 0;
-   uint32_t k = 0;
-   for (uint32_t b = 0; b < c->nblocks; b++) {
-      uint32_t k1 = k;
-      while (k1 < c->nsubs && c->results[k1].block == b) k1++;
-      uint64_t eb = 0;
-      file_off[b] = bit >> 3;
-      if (zh_stitch_plan(0, c->results.data() + k, k1 - k, c->max_block < ZH_MIN_BLOCK ? (uint32_t)ZH_MIN_BLOCK : c->max_block, (int)b, c->items.data() + k, &eb) != 0) {
-         snprintf(c->err, sizeof(c->err), "stream assembly overflows the per-block buffer bound (ZULTRA_ERROR_DST)");
-         return -2;
-      }
-      for (uint32_t j = k; j < k1; j++) c->items[j].dst_bit += bit;
-      bit = (bit + eb + 7) & ~7ull;
-      k = k1;
+   if (!c->d_file_off) {   // (a context of max-blocks: allocated on first use)
+      ZH_CHECK(c, hipSetDevice(c->device));
+      if (zh_alloc(c, &c->d_file_off, (size_t)c->max_blocks + 1)) return -1;
    }
-   file_off[c->nblocks] = bit >> 3;
-   const size_t nbytes = (size_t)(bit >> 3);
-   if (nbytes + 8 > c->stream_cap) {
-      snprintf(c->err, sizeof(c->err), "stream buffer too small");
-      return -1;
-   }
-   ZH_CHECK(c, hipSetDevice(c->device));
-   hipStream_t st = c->stream;
-   ZH_CHECK(c, hipEventRecord(c->ev[0], st));
-   ZH_CHECK(c, hipMemsetAsync(c->d_stream, 0, (nbytes + 8 + 3) & ~(size_t)3, st));
-   ZH_CHECK(c, hipMemcpyAsync(c->d_items, c->items.data(), c->nsubs * sizeof(zh_stitch_item_t), hipMemcpyHostToDevice, st));
-   ZH_CHECK(c, hipMemcpyAsync(c->d_results_compact, c->results.data(), c->nsubs * sizeof(zh_subblock_t), hipMemcpyHostToDevice, st));
-   ZH_LAUNCH(zh_stitch, c->nsubs, ZH_STITCH_THREADS, st, (const zh_subblock_t *)c->d_results_compact, (const zh_stitch_item_t *)c->d_items,
-             (const zh_block_t *)c->d_blocks, c->cur_data, (const uint8_t *)c->d_payload, c->d_stream);
-   ZH_CHECK(c, hipEventRecord(c->ev[1], st));
-   ZH_CHECK(c, hipStreamSynchronize(st));
-   ZH_CHECK(c, hipGetLastError());
-   (void)hipEventElapsedTime(&c->timing.stitch_ms, c->ev[0], c->ev[1]);
+   const int rc = zh_stitch_on_device(c, 0, -1, 1);
+   if (rc != 0) return rc;
+   ZH_CHECK(c, hipMemcpy(file_off, c->d_file_off, ((size_t)c->nblocks + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
    return 0;
 }
 
@@ -1718,7 +1566,7 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
    memset(out, 0, sizeof(*out));
    out->blocks = c->nblocks;
    out->subblocks = c->nsubs;
-   for (int k = 0; k < ZH_MAX_RUNS; k++) {
+   for (int k = 0; k < c->last_runs && k < ZH_MAX_RUNS; k++) {   // (a run's counters are cleared when it is launched: only the last batch's runs count)
       const uint32_t *cnt = c->h_ntasks + (size_t)k * ZH_CNT_STRIDE;
       out->tasks += cnt[ZH_CNT_TASKS];
       out->huge_tasks += cnt[ZH_CNT_VLONG] + cnt[ZH_CNT_LONG] + cnt[ZH_CNT_SHORT] + cnt[ZH_CNT_SEGTASKS];
@@ -1757,8 +1605,9 @@ extern "C" int zultra_hip_get_matches(zultra_hip_ctx_t *c, uint32_t block, uint1
 extern "C" int zultra_hip_get_splits(zultra_hip_ctx_t *c, uint32_t block, int *out) {
    if (!c || block >= c->nblocks) return -1;
    ZH_CHECK(c, hipSetDevice(c->device));
-   uint32_t st[ZH_MAX_SPLITS + 1], nt = 0;
-   const uint32_t cnt = c->split_cnt[block];
+   uint32_t st[ZH_MAX_SPLITS + 1], nt = 0, cnt = 0;
+   ZH_CHECK(c, hipMemcpy(&cnt, c->d_split_cnt + block, sizeof(cnt), hipMemcpyDeviceToHost));   // (the host never needs the splitter's counts: fetched for this getter)
+   if (cnt > ZH_MAX_SPLITS) return -1;
    ZH_CHECK(c, hipMemcpy(st, c->d_split_tok + (uint64_t)block * (ZH_MAX_SPLITS + 1), sizeof(st), hipMemcpyDeviceToHost));
    ZH_CHECK(c, hipMemcpy(&nt, c->d_ntok + block, sizeof(nt), hipMemcpyDeviceToHost));
    for (uint32_t k = 0; k < cnt; k++) {

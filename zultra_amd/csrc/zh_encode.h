@@ -33,45 +33,97 @@
 
 #define ZH_OBUF_WORDS 128   // LDS staging window for token bits: 64 tokens x 48 bits = 96 dwords + carry
 
-// ---- work-list planning: one thread per max-block turns the token boundaries into sub-block work items ----
-// (libzultra.c:309-314: nBlockSize = nSplitOffset[k] - (nInStart + prev)). Sub-block k of block b gets the
-// payload slot starting at (block's slot base) + (offset of the sub-block in the block) + 64*k, so slots
-// never overlap and every slot can hold size+8 bytes. Each sub-block also reserves its run of the batch's task list.
-__global__ void zh_plan_subblocks(const zh_block_t *__restrict__ blocks, uint32_t nblocks, const uint32_t *__restrict__ tok_pos,
-                                  uint64_t tok_stride, const uint32_t *__restrict__ ntok, const uint32_t *__restrict__ split_tok,
-                                  const uint32_t *__restrict__ split_cnt, const uint32_t *__restrict__ sub_base /* exclusive scan of split_cnt */,
-                                  uint64_t slot_stride, zh_work_t *work, uint2 *taskmap, uint32_t *ntasks_total) {
-   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-   if (b >= nblocks) return;
-   const zh_block_t blk = blocks[b];
-   const uint32_t *tp = tok_pos + (uint64_t)b * tok_stride;
-   const uint32_t *st = split_tok + (uint64_t)b * (ZH_MAX_SPLITS + 1);
-   const uint32_t cnt = split_cnt[b];
-   const uint32_t nt = ntok[b];
-   for (uint32_t k = 0; k < cnt; k++) {
-      const uint32_t t0 = st[k], t1 = st[k + 1];
-      const uint32_t p0 = (t0 < nt) ? tp[t0] : blk.prev + blk.n;
-      const uint32_t p1 = (t1 < nt) ? tp[t1] : blk.prev + blk.n;
-      zh_work_t w;
-      w.block = b;
-      w.start = p0;
-      w.size = p1 - p0;
-      w.tok0 = t0;
-      w.tok1 = t1;
-      const uint32_t rel = p0 - blk.prev;
-      w.out_off = (uint64_t)b * slot_stride + ((rel + 3u) & ~3u) + 64u * k;
-      w.out_cap = ((p1 - p0) + 8u + 3u) & ~3u;
-      w.index = sub_base[b] + k;
-      w.ntasks = (w.size + ZH_TASK - 1) / ZH_TASK;
-      w.task_base = atomicAdd(ntasks_total, w.ntasks);
-      w.pad = 0;
-      for (uint32_t j = 0; j < w.ntasks; j++) {
-         uint2 e;
-         e.x = w.index;
-         e.y = j;
-         taskmap[w.task_base + j] = e;
+// ---- work-list planning: the splitter's token boundaries become sub-block work items --------------------------------------------------
+// (libzultra.c:303-314: nBlockSize = nSplitOffset[k] - (nInStart + prev)). Sub-block k of block b gets the payload slot starting at
+// (block's slot base) + (offset of the sub-block in the block) + 64*k, so slots never overlap and every slot can hold size+8 bytes.
+// ONE workgroup per run, a thread per max-block: the sub-block indices (stream order) and the task ranges are exclusive prefix sums over the
+// run's max-blocks, taken here — the reference simply loops (libzultra.c:303-324); rounds 1-4 read the splitter's counts back to the host,
+// summed them there and uploaded the bases: two host round trips in the middle of every run. The run's totals go to its counters
+// (cnt[ZH_CNT_NSUBS], cnt[ZH_CNT_TASKS]): every later kernel takes its bounds from there, the host sizes grids from the input bytes alone.
+// (THREADS: 256 for a run of a few thousand max-blocks — four waves of a dozen registers find room on a CU that a matchfinder workgroup of another run
+// fills, which a 1024-thread workgroup does not: it waited 2.5 ms for one on the 100 MB step; 1024 for the tens of thousands of inputs of a files batch)
+template <uint32_t ZH_PLAN_THREADS>
+__global__ void __launch_bounds__(ZH_PLAN_THREADS)
+zh_plan_subblocks(const zh_block_t *__restrict__ blocks, uint32_t nblocks, const uint32_t *__restrict__ tok_pos, uint64_t tok_stride, const uint32_t *__restrict__ ntok,
+                  const uint32_t *__restrict__ split_tok, const uint32_t *__restrict__ split_cnt, uint32_t *sub_base /* out: exclusive scan of split_cnt */,
+                  uint64_t slot_stride, zh_work_t *work, uint2 *taskmap, uint32_t *cnt /* the run's counters */) {
+   __shared__ uint32_t wsum[2][ZH_PLAN_THREADS / 64];
+   __shared__ uint32_t carry[2];
+   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+   if (tid < 2) carry[tid] = 0;
+   __syncthreads();
+   for (uint32_t b0 = 0; b0 < nblocks; b0 += ZH_PLAN_THREADS) {
+      const uint32_t b = b0 + tid;
+      const bool on = b < nblocks;
+      zh_block_t blk = {0, 0, 0};
+      uint32_t n_sub = 0, n_task = 0, nt = 0;
+      const uint32_t *tp = tok_pos, *st = split_tok;
+      if (on) {
+         blk = blocks[b];
+         tp = tok_pos + (uint64_t)b * tok_stride;
+         st = split_tok + (uint64_t)b * (ZH_MAX_SPLITS + 1);
+         n_sub = split_cnt[b];
+         nt = ntok[b];
+         uint32_t p0 = (st[0] < nt) ? tp[st[0]] : blk.prev + blk.n;
+         for (uint32_t k = 0; k < n_sub; k++) {
+            const uint32_t t1 = st[k + 1];
+            const uint32_t p1 = (t1 < nt) ? tp[t1] : blk.prev + blk.n;
+            n_task += (p1 - p0 + ZH_TASK - 1) / ZH_TASK;
+            p0 = p1;
+         }
       }
-      work[w.index] = w;
+      // exclusive prefix over the workgroup's max-blocks, of the sub-blocks and of the tasks
+      const uint32_t xs = zh_wave_excl_sum(n_sub), xt = zh_wave_excl_sum(n_task);
+      if (lane == 63) {
+         wsum[0][wave] = xs + n_sub;
+         wsum[1][wave] = xt + n_task;
+      }
+      __syncthreads();
+      uint32_t sub0 = carry[0] + xs, task0 = carry[1] + xt;
+      for (uint32_t w = 0; w < wave; w++) {
+         sub0 += wsum[0][w];
+         task0 += wsum[1][w];
+      }
+      __syncthreads();
+      if (tid == ZH_PLAN_THREADS - 1) {
+         carry[0] = sub0 + n_sub;
+         carry[1] = task0 + n_task;
+      }
+      if (on) {
+         sub_base[b] = sub0;
+         uint32_t p0 = (st[0] < nt) ? tp[st[0]] : blk.prev + blk.n;
+         for (uint32_t k = 0; k < n_sub; k++) {
+            const uint32_t t0 = st[k], t1 = st[k + 1];
+            const uint32_t p1 = (t1 < nt) ? tp[t1] : blk.prev + blk.n;
+            zh_work_t w;
+            w.block = b;
+            w.start = p0;
+            w.size = p1 - p0;
+            w.tok0 = t0;
+            w.tok1 = t1;
+            const uint32_t rel = p0 - blk.prev;
+            w.out_off = (uint64_t)b * slot_stride + ((rel + 3u) & ~3u) + 64u * k;
+            w.out_cap = ((p1 - p0) + 8u + 3u) & ~3u;
+            w.index = sub0 + k;
+            w.ntasks = (w.size + ZH_TASK - 1) / ZH_TASK;
+            w.task_base = task0;
+            w.pad = 0;
+            for (uint32_t j = 0; j < w.ntasks; j++) {
+               uint2 e;
+               e.x = w.index;
+               e.y = j;
+               taskmap[w.task_base + j] = e;
+            }
+            work[w.index] = w;
+            task0 += w.ntasks;
+            p0 = p1;
+         }
+      }
+      __syncthreads();   // the carries are in
+   }
+   if (tid == 0) {
+      cnt[ZH_CNT_NSUBS] = carry[0];
+      cnt[ZH_CNT_TASKS] = carry[1];
    }
 }
 
@@ -112,11 +164,9 @@ __device__ inline void zh_store_codes_wave(zh_sbstate_t *st, const zh_sb_ws_t *w
 }
 
 // ---- zh_sb_init: libzultra.c:317-324 and the start of zultra_block_deflate (blockdeflate.c:832-868) -------------
-__global__ void __launch_bounds__(64)
-zh_sb_init(const uint16_t *__restrict__ tok_info, uint64_t tok_stride, const zh_work_t *__restrict__ work, zh_sbstate_t *states) {
-   __shared__ zh_sb_ws_t ws;
-   const zh_work_t wk = work[blockIdx.x];
-   zh_sbstate_t *st = states + blockIdx.x;
+__device__ __forceinline__ void zh_sb_init_one(zh_sb_ws_t &ws, uint32_t sb, const uint16_t *__restrict__ tok_info, uint64_t tok_stride, const zh_work_t *__restrict__ work, zh_sbstate_t *states) {
+   const zh_work_t wk = work[sb];
+   zh_sbstate_t *st = states + sb;
    const uint16_t *ti = tok_info + (uint64_t)wk.block * tok_stride;
    const uint32_t lane = zh_lane();
 
@@ -162,6 +212,26 @@ zh_sb_init(const uint16_t *__restrict__ tok_info, uint64_t tok_stride, const zh_
       st->hdr_bits = 0;
       st->static_cost = static_cost;
       st->dynamic_cost = dynamic_cost;
+   }
+}
+
+// One wave per sub-block. How many sub-blocks the splitter made is known on the device only (cnt[ZH_CNT_NSUBS], zh_plan_subblocks): the host launches
+// the <false> form over a grid of what data usually gives (a few per max-block; surplus workgroups leave at once) and, behind it, the <true> form —
+// a few workgroups that stride over whatever lies beyond that grid (`first`), i.e. nearly always over nothing. (One kernel that strides over
+// everything keeps three times the registers: the early exits of a sub-block become branches inside a loop.)
+template <bool MORE>
+__global__ void __launch_bounds__(64)
+zh_sb_init(const uint16_t *__restrict__ tok_info, uint64_t tok_stride, const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint32_t *__restrict__ cnt /* the run's counters */,
+           uint32_t first) {
+   __shared__ zh_sb_ws_t ws;
+   const uint32_t nsubs = cnt[ZH_CNT_NSUBS];
+   if (!MORE) {
+      if (blockIdx.x < nsubs) zh_sb_init_one(ws, blockIdx.x, tok_info, tok_stride, work, states);
+      return;
+   }
+   for (uint32_t sb = first + blockIdx.x; sb < nsubs; sb += gridDim.x) {
+      zh_sync();   // the sub-block before this one is done with the workspace
+      zh_sb_init_one(ws, sb, tok_info, tok_stride, work, states);
    }
 }
 
@@ -347,14 +417,20 @@ __device__ __forceinline__ uint32_t zh_sb_build_one(zh_sb_ws_t &ws, const zh_wor
    return failed;
 }
 
-// sbflags != NULL: only the sub-blocks with a chain task (bit 0; zh_list_huge) — the others are rebuilt by the wave of zh_parse_loop that
-// finishes their pass (zh_parse_loop.h)
+// (one wave per sub-block; <false> over the usual grid, <true> strides over what lies beyond it: see zh_sb_init)
+template <bool MORE>
 __global__ void __launch_bounds__(64)
-zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint32_t *__restrict__ hist_part, uint8_t *payload, int pass, const uint32_t *__restrict__ sbflags,
-            uint32_t *cnt) {
+zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint32_t *__restrict__ hist_part, uint8_t *payload, int pass, uint32_t *cnt, uint32_t first) {
    __shared__ zh_sb_ws_t ws;
-   if (sbflags && !(sbflags[blockIdx.x] & 1u)) return;
-   (void)zh_sb_build_one(ws, work[blockIdx.x], states + blockIdx.x, hist_part, payload, pass, cnt);
+   const uint32_t nsubs = cnt[ZH_CNT_NSUBS];
+   if (!MORE) {
+      if (blockIdx.x < nsubs) (void)zh_sb_build_one(ws, work[blockIdx.x], states + blockIdx.x, hist_part, payload, pass, cnt);
+      return;
+   }
+   for (uint32_t sb = first + blockIdx.x; sb < nsubs; sb += gridDim.x) {
+      zh_sync();   // the sub-block before this one is done with the workspace
+      (void)zh_sb_build_one(ws, work[sb], states + sb, hist_part, payload, pass, cnt);
+   }
 }
 
 // ---- prices / sizes of the codes in a sub-block state, staged in LDS by the task kernels -------------------------
@@ -369,13 +445,9 @@ struct zh_task_ws_t {
 };
 
 // ---- zh_post_tasks: matches that are cheaper as literals (blockdeflate.c:410-458), then the bit count of the task --
-__global__ void __launch_bounds__(64)
-zh_post_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride,
-              const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total,
-              const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *task_bits, const uint2 *__restrict__ taskinfo) {
-   __shared__ zh_task_ws_t ws;
-   const uint32_t gt = blockIdx.x;
-   if (gt >= *ntasks_total) return;
+__device__ __forceinline__ void zh_post_task_one(zh_task_ws_t &ws, uint32_t gt, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars,
+                                                 uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
+                                                 uint32_t *best_all, uint64_t best_stride, uint32_t *task_bits, const uint2 *__restrict__ taskinfo) {
    const uint2 tm = taskmap[gt];
    const zh_work_t wk = work[tm.x];
    const zh_sbstate_t *st = states + tm.x;
@@ -472,6 +544,25 @@ zh_post_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ b
    if (lane == 0) task_bits[gt] = bits;
 }
 
+// One wave per task; the length of the run's task list is known on the device only: <false> over a grid of what data usually gives (surplus
+// workgroups leave at once), <true> a few workgroups that stride over what lies beyond it (see zh_sb_init).
+template <bool MORE>
+__global__ void __launch_bounds__(64)
+zh_post_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride,
+              const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total,
+              const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *task_bits, const uint2 *__restrict__ taskinfo, uint32_t first) {
+   __shared__ zh_task_ws_t ws;
+   const uint32_t ntasks = *ntasks_total;
+   if (!MORE) {
+      if (blockIdx.x < ntasks) zh_post_task_one(ws, blockIdx.x, data, blocks, bars, bar_stride, work, taskmap, states, best_all, best_stride, task_bits, taskinfo);
+      return;
+   }
+   for (uint32_t gt = first + blockIdx.x; gt < ntasks; gt += gridDim.x) {
+      zh_sync();   // the task before this one is done with the workspace
+      zh_post_task_one(ws, gt, data, blocks, bars, bar_stride, work, taskmap, states, best_all, best_stride, task_bits, taskinfo);
+   }
+}
+
 // ---- zh_emit_tasks: token emission (blockdeflate.c:471-507) -------------------------------------------------------
 // Adds `nb` bits of `code` per lane, in lane order, at bit position bitpos of the slot; complete dwords leave the LDS
 // window for HBM (the task's first dword may be shared with its predecessor: atomic OR). Returns the new position.
@@ -510,14 +601,10 @@ __device__ inline uint32_t zh_emit_tile(uint32_t *obuf, uint32_t *out, uint32_t 
    return newpos;
 }
 
-__global__ void __launch_bounds__(64)
-zh_emit_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride,
-              const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total,
-              const zh_sbstate_t *__restrict__ states, const uint32_t *__restrict__ best_all, uint64_t best_stride,
-              const uint32_t *__restrict__ task_bits, uint8_t *payload, zh_subblock_t *results, const uint2 *__restrict__ taskinfo) {
-   __shared__ zh_task_ws_t ws;
-   const uint32_t gt = blockIdx.x;
-   if (gt >= *ntasks_total) return;
+__device__ __forceinline__ void zh_emit_task_one(zh_task_ws_t &ws, uint32_t gt, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars,
+                                                 uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
+                                                 const uint32_t *__restrict__ best_all, uint64_t best_stride, const uint32_t *__restrict__ task_bits, uint8_t *payload,
+                                                 zh_subblock_t *results, const uint2 *__restrict__ taskinfo) {
    const uint2 tm = taskmap[gt];
    const zh_work_t wk = work[tm.x];
    const zh_sbstate_t *st = states + tm.x;
@@ -615,5 +702,23 @@ zh_emit_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ b
       r.nbits = nbits;
       r.bits_off = wk.out_off;
       results[wk.index] = r;
+   }
+}
+
+template <bool MORE>
+__global__ void __launch_bounds__(64)
+zh_emit_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride,
+              const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total,
+              const zh_sbstate_t *__restrict__ states, const uint32_t *__restrict__ best_all, uint64_t best_stride,
+              const uint32_t *__restrict__ task_bits, uint8_t *payload, zh_subblock_t *results, const uint2 *__restrict__ taskinfo, uint32_t first) {
+   __shared__ zh_task_ws_t ws;
+   const uint32_t ntasks = *ntasks_total;
+   if (!MORE) {
+      if (blockIdx.x < ntasks) zh_emit_task_one(ws, blockIdx.x, data, blocks, bars, bar_stride, work, taskmap, states, best_all, best_stride, task_bits, payload, results, taskinfo);
+      return;
+   }
+   for (uint32_t gt = first + blockIdx.x; gt < ntasks; gt += gridDim.x) {
+      zh_sync();   // the task before this one is done with the workspace
+      zh_emit_task_one(ws, gt, data, blocks, bars, bar_stride, work, taskmap, states, best_all, best_stride, task_bits, payload, results, taskinfo);
    }
 }

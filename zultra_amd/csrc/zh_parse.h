@@ -97,7 +97,8 @@ enum {
    ZH_CNT_TASKS = 0, ZH_CNT_VLONG, ZH_CNT_LONG, ZH_CNT_SHORT, ZH_CNT_HUGE_POS, ZH_CNT_SEGTASKS, ZH_CNT_SEGITEMS, ZH_CNT_SEG_FAILED,
    ZH_CNT_CHAIN_TICKET = 8, ZH_CNT_TASK_TICKET = 12, ZH_CNT_FIX_TICKET = 16, ZH_CNT_SEGWAVES = 20,
    ZH_CNT_SETTLED = 21 /* parse passes not run because the sub-block's prices had stopped moving (zh_sb_build_one) */, ZH_CNT_SETTLED_POS = 22 /* ... in KiB of input */,
-   ZH_CNT_DEMOTED = 23 /* cut tasks handed to zh_parse_chain as whole chains for the passes left (zh_parse_one_task) */, ZH_CNT_DEMOTED_PASS = 24 /* .. 27: listed in pass p */, ZH_CNT_STRIDE = 32
+   ZH_CNT_DEMOTED = 23 /* cut tasks handed to zh_parse_chain as whole chains for the passes left (zh_parse_one_task) */, ZH_CNT_DEMOTED_PASS = 24 /* .. 27: listed in pass p */,
+   ZH_CNT_NSUBS = 28 /* sub-blocks of the run (zh_plan_subblocks: the host never sees the splitter's counts) */, ZH_CNT_STRIDE = 32
 };
 
 // sub-block work item produced by zh_plan_subblocks
@@ -570,45 +571,43 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
    }
 }
 
-// ticket == NULL: one workgroup (= one wave) per task, the grid covers the task list. Otherwise the workgroups are persistent and
-// take tasks from *ticket: the host launches a BOUNDED number of them per CU when the pass also has chains (zh_parse_chain.h) —
-// a grid of tens of thousands of single-wave workgroups keeps every wave slot, register and LDS granule of the chip taken, and
-// the four-wave workgroup that carries the longest chain of the batch would wait for room until the grid has drained (measured,
-// tools/probes/chain2_probe.hip: a 3.6 ms chain next to such a grid ended after 25 ms).
-__global__ void __launch_bounds__(64)
-zh_parse_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match,
-               uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
-               const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states,
-               uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket) {
-   __shared__ zh_parse_ws_t ws;
-   const uint32_t ntasks = cnt[ZH_CNT_TASKS];
-   for (;;) {
-      uint32_t gt = blockIdx.x;
-      if (ticket) {
-         if (zh_lane() == 0) gt = atomicAdd(ticket, 1u);
-         gt = zh_readfirstlane(gt);
-      }
-      if (gt >= ntasks) return;
-      zh_sync();   // (persistent form) the previous task is done with the workspace
-      zh_parse_one_task<false>(ws, gt, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, 0u, 0u, 0u,
-                               (int16_t *)NULL, (uint32_t *)NULL, (uint32_t *)NULL, (uint32_t *)NULL, 0u);
-      if (!ticket) return;
-   }
+// Which of the two ways a run's cut tasks are parsed (see "speculative segments" above): many segments are throughput — four to a wave of
+// zh_parse_segments, which also checks them; a few are latency — each one a job of zh_parse_chain (five times faster per position). Decided on
+// the device from the run's counters (zh_list_huge), the same way by both kernels: the host launches both and never reads the counts.
+__device__ __forceinline__ bool zh_segments_are_wide(const uint32_t *cnt, uint32_t seg_wide_min) {
+   return cnt[ZH_CNT_SEGTASKS] != 0 && cnt[ZH_CNT_SEGITEMS] >= seg_wide_min;
 }
 
-// The cut tasks (see "speculative segments" above): one workgroup (= one wave) per entry of segwaves, four segments each; the
-// wave that finishes a task checks it. Launched next to zh_parse_tasks and zh_parse_chain, on a stream of its own.
+// The cut tasks (see "speculative segments" above): one wave per entry of segwaves, four segments each; the wave that finishes a task
+// checks it. Launched next to zh_parse_lanes and zh_parse_chain, on a stream of its own. How many entries there are is known on the device only:
+// <false> over a bounded grid (surplus workgroups leave at once — all of them when zh_parse_chain takes the run's segments), <true> a few workgroups
+// that stride over what lies beyond it (see zh_sb_init, zh_encode.h).
+template <bool MORE>
 __global__ void __launch_bounds__(64)
 zh_parse_segments(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                   const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
                   const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint4 *segtasks,
                   const uint2 *__restrict__ segwaves, int16_t *vecs, uint32_t *cnt, uint32_t *demote_list /* the run's fourth chain list */,
-                  uint32_t demote_min /* a task with this many failed cuts in a pass is a whole chain from the next pass on; 0: never */) {
+                  uint32_t demote_min /* a task with this many failed cuts in a pass is a whole chain from the next pass on; 0: never */,
+                  uint32_t seg_wide_min /* fewer segments in the run: zh_parse_chain takes them */, uint32_t first) {
    __shared__ zh_parse_ws_t ws;
-   if (blockIdx.x >= cnt[ZH_CNT_SEGWAVES]) return;
-   const uint2 sw = segwaves[blockIdx.x];
-   const uint4 stask = segtasks[sw.x];
-   if (stask.y & ZH_CUT_DEMOTED) return;   // (set by the task's checker at the end of an earlier pass: every wave of the task sees it or none)
-   zh_parse_one_task<true>(ws, stask.x, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, stask.y, sw.y,
-                           stask.z, vecs, &segtasks[sw.x].w, cnt, demote_list, demote_min);
+   if (!zh_segments_are_wide(cnt, seg_wide_min)) return;
+   const uint32_t nwaves = cnt[ZH_CNT_SEGWAVES];
+   if (!MORE) {
+      if (blockIdx.x >= nwaves) return;
+      const uint2 sw = segwaves[blockIdx.x];
+      const uint4 stask = segtasks[sw.x];
+      if (stask.y & ZH_CUT_DEMOTED) return;   // (set by the task's checker at the end of an earlier pass: every wave of the task sees it or none)
+      zh_parse_one_task<true>(ws, stask.x, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, stask.y, sw.y,
+                              stask.z, vecs, &segtasks[sw.x].w, cnt, demote_list, demote_min);
+      return;
+   }
+   for (uint32_t w = first + blockIdx.x; w < nwaves; w += gridDim.x) {
+      zh_sync();   // the entry before this one is done with the workspace
+      const uint2 sw = segwaves[w];
+      const uint4 stask = segtasks[sw.x];
+      if (stask.y & ZH_CUT_DEMOTED) continue;
+      zh_parse_one_task<true>(ws, stask.x, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, stask.y, sw.y,
+                              stask.z, vecs, &segtasks[sw.x].w, cnt, demote_list, demote_min);
+   }
 }

@@ -419,14 +419,10 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
 // Tasks of at least seg_min positions that are not periodic are cut into segments (zh_parse.h): listed in segtasks, with one
 // entry of segitems per segment (for zh_parse_chain) and one entry of segwaves per four segments (for zh_parse_segments): the
 // host picks one of the two ways by the number of segments in the run.
-__global__ void __launch_bounds__(64)
-zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
-             const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ longest, uint64_t longest_stride, uint32_t *hugelist, uint32_t cap, uint4 *segtasks,
-             uint2 *segitems, uint2 *segwaves, uint32_t seg_min, uint32_t cut_len, uint32_t *cnt, uint2 *taskinfo, uint32_t *sbflags /* zeroed; bit 0: the sub-block has a listed task */,
-             uint32_t coop_min /* <= ZH_COOP_MIN: tasks with a longer barrier-free piece are listed */) {
-   __shared__ uint32_t bnd[ZH_MAXPIECES + 1];
-   const uint32_t gt = blockIdx.x;
-   if (gt >= cnt[ZH_CNT_TASKS]) return;
+__device__ __forceinline__ void zh_list_huge_one(uint32_t *bnd /* LDS, ZH_MAXPIECES + 1 */, uint32_t gt, const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride,
+                                                 const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ longest, uint64_t longest_stride,
+                                                 uint32_t *hugelist, uint32_t cap, uint4 *segtasks, uint2 *segitems, uint2 *segwaves, uint32_t seg_min, uint32_t cut_len, uint32_t *cnt,
+                                                 uint2 *taskinfo, uint32_t coop_min) {
    const uint2 tm = taskmap[gt];
    const zh_work_t wk = work[tm.x];
    const uint32_t prev = blocks[wk.block].prev;
@@ -441,7 +437,6 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
    // barrier bitmap, 64 positions per dependent load — on data with few barriers that was a third of that kernel's time
    if (lane == 0) taskinfo[gt] = make_uint2(t0, t1 | (huge ? 0x80000000u : 0u));
    if (!huge) return;
-   if (lane == 0 && sbflags) atomicOr(&sbflags[tm.x], 1u);
    const uint32_t len = t1 - t0;
    if (len >= seg_min) {
       // periodic? (a 258-byte match at most positions: the costs 258 apart copy each other, a speculative start never converges)
@@ -485,6 +480,29 @@ zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__
       else
          hugelist[2u * cap + atomicAdd(&cnt[ZH_CNT_SHORT], 1u)] = gt;
       atomicAdd(&cnt[ZH_CNT_HUGE_POS], len);
+   }
+}
+
+// One wave per task; the length of the run's task list is known on the device only (cnt[ZH_CNT_TASKS], zh_plan_subblocks): <false> over a grid of what data
+// usually gives (surplus workgroups leave at once), <true> a few workgroups that stride over what lies beyond it (see zh_sb_init).
+// coop_min: tasks with a longer barrier-free piece are listed; a run of at most small_tasks tasks (one call on a few max-blocks: what counts is
+// the longest chain of steps, and a chain workgroup steps faster) lists from coop_small on.
+template <bool MORE>
+__global__ void __launch_bounds__(64)
+zh_list_huge(const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work,
+             const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ longest, uint64_t longest_stride, uint32_t *hugelist, uint32_t cap, uint4 *segtasks,
+             uint2 *segitems, uint2 *segwaves, uint32_t seg_min, uint32_t cut_len, uint32_t *cnt, uint2 *taskinfo,
+             uint32_t coop_min /* <= ZH_COOP_MIN */, uint32_t coop_small /* <= coop_min */, uint32_t small_tasks, uint32_t first) {
+   __shared__ uint32_t bnd[ZH_MAXPIECES + 1];
+   const uint32_t ntasks = cnt[ZH_CNT_TASKS];
+   const uint32_t cm = ntasks <= small_tasks ? coop_small : coop_min;
+   if (!MORE) {
+      if (blockIdx.x < ntasks) zh_list_huge_one(bnd, blockIdx.x, blocks, bars, bar_stride, work, taskmap, longest, longest_stride, hugelist, cap, segtasks, segitems, segwaves, seg_min, cut_len, cnt, taskinfo, cm);
+      return;
+   }
+   for (uint32_t gt = first + blockIdx.x; gt < ntasks; gt += gridDim.x) {
+      zh_sync();   // the task before this one is done with bnd
+      zh_list_huge_one(bnd, gt, blocks, bars, bar_stride, work, taskmap, longest, longest_stride, hugelist, cap, segtasks, segitems, segwaves, seg_min, cut_len, cnt, taskinfo, cm);
    }
 }
 
@@ -595,7 +613,7 @@ __global__ void __launch_bounds__(ZH_CHAIN_THREADS) ZH_CHAIN_VGPR_ATTR
 zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
                const uint32_t *__restrict__ hugelist, uint32_t cap, uint4 *segtasks, const uint2 *__restrict__ segitems, int16_t *vecs,
-               uint32_t nseg /* the run's segments if they are parsed here, else 0 */, uint32_t seg_whole /* ... cut tasks shorter than this as one job */,
+               uint32_t seg_wide_min /* a run with fewer segments than this has them parsed here, one job each (zh_segments_are_wide) */, uint32_t seg_whole /* ... cut tasks shorter than this as one job */,
                uint32_t *cnt, const zh_sbstate_t *__restrict__ states,
                uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint32_t *ticket, uint64_t *trace /* diagnostics (ZULTRA_HIP_CHAIN_TRACE): per ticket {positions, start, end} on the 100 MHz clock, or NULL */) {
    __shared__ zh_chain_ws_t ws;
@@ -605,7 +623,9 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
    // passes): whole chains, and the longest of the pass — they get the first tickets
    uint32_t ndem = 0;
    for (int q = 0; q < pass; q++) ndem += cnt[ZH_CNT_DEMOTED_PASS + q];
+   const uint32_t nseg = (cnt[ZH_CNT_SEGTASKS] != 0 && !zh_segments_are_wide(cnt, seg_wide_min)) ? cnt[ZH_CNT_SEGITEMS] : 0u;   // the run's segments if they are parsed here
    const uint32_t nvlong = ndem + cnt[ZH_CNT_VLONG], nlong = cnt[ZH_CNT_LONG], count = nvlong + nlong + nseg + cnt[ZH_CNT_SHORT];
+   if (count == 0) return;   // (the grid is launched whatever the run holds: nothing listed, nothing to take a ticket for)
    for (;;) {
       __syncthreads();   // the previous task's histogram has left LDS, s_item has been read
       if (tid == 0) s_item = atomicAdd(ticket, 1u);

@@ -528,10 +528,13 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    ZH_LP_COUNT(5, ZH_LP_CLOCK() - tic2);
 }
 
-// ticket == NULL: one workgroup (= one wave) per tasks_per_wave tasks, the grid covers the task list. The host gives a wave up to
-// ZH_LP_TASKS tasks — a pool of pieces large enough to keep its sixteen quads busy — but no more than it takes to give every wave slot
-// of the chip a wave: a small batch (one 40 KB input: 20 tasks) is a matter of latency, not of lane utilisation. Otherwise the workgroups are
-// persistent and take task groups from *ticket (see zh_parse_tasks: next to zh_parse_chain the host launches a bounded grid).
+// Single-wave workgroups take groups of tasks_per_wave consecutive tasks from *ticket until the run's task list — whose length only the device
+// knows (cnt[ZH_CNT_TASKS]) — is used up. The host gives a wave up to ZH_LP_TASKS tasks — a pool of pieces large enough to keep its sixteen quads
+// busy — but no more than it takes to give every wave slot of the chip a wave: a small batch (one 40 KB input: 20 tasks) is a matter of latency,
+// not of lane utilisation. Next to chains (zh_parse_chain, zh_parse_segments: the run's counters say whether it has any) only the first
+// `bounded` workgroups stay: a grid that keeps every wave slot, register and LDS granule of the chip taken would make the four-wave workgroup that
+// carries the longest chain of the batch wait for room until the grid has drained (measured, tools/probes/chain2_probe.hip: a 3.6 ms chain next to
+// such a grid ended after 25 ms).
 // (118 registers. Capped at 96 — a wave would then fit on a SIMD next to the four 104-register waves of another run's matchfinder
 // workgroup — the compiler spills 17 of them and the kernel takes 1.5 times as long: measured, not kept.)
 __global__ void __launch_bounds__(64)
@@ -539,9 +542,10 @@ zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
                const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all,
                uint32_t *hist_part, int pass, uint32_t *ticket, const uint2 *__restrict__ taskinfo, uint32_t tasks_per_wave /* 1 .. ZH_LP_TASKS */,
-               const uint32_t *__restrict__ sbflags /* != NULL: only sub-blocks with a chain task (bit 0); zh_parse_loop takes the others through all their passes */) {
+               uint32_t bounded /* workgroups that stay when the run has chains */) {
    __shared__ zh_lp_ws_t ws;
    const uint32_t ntasks = cnt[ZH_CNT_TASKS];
+   if (blockIdx.x >= bounded && (cnt[ZH_CNT_VLONG] | cnt[ZH_CNT_LONG] | cnt[ZH_CNT_SHORT] | cnt[ZH_CNT_SEGTASKS]) != 0u) return;
    for (;;) {
       uint32_t w = blockIdx.x;
       if (ticket) {
@@ -556,10 +560,6 @@ zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          const uint32_t sb = taskmap[g].x;
          uint32_t ge = g + 1;
          while (ge < g1 && taskmap[ge].x == sb) ge++;
-         if (sbflags && !(sbflags[sb] & 1u)) {
-            g = ge;
-            continue;
-         }
          zh_lp_group(ws, g, ge, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, cost_all, hist_part, pass, taskinfo);
          g = ge;
       }

@@ -12,11 +12,26 @@
 
 #define ZH_WAVE 64
 
+#ifdef ZH_TRACE_LAUNCH
+// probe builds only (tools/build_variant.sh trace -DZH_TRACE_LAUNCH): every launch is named on stderr, waited for, and its outcome printed — the
+// kernel a memory fault belongs to is the last one named
+#include <stdio.h>
+#define ZH_LAUNCH_LDS(kernel, grid, block, lds, stream, ...)                                                                    \
+   do {                                                                                                                         \
+      fprintf(stderr, "launch %s grid %u block %u\n", #kernel, (unsigned)(grid), (unsigned)(block));                            \
+      (void)hipDeviceSynchronize();                                                                                             \
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds), (hipStream_t)(stream), __VA_ARGS__);                           \
+      const hipError_t e_ = hipDeviceSynchronize();                                                                             \
+      fprintf(stderr, "   done %s: %s\n", #kernel, hipGetErrorString(e_));                                                      \
+   } while (0)
+#define ZH_LAUNCH(kernel, grid, block, stream, ...) ZH_LAUNCH_LDS(kernel, grid, block, 0, stream, __VA_ARGS__)
+#else
 #define ZH_LAUNCH(kernel, grid, block, stream, ...) \
    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (hipStream_t)(stream), __VA_ARGS__)
 // launch with `lds` bytes of dynamic LDS; the kernel declares it with ZH_DYN_LDS(name) and carves its arrays out of it
 #define ZH_LAUNCH_LDS(kernel, grid, block, lds, stream, ...) \
    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (lds), (hipStream_t)(stream), __VA_ARGS__)
+#endif
 #define ZH_DYN_LDS(name) extern __shared__ uint32_t name[]
 
 __device__ __forceinline__ unsigned zh_lane() { return __lane_id(); }

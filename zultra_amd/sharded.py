@@ -57,15 +57,18 @@ def phase_table(lib, ctx, max_block):
         tab[:, 0] = np.arange(8)
         tab[:, 1] = 1
         return tab
-    p, cnt = ctx.subblocks_raw()
-    dummy = (C.c_uint64 * 1)(0)
+    # the device scan of the stitcher walks the shard's descriptors once for all eight start phases (zh_stitch_scan): no host planning
+    ends = (C.c_uint64 * 8)()
+    failed = C.c_uint32(0)
+    lib.L.zultra_hip_stitch_phase_table.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    rc = lib.L.zultra_hip_stitch_phase_table(ctx.h, ends, C.byref(failed))
+    if rc != 0:
+        raise RuntimeError("zultra_hip_stitch_phase_table: %d %s" % (rc, lib.L.zultra_hip_last_error(ctx.h).decode()))
     for ph in range(8):
-        st = BitState(0, ph)
-        w = lib.L.zultra_hip_stitch(C.byref(st), p, cnt, None, None, dummy, max_block, -1, None, 0)
-        if w == _SIZE_MAX:
+        if (failed.value >> ph) & 1:
             tab[ph] = (ph, 0)   # the reference fails with ZULTRA_ERROR_DST at this phase; only an error if it is the true one
         else:
-            tab[ph] = (8 * w + st.nacc, 1)
+            tab[ph] = (int(ends[ph]), 1)
     return tab
 
 
