@@ -506,7 +506,10 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup, last_rank=None):
         raise RuntimeError("bench.py: rank 0 has no max-block (fewer max-blocks than ranks)")
     res = {"n": n, "nblocks": nblocks, "dt": dt, "stats": ctx.stats() if ctx is not None else None, "ctx": ctx, "d_data": d_data, "blocks": blocks}
     # what every rank spent where: device pipeline (first launch to last completion of a batch), the exchange steps of the assembly
-    mine = [float(np.mean([t["total_ms"] for t in timings])) if timings else 0.0, float(np.mean([c[0] for c in colls])), float(colls[-1][1]), float(colls[-1][2]), float(n)]
+    # (head = first launch to the end of the first run's matchfinder, tail = end of the last run's matchfinder to the last completion + the stitch: neither
+    # shrinks with the shard; what lies between does — DESIGN.md 5's model of N ranks on one stream, checkable from this line)
+    tm = (lambda k: float(np.mean([t[k] for t in timings])) if timings else 0.0)
+    mine = [tm("total_ms"), float(np.mean([c[0] for c in colls])), float(colls[-1][1]), float(colls[-1][2]), float(n), tm("head_ms"), tm("tail_ms") + tm("stitch_ms")]
     per_rank = [mine]
     if group and world > 1:
         tt = torch.tensor(mine, dtype=torch.float64, device=device)
@@ -514,7 +517,10 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup, last_rank=None):
         dist.all_gather(allr, tt)
         per_rank = [[float(x) for x in a.cpu().tolist()] for a in allr]
     res["per_rank"] = {"device_pipeline_ms": [round(p[0], 3) for p in per_rank], "collective_ms": [round(p[1], 3) for p in per_rank],
-                       "sent_bytes": [int(p[2]) for p in per_rank], "received_bytes_rank0": int(per_rank[0][3]), "input_bytes": [int(p[4]) for p in per_rank]}
+                       "sent_bytes": [int(p[2]) for p in per_rank], "received_bytes_rank0": int(per_rank[0][3]), "input_bytes": [int(p[4]) for p in per_rank],
+                       "head_ms": [round(p[5], 3) for p in per_rank], "tail_ms": [round(p[6], 3) for p in per_rank],
+                       "throughput_part_ms": [round(max(0.0, p[0] - p[5] - p[6]), 3) for p in per_rank],   # (tail_ms includes the stitch, which follows device_pipeline_ms: a lower bound)
+                       "model": "a rank's step = head + throughput part + tail; only the throughput part shrinks with the rank's share of ONE stream (DESIGN.md 5); unmeasured beyond the ranks of this run"}
     if rank == 0:
         # fold the ranks' checksum contributions in stream order
         total_in, chk = 0, (0 if flags == 2 else 1)

@@ -51,7 +51,7 @@ class SubBlock(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [(k, C.c_float) for k in ("h2d_ms", "matchfinder_ms", "tokenize_split_ms", "encode_ms", "d2h_ms", "total_ms",
-                                         "group_ms", "frontier_ms", "stitch_ms", "init_ms", "parse_ms", "build_ms", "post_ms", "emit_ms", "loop_ms")]
+                                         "group_ms", "frontier_ms", "stitch_ms", "init_ms", "parse_ms", "build_ms", "post_ms", "emit_ms", "head_ms", "tail_ms")]
 
 
 class Stats(C.Structure):

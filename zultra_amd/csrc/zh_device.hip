@@ -895,11 +895,12 @@ __global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, 
 // halves of a files-mode run captured as graphs of their own (zh_run_files).
 // A kernel whose item count only the device knows (sub-blocks, tasks, segment waves of a run): the <false> form over `grid_` workgroups, one item each (what data
 // usually gives; surplus workgroups leave at once), then the <true> form, ZH_MORE_GRID workgroups striding over what lies beyond grid_ — nearly always nothing.
+// (bound_: what the item count cannot exceed — a grid that covers it needs no second launch: a call on a few max-blocks is a matter of launches)
 #define ZH_MORE_GRID 256u
-#define ZH_LAUNCH_BOTH(kernel_, grid_, stream_, ...)                                              \
-   do {                                                                                           \
-      ZH_LAUNCH(kernel_<false>, (grid_), 64, stream_, __VA_ARGS__, 0u);                           \
-      ZH_LAUNCH(kernel_<true>, ZH_MORE_GRID, 64, stream_, __VA_ARGS__, (uint32_t)(grid_));        \
+#define ZH_LAUNCH_BOTH(kernel_, grid_, bound_, stream_, ...)                                                                  \
+   do {                                                                                                                       \
+      ZH_LAUNCH(kernel_<false>, (grid_), 64, stream_, __VA_ARGS__, 0u);                                                       \
+      if ((uint64_t)(grid_) < (uint64_t)(bound_)) ZH_LAUNCH(kernel_<true>, ZH_MORE_GRID, 64, stream_, __VA_ARGS__, (uint32_t)(grid_)); \
    } while (0)
 
 static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, uint64_t total_n, uint32_t sg0, uint32_t nsg, hipStream_t st, hipStream_t side, hipStream_t segst, int part) {
@@ -933,8 +934,10 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
    const uint32_t mf_grid = min(nsg, max(1u, c->num_cus * c->mf_cu_pct / 100u));   // persistent workgroups, one per CU (zh_matchfinder.h)
    // grids: bounded by what the input bytes allow, sized for what data usually gives; the kernels stride
    const uint32_t est_tasks = (uint32_t)zh_min64(cap, total_n / ZH_TASK + 2ull * nb);                                   // tasks: ~ bytes / 2048 + one per sub-block
-   const uint32_t task_grid = (uint32_t)zh_min64(cap, total_n / ZH_TASK + 4ull * nb);                                    // one wave per task (zh_list_huge, zh_post_tasks, zh_emit_tasks)
-   const uint32_t sb_grid = (uint32_t)zh_min64((uint64_t)nb * c->max_subs, zh_max64(4ull * nb, zh_min64(1024, (uint64_t)nb * c->max_subs)));   // one wave per sub-block (zh_sb_init, zh_sb_build)
+   const uint32_t task_grid = cap <= 2048u ? cap : (uint32_t)zh_min64(cap, total_n / ZH_TASK + 4ull * nb);               // one wave per task (zh_list_huge, zh_hist_tasks, zh_post_tasks, zh_emit_tasks)
+   const uint64_t sb_bound = (uint64_t)nb * c->max_subs;
+   const uint32_t sb_grid = (uint32_t)zh_min64(sb_bound, zh_max64(4ull * nb, 1024));   // one wave per sub-block (zh_sb_init, zh_sb_build)
+   const uint64_t seg_bound = (uint64_t)nb * c->seg_items_per_block;                     // entries of segwaves (zh_list_huge)
    if (part != 2) {
       ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, rn, c->sort_stride, c->run_stride, 0, nsg, ctr + (size_t)nsg * 2 + 1, pay,
                     c->mf_lds_cap);
@@ -980,9 +983,9 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
    else
       ZH_LAUNCH_PLAN(256u);
 #undef ZH_LAUNCH_PLAN
-   ZH_LAUNCH_BOTH(zh_sb_init, sb_grid, st, (const uint16_t *)(c->d_tok_info + (uint64_t)b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states, (const uint32_t *)cnt);
+   ZH_LAUNCH_BOTH(zh_sb_init, sb_grid, sb_bound, st, (const uint16_t *)(c->d_tok_info + (uint64_t)b0 * c->tok_stride), c->tok_stride, (const zh_work_t *)work, states, (const uint32_t *)cnt);
    // (inputs of a files batch are never cut into speculative segments: seg_min = all ones; a run of at most coop_tasks tasks counts as small)
-   ZH_LAUNCH_BOTH(zh_list_huge, task_grid, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride),
+   ZH_LAUNCH_BOTH(zh_list_huge, task_grid, cap, st, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride),
              c->match_stride, hugelist, cap, segtasks, segitems, segwaves, files ? 0xFFFFFFFFu : c->cut_min, files ? (uint32_t)ZH_CUT_LEN : c->cut_len, cnt, taskinfo, (uint32_t)ZH_COOP_MIN,
              files ? (uint32_t)ZH_COOP_MIN : c->coop_small, files ? 0u : c->coop_tasks);
    if (!files) ZH_CHECK(c, hipEventRecord(ev[5], st));   // (timing marks)
@@ -992,7 +995,7 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
    const uint32_t tpw = zh_tasks_per_wave(c, est_tasks);
    const uint32_t lane_grid = max(1u, min((est_tasks + tpw - 1) / tpw, c->num_cus * 16u));
    const uint32_t chain_grid = files ? min(nb, c->files_chain_grid) : (uint32_t)zh_min64(ZH_CHAIN_GRID, total_n / 256u + nb);
-   const uint32_t seg_grid = c->num_cus * 8u;
+   const uint32_t seg_grid = (uint32_t)zh_min64(c->num_cus * 8u, zh_max64(1, seg_bound));
    for (int pass = 0; pass <= 3; pass++) {
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
       ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
@@ -1002,7 +1005,7 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
       if (!files) {
          ZH_CHECK(c, hipStreamWaitEvent(segst, c->side_ev[k][2 * pass], 0));
-         ZH_LAUNCH_BOTH(zh_parse_segments, seg_grid, segst, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
+         ZH_LAUNCH_BOTH(zh_parse_segments, seg_grid, seg_bound, segst, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
                    (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, segtasks, (const uint2 *)segwaves, vecs, cnt, hugelist + 3 * (size_t)cap, c->demote_min, c->seg_wide);
          ZH_CHECK(c, hipEventRecord(c->seg_ev[k][pass], segst));
       }
@@ -1011,14 +1014,17 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
                 files ? 0xFFFFFFFFu : c->num_cus * c->lane_waves);
       if (!files) ZH_CHECK(c, hipStreamWaitEvent(st, c->seg_ev[k][pass], 0));
       ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
+      // the histogram of every task's parse, then the code builds from their sums
+      ZH_LAUNCH_BOTH(zh_hist_tasks, task_grid, cap, st, c->cur_data, blk, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, (const uint32_t *)best,
+                     c->best_stride, hist_part, pass, (const uint2 *)taskinfo);
       if (!files) ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));   // (timing marks)
-      ZH_LAUNCH_BOTH(zh_sb_build, sb_grid, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, cnt);
+      ZH_LAUNCH_BOTH(zh_sb_build, sb_grid, sb_bound, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, cnt);
       if (!files) ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));   // (timing marks)
    }
-   ZH_LAUNCH_BOTH(zh_post_tasks, task_grid, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best,
+   ZH_LAUNCH_BOTH(zh_post_tasks, task_grid, cap, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, best,
              c->best_stride, task_bits, (const uint2 *)taskinfo);
    if (!files) ZH_CHECK(c, hipEventRecord(ev[14], st));   // (timing marks)
-   ZH_LAUNCH_BOTH(zh_emit_tasks, task_grid, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states,
+   ZH_LAUNCH_BOTH(zh_emit_tasks, task_grid, cap, st, c->cur_data, blk, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states,
              (const uint32_t *)best, c->best_stride, (const uint32_t *)task_bits, payload, c->d_results + s0, (const uint2 *)taskinfo);
    if (!files) ZH_CHECK(c, hipEventRecord(ev[15], st));   // (timing marks)
    // per-max-block CRC-32 (linear part) and Adler-32 for the framing's footer (a batch of max-blocks computes them next to its matchfinder: zultra_hip_compress_blocks)
@@ -1367,6 +1373,11 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       if (hipEventElapsedTime(&tot, c->lane_ev[0][0], ev[16]) == hipSuccess && tot > c->timing.total_ms) c->timing.total_ms = tot;
    }
    (void)hipEventElapsedTime(&c->timing.h2d_ms, c->lane_ev[0][0], c->ev_input);
+   (void)hipEventElapsedTime(&c->timing.head_ms, c->lane_ev[0][0], c->lane_ev[0][3]);
+   {
+      float last_mf = 0;
+      if (hipEventElapsedTime(&last_mf, c->lane_ev[0][0], c->lane_ev[lanes - 1][3]) == hipSuccess) c->timing.tail_ms = c->timing.total_ms - last_mf;
+   }
    c->timing.matchfinder_ms = c->timing.group_ms + c->timing.frontier_ms;
    c->timing.encode_ms = c->timing.init_ms + c->timing.parse_ms + c->timing.build_ms + c->timing.post_ms + c->timing.emit_ms;
    return (int)nsubs;

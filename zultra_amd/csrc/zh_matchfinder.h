@@ -1195,24 +1195,30 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
       uint32_t fo = max(cur, 3u) - 3u;
       uint32_t ci = (mine && fo) ? (LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo)) : first4;
 
-      uint32_t cand = own;
+      // The feed's "no entry": marked like a class head, farther than any legal distance from every window position, and — unlike ZH_MF_SENTINEL — a
+      // position whose probe is a harmless read inside this kernel's LDS: the probes of a walk step are issued for every lane as it stands
+#define ZH_MF_FEED_NONE (ZH_MF_HEAD | (ZH_MF_LDS_WINDOW + 256u))
+      static_assert(ZH_MF_LDS_WINDOW + 256u + ZH_MAX_MATCH + 16u < ZH_MF_FRONTIER_LDS, "the feed's no-entry position lies inside the kernel's LDS");
+      uint32_t cand = t < M ? own : ZH_MF_FEED_NONE;
       int64_t vbase = (int64_t)c - 64;                            // sorted index of lane 0 of the feed vector
-      uint32_t vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_SENTINEL;
+      uint32_t vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_FEED_NONE;
       int vi = 63;
 
       // A candidate can only beat `cur` if its bytes fo..fo+3 equal ci: the 4-byte probe weeds out nearly all; the survivors get
       // their true match length from byte 0 (an entry of a neighbouring class met after the class head fails there) — the
       // first 16 bytes per lane against the lane's own 16 in registers, anything longer by the whole wave at once
-      // (zh_mf_extend_wave). The walk is a chain of LDS round trips with four waves per SIMD to hide them (round 2: eight to ten
-      // per step — probe, then the candidate's words one early exit at a time, then the record, for each of the two candidates);
-      // a step now has two for the common case: both probes together, then the first 16 bytes of both candidates together, with
-      // the lengths worked out without branches. A probe taken before `cur` grew stays a valid pre-filter.
+      // (zh_mf_extend_wave). The kernel is bound by the instructions it issues (round 5: fifteen more per step made it 8 % slower; its probes'
+      // bank conflicts in LDS do not matter), so a step is written for few of them:
+      //  * the probes are issued for every lane as it stands — a dead lane's, or one whose candidate is out of reach, is a harmless read —
+      //    instead of steering the lanes that should not probe to address 0;
+      //  * the lanes verify their survivors by RANK, not by candidate: in a round every lane with a survivor left takes its nearest one.
+      //    A step has a survivor in two or three of its four candidates (some lane's), but a lane rarely has more than one: rounds 1-4 ran the
+      //    verification once per candidate with a survivor in any lane, each time for a lane or two.
+      // A probe taken before `cur` grew stays a valid pre-filter.
       while (const uint64_t alive_mask_ = zh_ballot(alive)) {
          ZH_MF_WALK_TOP(alive_mask_);
          // advance ZH_MF_STEP times: entries c+l-1-Nk .. c+l-N-Nk arrive at lane l, nearest first; lane 0 takes the next entries below the chunk
-         uint32_t cs[ZH_MF_STEP], qs[ZH_MF_STEP], ds[ZH_MF_STEP], pbs[ZH_MF_STEP];
-         bool oks[ZH_MF_STEP], vs[ZH_MF_STEP];
-         uint64_t vms[ZH_MF_STEP];
+         uint32_t cs[ZH_MF_STEP], qs[ZH_MF_STEP], pbs[ZH_MF_STEP];
 #pragma unroll
          for (int k = 0; k < (int)ZH_MF_STEP; k++) {
             cand = zh_wave_shr1(cand, zh_readlane(vec, vi - k));
@@ -1221,39 +1227,34 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
          vi -= (int)ZH_MF_STEP;
          if (vi < 0) {
             vbase -= 64;
-            vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_SENTINEL;
+            vec = (vbase + lane >= 0) ? S[vbase + lane] : ZH_MF_FEED_NONE;
             vi = 63;
          }
-         // all the 4-byte probes of the step are issued before any is used; nearly every candidate dies here, so the verification
-         // below runs for few lanes (lanes that are done, or whose candidate is out of reach, probe offset 0: their position may be
-         // the sentinel)
-         uint32_t heads = 0;
-         bool okall = alive;
+         // all the 4-byte probes of the step are issued before any is used
 #pragma unroll
          for (int k = 0; k < (int)ZH_MF_STEP; k++) {
             qs[k] = cs[k] & ZH_MF_POS_MASK;
-            ds[k] = i - qs[k];
-            oks[k] = alive && ds[k] <= ZH_MAX_DIST;     // false for the sentinel too
-            const uint32_t ad = oks[k] ? qs[k] + fo : 0u;
-            pbs[k] = LDS_WIN ? zh_load32_at(lwin32, ad) : zh_ld32(win + ad);
-            heads |= cs[k];
-            okall = okall && oks[k];
+            pbs[k] = LDS_WIN ? zh_load32_at(lwin32, qs[k] + fo) : zh_ld32(win + ((alive && i - qs[k] <= ZH_MAX_DIST) ? qs[k] + fo : 0u));
          }
-         uint64_t vany = 0;
+         // the lane's survivors, nearest first: bit k of pend
+         uint32_t pend = 0, heads = 0;
 #pragma unroll
          for (int k = 0; k < (int)ZH_MF_STEP; k++) {
-            vs[k] = oks[k] && pbs[k] == ci;
-            vms[k] = zh_ballot(vs[k]);
-            vany |= vms[k];
+            pend |= (alive && i - qs[k] <= ZH_MAX_DIST && pbs[k] == ci) ? (1u << k) : 0u;   // (out of reach: false for the feed's no-entry too)
+            heads |= cs[k];
          }
+         // a class is ascending in position and walked downwards: while no head has been met, the step's last candidate is its farthest
+         const bool inreach = i - qs[ZH_MF_STEP - 1u] <= ZH_MAX_DIST;
          ZH_MF_WALK_PROBED();
-         if (vany) {   // (wave-uniform, and so are the branches on vms[k]: a candidate without a survivor in any lane costs nothing)
+         if (zh_ballot(pend != 0u)) {
             bool moved = false;   // a record of this step moved `cur`: the probes above were taken at the old one (still a valid pre-filter)
+            do {
+               const bool v = pend != 0u;
+               const uint32_t kk = v ? (uint32_t)__builtin_ctz(pend) : 0u;
+               pend &= pend - 1u;
+               uint32_t q = qs[0];
 #pragma unroll
-            for (int k = 0; k < (int)ZH_MF_STEP; k++) {
-               if (!vms[k]) continue;
-               const bool v = vs[k];
-               const uint32_t q = qs[k];
+               for (int k = 1; k < (int)ZH_MF_STEP; k++) q = kk == (uint32_t)k ? qs[k] : q;
                uint32_t f[4];
                if (LDS_WIN)
                   zh_load128_at(lwin32, v ? q : 0u, f);
@@ -1265,7 +1266,7 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
                // a candidate has to beat the record as it stands now. Sixteen bytes or fewer: its length is known. More: where the
                // record has moved since the probe, four bytes ending at the new record are probed first
                bool deep = v && l == 16 && maxlen > 16 && cur < maxlen;
-               if (k > 0 && zh_ballot(deep && moved)) {
+               if (zh_ballot(deep && moved)) {
                   if (deep && moved) {
                      const uint32_t fn = cur - 3u;
                      deep = LDS_WIN ? zh_load32_at(lwin32, q + fn) == zh_load32_at(lwin32, i + fn) : zh_ld32(win + q + fn) == zh_ld32(win + i + fn);
@@ -1279,21 +1280,22 @@ zh_mf_frontier(const uint8_t *__restrict__ data, const zh_seg_t *__restrict__ se
                l = min(l, maxlen);
                const bool rec = v && l > cur && (l < 16u || deep || maxlen <= 16u);
                if (rec) {
-                  myring[(nm & 7u) * ZH_MF_THREADS] = l | (ds[k] << 16);   // offset 32768 needs all 16 bits
+                  myring[(nm & 7u) * ZH_MF_THREADS] = l | ((i - q) << 16);   // offset 32768 needs all 16 bits
                   nm++;
                   cur = l;
                }
                moved = moved || rec;
-            }
+            } while (zh_ballot(pend != 0u));
             if (moved && cur < maxlen) {
-               fo = cur - 3;
+               fo = cur - 3;   // (a record of the class walk is at least 6)
                ci = LDS_WIN ? zh_load32_at(lwin32, i + fo) : zh_ld32(win + i + fo);
             }
             ZH_MF_WALK_VERIFIED();
          }
          // the class ends at its head; beyond 32 KiB everything else is farther still; 258 (or the window end) cannot be beaten
-         alive = okall && !(heads & ZH_MF_HEAD) && cur < maxlen;
+         alive = alive && inreach && !(heads & ZH_MF_HEAD) && cur < maxlen;
       }
+#undef ZH_MF_FEED_NONE
       ZH_MF_LAP(3);
       if (mine) {
          // rows are longest first: the ring read backwards from the last accepted match
