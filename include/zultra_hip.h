@@ -56,7 +56,7 @@ typedef struct zultra_hip_subblock_s {
 typedef struct zultra_hip_timing_s {
    float h2d_ms, matchfinder_ms, tokenize_split_ms, encode_ms, d2h_ms, total_ms;
    float group_ms, frontier_ms, stitch_ms;
-   float init_ms, parse_ms, build_ms, post_ms, emit_ms;   /* parts of encode_ms: planning + zh_sb_init + zh_list_huge, 4 x the parse kernels + zh_hist_tasks, 4 x zh_sb_build, zh_post_tasks, zh_emit_tasks
+   float init_ms, parse_ms, build_ms, post_ms, emit_ms;   /* parts of encode_ms: planning + zh_sb_init + zh_list_huge, 4 x the parse kernels, 4 x zh_sb_build, zh_post_tasks, zh_emit_tasks
                                                               (a batch runs as staggered runs on streams of their own: each figure is the SUM over the runs, which overlap in wall time) */
    float head_ms;                                          /* wall time from the batch's first launch to the end of the FIRST run's matchfinder: nothing of the batch can overlap it */
    float tail_ms;                                          /* wall time from the end of the LAST run's matchfinder to the batch's last completion: token chain, splitter, four parse / rebuild

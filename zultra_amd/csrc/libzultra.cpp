@@ -1005,8 +1005,13 @@ static size_t memory_compress_lanes(const unsigned char *pIn, size_t nIn, unsign
       }
       lanes = M.ctx.size();
       if (!lanes) return (size_t)-1;
-      threads.reserve(lanes);
-      for (size_t l = 0; l < lanes; l++) threads.emplace_back(mem_lane_thread, &M, l);
+      // (one lane with one job — a call on a few max-blocks, where 50 us of thread start-up and wake-ups count — runs on the calling thread)
+      if (lanes == 1 && M.jobs.size() == 1)
+         mem_lane_thread(&M, 0);
+      else {
+         threads.reserve(lanes);
+         for (size_t l = 0; l < lanes; l++) threads.emplace_back(mem_lane_thread, &M, l);
+      }
    } catch (...) {   // std::bad_alloc / std::system_error must not cross the C ABI
       {
          std::lock_guard<std::mutex> lk(M.m);

@@ -164,6 +164,8 @@ struct zultra_hip_ctx_s {
    size_t h_stage_size[2];
    // pinned host mirrors: async copies to pageable memory would block the host and serialise the runs
    uint32_t *h_crc;
+   zh_block_t *h_blocks;      // pinned staging of the batch's descriptors and segment list: an async copy from pageable memory is a blocking, staged one
+   zh_seg_t *h_segs;
    zh_subblock_t *h_results;
    zh_stitch_item_t *d_items;
    // stream assembly on the device (zh_stitch.h): the runs' descriptors laid end to end (d_results_compact, d_nsubs: total and per run), the first
@@ -526,6 +528,8 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    for (int k = 0; k < 2; k++)
       if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]);
    if (c->h_crc) (void)hipHostFree(c->h_crc);
+   if (c->h_blocks) (void)hipHostFree(c->h_blocks);
+   if (c->h_segs) (void)hipHostFree(c->h_segs);
    if (c->h_ntasks) (void)hipHostFree(c->h_ntasks);
    if (c->h_results) (void)hipHostFree(c->h_results);
    (void)hipFree(c->d_results_compact);
@@ -650,6 +654,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_scan_out, sizeof(zh_scan_out_t), 0));
       memset(c->h_nsubs, 0, (1 + ZH_MAX_RUNS) * sizeof(uint32_t));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_crc, B * sizeof(uint32_t), 0));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_blocks, B * sizeof(zh_block_t), 0));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_segs, B * c->segs_per_block * sizeof(zh_seg_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_ntasks, 2 * ZH_NCNT * sizeof(uint32_t), 0));   // a mirror of d_ntasks + per-run readbacks
       memset(c->h_ntasks, 0, 2 * ZH_NCNT * sizeof(uint32_t));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_adler, 2 * B * sizeof(uint32_t), 0));
@@ -847,7 +853,8 @@ static int zh_build_segments(zultra_hip_ctx_t *c, const zultra_hip_block_t *bloc
       snprintf(c->err, sizeof(c->err), "segment list overflows");
       return -1;
    }
-   ZH_CHECK(c, hipMemcpyAsync(c->d_segs, c->segs.data(), c->segs.size() * sizeof(zh_seg_t), hipMemcpyHostToDevice, st));
+   memcpy(c->h_segs, c->segs.data(), c->segs.size() * sizeof(zh_seg_t));
+   ZH_CHECK(c, hipMemcpyAsync(c->d_segs, c->h_segs, c->segs.size() * sizeof(zh_seg_t), hipMemcpyHostToDevice, st));
    return 0;
 }
 
@@ -934,7 +941,7 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
    const uint32_t mf_grid = min(nsg, max(1u, c->num_cus * c->mf_cu_pct / 100u));   // persistent workgroups, one per CU (zh_matchfinder.h)
    // grids: bounded by what the input bytes allow, sized for what data usually gives; the kernels stride
    const uint32_t est_tasks = (uint32_t)zh_min64(cap, total_n / ZH_TASK + 2ull * nb);                                   // tasks: ~ bytes / 2048 + one per sub-block
-   const uint32_t task_grid = cap <= 2048u ? cap : (uint32_t)zh_min64(cap, total_n / ZH_TASK + 4ull * nb);               // one wave per task (zh_list_huge, zh_hist_tasks, zh_post_tasks, zh_emit_tasks)
+   const uint32_t task_grid = cap <= 2048u ? cap : (uint32_t)zh_min64(cap, total_n / ZH_TASK + 4ull * nb);               // one wave per task (zh_list_huge, zh_post_tasks, zh_emit_tasks)
    const uint64_t sb_bound = (uint64_t)nb * c->max_subs;
    const uint32_t sb_grid = (uint32_t)zh_min64(sb_bound, zh_max64(4ull * nb, 1024));   // one wave per sub-block (zh_sb_init, zh_sb_build)
    const uint64_t seg_bound = (uint64_t)nb * c->seg_items_per_block;                     // entries of segwaves (zh_list_huge)
@@ -1014,9 +1021,6 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
                 files ? 0xFFFFFFFFu : c->num_cus * c->lane_waves);
       if (!files) ZH_CHECK(c, hipStreamWaitEvent(st, c->seg_ev[k][pass], 0));
       ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
-      // the histogram of every task's parse, then the code builds from their sums
-      ZH_LAUNCH_BOTH(zh_hist_tasks, task_grid, cap, st, c->cur_data, blk, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt, (const zh_sbstate_t *)states, (const uint32_t *)best,
-                     c->best_stride, hist_part, pass, (const uint2 *)taskinfo);
       if (!files) ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));   // (timing marks)
       ZH_LAUNCH_BOTH(zh_sb_build, sb_grid, sb_bound, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, cnt);
       if (!files) ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));   // (timing marks)
@@ -1269,7 +1273,8 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       if (!per_run_stage) ZH_CHECK(c, hipMemcpyAsync(c->d_data, data, data_size, hipMemcpyHostToDevice, st0));
       c->cur_data = c->d_data;
    }
-   ZH_CHECK(c, hipMemcpyAsync(c->d_blocks, blocks, nblocks * sizeof(zh_block_t), hipMemcpyHostToDevice, st0));
+   memcpy(c->h_blocks, blocks, nblocks * sizeof(zh_block_t));
+   ZH_CHECK(c, hipMemcpyAsync(c->d_blocks, c->h_blocks, nblocks * sizeof(zh_block_t), hipMemcpyHostToDevice, st0));
    if (zh_build_segments(c, blocks, nblocks, st0) != 0) return -1;
    ZH_CHECK(c, hipEventRecord(c->ev_input, st0));
    if (c->files_mode) return zh_run_files(c, nblocks);
@@ -1338,6 +1343,9 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    // behind the last run: the descriptors in stream order and batch coordinates, the counts — the first thing the host waits for
    for (int k = 1; k < lanes; k++) ZH_CHECK(c, hipStreamWaitEvent(st0, c->lane_ev[k][16], 0));
    if (zh_enqueue_compact(c, run_b0, lanes, st0) != 0) return -1;
+   // (the host's copy of the descriptors — the getters' — needs the count: a small batch copies what it can hold with the counts, one wait instead of two)
+   const bool copy_bound = (uint64_t)nblocks * c->max_subs * sizeof(zh_subblock_t) <= (256u << 10);
+   if (copy_bound) ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results_compact, (size_t)nblocks * c->max_subs * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st0));
    ZH_CHECK(c, hipStreamSynchronize(st0));
    ZH_CHECK(c, hipGetLastError());
    const uint32_t nsubs = c->h_nsubs[0];
@@ -1345,7 +1353,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       snprintf(c->err, sizeof(c->err), "the device reports %u sub-blocks for %u max-blocks", nsubs, nblocks);
       return -1;
    }
-   ZH_CHECK(c, hipMemcpy(c->h_results, c->d_results_compact, (size_t)nsubs * sizeof(zh_subblock_t), hipMemcpyDeviceToHost));
+   if (!copy_bound) ZH_CHECK(c, hipMemcpy(c->h_results, c->d_results_compact, (size_t)nsubs * sizeof(zh_subblock_t), hipMemcpyDeviceToHost));
    c->results.assign(c->h_results, c->h_results + nsubs);
    memcpy(c->crc.data(), c->h_crc, nblocks * sizeof(uint32_t));
    c->adler.assign(c->h_adler, c->h_adler + 2 * (size_t)nblocks);

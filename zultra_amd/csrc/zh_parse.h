@@ -559,7 +559,16 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
       demote_list[atomicAdd(&cnt[ZH_CNT_DEMOTED], 1u)] = gt;
       atomicAdd(&cnt[ZH_CNT_DEMOTED_PASS + pass], 1u);
    }
-   // (the histogram of the task's parse is taken behind the pass: zh_hist_tasks)
+   // ---- histogram of the task's parse; the per-sub-block sum is taken by zh_sb_build ------------------------------------
+   if (st->is_dynamic) {
+      __threadfence_block();
+      zh_sync();
+      for (uint32_t k = lane; k < ZH_NSYM; k += 64) ws.hist[k] = 0;
+      zh_sync();
+      zh_walk_histogram_wave(ws.hist, win, prev, t0, t1, best);
+      uint32_t *hp = hist_part + (uint64_t)gt * ZH_NSYM;
+      for (uint32_t k = lane; k < ZH_NSYM; k += 64) hp[k] = ws.hist[k];
+   }
 }
 
 // Which of the two ways a run's cut tasks are parsed (see "speculative segments" above): many segments are throughput — four to a wave of
@@ -600,41 +609,5 @@ zh_parse_segments(const uint8_t *__restrict__ data, const zh_block_t *__restrict
       if (stask.y & ZH_CUT_DEMOTED) continue;
       zh_parse_one_task<true>(ws, stask.x, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, stask.y, sw.y,
                               stask.z, vecs, &segtasks[sw.x].w, cnt, demote_list, demote_min);
-   }
-}
-
-
-// ---- zh_hist_tasks: the histogram of every task's parse (blockdeflate.c:371-400), behind a pass's parse kernels -----------------------------------
-// The parse runs backwards; which of its entries lie on the chosen path is known walking it forwards, tile by tile, the token chain of a tile followed
-// on the scalar unit — a chain of loads and scalar steps that issues next to nothing. Rounds 3-4 took it at the end of each parse kernel's work item: a
-// fifth of zh_parse_lanes' wave-cycles (tools/lp_profile.py), in waves of 118 registers whose slots are what that kernel is short of — and four waves of
-// a chain workgroup idling behind the one that walks. Here it is a wave of a dozen registers per task, eight to a SIMD, next to whatever else runs:
-// one launch between a pass's parse kernels and its zh_sb_build, which sums a sub-block's task slots. A task of a sub-block the pass skips — failed,
-// static after pass 0, settled (zh_lp_group, zh_chain_task) — keeps the histogram it has.
-// <false> one workgroup per task over the usual grid, <true> a few that stride over what lies beyond it (zh_sb_init, zh_encode.h).
-template <bool MORE>
-__global__ void __launch_bounds__(64)
-zh_hist_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
-              const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states, const uint32_t *__restrict__ best_all, uint64_t best_stride, uint32_t *hist_part, int pass,
-              const uint2 *__restrict__ taskinfo, uint32_t first) {
-   __shared__ uint32_t hist[ZH_NSYM];
-   const uint32_t ntasks = cnt[ZH_CNT_TASKS];
-   const uint32_t lane = zh_lane();
-   for (uint32_t gt = first + blockIdx.x; gt < ntasks; gt += gridDim.x) {
-      const uint2 tm = taskmap[gt];
-      const zh_sbstate_t *st = states + tm.x;
-      if (!(st->failed || !st->is_dynamic || st->settled)) {   // (a static sub-block's parse has no histogram to take: its codes are fixed)
-         const zh_work_t wk = work[tm.x];
-         const zh_block_t blk = blocks[wk.block];
-         zh_sync();   // the task before this one is done with the counters
-         for (uint32_t k = lane; k < ZH_NSYM; k += 64) hist[k] = 0;
-         zh_sync();
-         const uint2 ti = taskinfo[gt];
-         zh_walk_histogram_wave(hist, data + blk.win_off, blk.prev, ti.x, ti.y & 0x7fffffffu, best_all + (uint64_t)wk.block * best_stride);
-         zh_sync();
-         uint32_t *hp = hist_part + (uint64_t)gt * ZH_NSYM;
-         for (uint32_t k = lane; k < ZH_NSYM; k += 64) hp[k] = hist[k];
-      }
-      if (!MORE) return;
    }
 }

@@ -556,6 +556,18 @@ __device__ __forceinline__ void zh_chain_prices(zh_chain_ws_t &ws, const zh_sbst
    __syncthreads();
 }
 
+// histogram of the task's parse (the per-sub-block sum is taken by zh_sb_build). All threads.
+__device__ __forceinline__ void zh_chain_histogram(zh_chain_ws_t &ws, const zh_chain_task_t &T, uint32_t *hp) {
+   const uint32_t tid = threadIdx.x;
+   __threadfence_block();
+   __syncthreads();
+   for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) ws.hist[k] = 0;
+   __syncthreads();
+   zh_walk_histogram_wave(ws.hist, T.win, T.prev, (tid >> 6) == 0 ? T.t0 : T.t1, T.t1, T.best);   // the other waves walk nothing
+   zh_sync();   // (the walk ends with a sync of its own wave only: zh_parse_own calls it from waves that are not in step)
+   for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) hp[k] = ws.hist[k];
+}
+
 // The workgroup that finishes the last segment of a cut task checks the task: accept the segments whose speculated costs match
 // what their right neighbour left, parse the others again from there, then take the task's histogram. All threads call; the
 // prices of the pass are in ws.
@@ -587,8 +599,7 @@ __device__ inline void zh_chain_check_task(zh_chain_ws_t &ws, uint32_t *s_bad_p,
       __threadfence();
       __syncthreads();   // the new left vector is visible to the next comparison; the workspace is free
    }
-   (void)hist_part;   // (the task's histogram: zh_hist_tasks, behind the pass)
-   (void)gt;
+   if (T.st->is_dynamic) zh_chain_histogram(ws, T, hist_part + (uint64_t)gt * ZH_NSYM);
 }
 
 // Persistent workgroups take the listed items from a ticket: the grid is small and fixed (ZH_CHAIN_GRID), so it is dispatched at
@@ -672,7 +683,10 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          trace[3 * (uint64_t)item + 1] = trace_t0;
          trace[3 * (uint64_t)item + 2] = zh_wall_clock();
       }
-      if (whole) continue;   // (the task's histogram: zh_hist_tasks, behind the pass)
+      if (whole) {
+         if (T.st->is_dynamic) zh_chain_histogram(ws, T, hist_part + (uint64_t)gt * ZH_NSYM);
+         continue;
+      }
       // a segment: the task's segments are counted (the counter runs on over the passes), the workgroup that finishes the last one checks them
       __threadfence();   // this segment's parse entries and vectors are out
       __syncthreads();

@@ -82,6 +82,7 @@ struct alignas(16) zh_lp_ws_t {
          uint32_t outp[2][ZH_LP_C][4];          // the parse entries of two batches (by batch parity) ...
          uint32_t outc[2][ZH_LP_C][4];          // ... and their costs
       };
+      uint32_t hist[ZH_NSYM];                   // after the parse: histogram of the group
    };
    uint32_t plo[ZH_LP_MAXP], phi[ZH_LP_MAXP];   // the group's pieces: the long ones from the front, the others from the back
    uint32_t bnd[ZH_MAXPIECES + 1];
@@ -504,9 +505,26 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    ZH_LP_COUNT(2, ZH_LP_CLOCK() - tic1);
    const uint64_t tic2 = ZH_LP_CLOCK();
 
-   // (the histogram of the group's parse is taken behind the pass, by zh_hist_tasks: a fifth of this kernel's wave-cycles in rounds 3-4)
-   (void)parsed;
-   (void)sb_dynamic;
+   // ---- histogram of the group's parse; the per-sub-block sum is taken by zh_sb_build ------------------------------------
+   if (sb_dynamic) {
+      __threadfence_block();
+      zh_wave_sync();
+      for (uint32_t k = lane; k < ZH_NSYM; k += 64) ws.hist[k] = 0;
+      zh_wave_sync();
+      for (uint32_t gt = g0; gt < g1; gt++) {
+         if (!((parsed >> (gt - g0)) & 1ull)) continue;
+         const uint2 ti = taskinfo[gt];
+         zh_walk_histogram_wave(ws.hist, win, prev, ti.x, ti.y, best);
+      }
+      zh_wave_sync();
+      bool first = true;
+      for (uint32_t gt = g0; gt < g1; gt++) {
+         if (!((parsed >> (gt - g0)) & 1ull)) continue;
+         uint32_t *hp = hist_part + (uint64_t)gt * ZH_NSYM;
+         for (uint32_t k = lane; k < ZH_NSYM; k += 64) hp[k] = first ? ws.hist[k] : 0u;
+         first = false;
+      }
+   }
    ZH_LP_COUNT(5, ZH_LP_CLOCK() - tic2);
 }
 
