@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostics: device pipeline time of one 100 MB batch (first launch to last completion, HIP events) under different settings of the library's
-tuning knobs (environment variables read at context creation). usage: python tools/knob_sweep.py [bytes] [corpus] -- KEY=VAL,KEY=VAL ... (one group per setting)"""
+tuning knobs (environment variables read at context creation). The shipped library has its tuning knobs compiled in: build a probe library first —
+tools/build_variant.sh knobs -DZH_TUNING_KNOBS — and name it in KNOB_LIB=build/libzultra_amd_knobs.so.
+usage: KNOB_LIB=... python tools/knob_sweep.py [bytes] [corpus] -- KEY=VAL,KEY=VAL ... (one group per setting)"""
 import os
 import sys
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostics: throughput of N batches in flight on one GPU (one context and one host thread each, every batch the same 100 MB of
-real text) against one batch at a time. usage: python tools/two_in_flight.py [bytes] [threads] [batches per thread]"""
+real text) against one batch at a time. usage: python tools/two_in_flight.py [bytes] [threads] [batches per thread] [path of another build of the library]"""
 import os
 import sys
 import threading
@@ -16,7 +16,11 @@ size = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 nthreads = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 bs = 65536
-L = zultra_amd.lib()
+if len(sys.argv) > 4:
+    from zultra_amd._ffi import Lib
+    L = Lib(sys.argv[4])
+else:
+    L = zultra_amd.lib()
 d = corpus.real_text(size)
 size = len(d)
 nb = (size + bs - 1) // bs

@@ -156,8 +156,6 @@ struct zultra_hip_ctx_s {
    hipEvent_t lane_ev[ZH_MAX_RUNS][24];
    hipStream_t side_stream[ZH_MAX_RUNS];     // per run: zh_parse_chain runs next to zh_parse_tasks
    hipEvent_t side_ev[ZH_MAX_RUNS][8];       // per pass: fork, join
-   hipStream_t seg_stream[ZH_MAX_RUNS];      // per run: zh_parse_segments, likewise
-   hipEvent_t seg_ev[ZH_MAX_RUNS][4];        // per pass: join
    hipEvent_t ev_input;
    zh_subblock_t *d_results_compact;
    uint8_t *h_stage[2];         // pinned staging for callers that hand over pageable host memory (zultra_hip_staging)
@@ -513,9 +511,6 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
       for (int i = 0; i < 8; i++)
          if (c->side_ev[k][i]) (void)hipEventDestroy(c->side_ev[k][i]);
       if (c->side_stream[k]) (void)hipStreamDestroy(c->side_stream[k]);
-      for (int i = 0; i < 4; i++)
-         if (c->seg_ev[k][i]) (void)hipEventDestroy(c->seg_ev[k][i]);
-      if (c->seg_stream[k]) (void)hipStreamDestroy(c->seg_stream[k]);
    }
    if (c->ev_input) (void)hipEventDestroy(c->ev_input);
    for (int i = 0; i < 2; i++)
@@ -641,12 +636,6 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
             ZH_CHECK(c, hipStreamCreateWithPriority(&c->side_stream[k], hipStreamNonBlocking, hi_prio));
          }
          for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->side_ev[k][i]));
-         if (!c->files_mode) {
-            int lo_prio = 0, hi_prio = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
-            ZH_CHECK(c, hipStreamCreateWithPriority(&c->seg_stream[k], hipStreamNonBlocking, hi_prio));
-            for (int i = 0; i < 4; i++) ZH_CHECK(c, hipEventCreate(&c->seg_ev[k][i]));
-         }
       }
       ZH_CHECK(c, hipEventCreate(&c->ev_input));
       if (zh_alloc(c, &c->d_results_compact, B * c->max_subs)) return -1;
@@ -892,8 +881,8 @@ __global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, 
 }
 
 // The kernel sequence of one run of a batch — max-blocks b0 .. b0 + nb with `total_n` input bytes, matchfinder segments sg0 .. sg0 + nsg — with
-// NO HOST DECISION in it: run k on stream st, its chains on `side`, its cut tasks' segments on `segst` (not in files mode: inputs below 8192 bytes
-// are never cut). Everything the splitter decides — how many sub-blocks, hence how many tasks, chains, segments — stays on the device: zh_plan_subblocks
+// NO HOST DECISION in it: run k on stream st, its chains on `side` (a cut task's segments, when a run has many, in the first workgroups of zh_parse_lanes' grid; not in files
+// mode: inputs below 8192 bytes are never cut). Everything the splitter decides — how many sub-blocks, hence how many tasks, chains, segments — stays on the device: zh_plan_subblocks
 // sums it up into the run's counters, every later kernel takes its bounds from there, and the grids here are sized from the input bytes alone, as
 // bounded grids that stride over what there is (rounds 1-4 read the counts back twice per run, in the middle of the pipeline: 0.8-2.2 ms each on the
 // 100 MB step, profiles/r04_timeline_c2.txt). Per-block buffers are addressed as base + block * stride, so a run sees the base pointers advanced to its
@@ -910,7 +899,7 @@ __global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, 
       if ((uint64_t)(grid_) < (uint64_t)(bound_)) ZH_LAUNCH(kernel_<true>, ZH_MORE_GRID, 64, stream_, __VA_ARGS__, (uint32_t)(grid_)); \
    } while (0)
 
-static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, uint64_t total_n, uint32_t sg0, uint32_t nsg, hipStream_t st, hipStream_t side, hipStream_t segst, int part) {
+static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, uint64_t total_n, uint32_t max_n, uint32_t sg0, uint32_t nsg, hipStream_t st, hipStream_t side, int part) {
    const bool files = c->files_mode != 0;
    hipEvent_t *ev = c->lane_ev[k];
    const zh_block_t *blk = c->d_blocks + b0;
@@ -969,7 +958,7 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
 #define ZH_LAUNCH_SPLIT(W_)                                                                                                                                   \
    ZH_LAUNCH(zh_split<W_>, nb, 64 * W_, st, blk, (const uint32_t *)(c->d_tok_pos + b0 * c->tok_stride), (const uint16_t *)(c->d_tok_info + b0 * c->tok_stride), \
              c->tok_stride, (const uint32_t *)(c->d_ntok + b0), c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1), c->d_split_cnt + b0)
-      const uint32_t sw = c->split_waves ? c->split_waves : (c->max_block > 131072 ? 16u : 8u);
+      const uint32_t sw = c->split_waves ? c->split_waves : (max_n > 131072 ? 16u : 8u);   // (by the run's largest max-block, not the context's limit)
       if (sw >= 16)
          ZH_LAUNCH_SPLIT(16);
       else if (sw >= 8)
@@ -1010,16 +999,19 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
                 (const uint32_t *)hugelist, cap, segtasks, (const uint2 *)segitems, vecs, c->seg_wide, c->seg_whole, cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
                 cnt + ZH_CNT_CHAIN_TICKET + pass, (c->d_chain_trace && !files) ? c->d_chain_trace + 3 * (uint64_t)ZH_TRACE_SLOTS * (4 * k + pass) : (uint64_t *)NULL);
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
-      if (!files) {
-         ZH_CHECK(c, hipStreamWaitEvent(segst, c->side_ev[k][2 * pass], 0));
-         ZH_LAUNCH_BOTH(zh_parse_segments, seg_grid, seg_bound, segst, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                   (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass, segtasks, (const uint2 *)segwaves, vecs, cnt, hugelist + 3 * (size_t)cap, c->demote_min, c->seg_wide);
-         ZH_CHECK(c, hipEventRecord(c->seg_ev[k][pass], segst));
+      {
+         zh_seg_args_t sg;
+         sg.segtasks = segtasks;
+         sg.segwaves = (const uint2 *)segwaves;
+         sg.vecs = vecs;
+         sg.demote_list = hugelist + 3 * (size_t)cap;
+         sg.demote_min = c->demote_min;
+         sg.seg_wide_min = c->seg_wide;
+         sg.seg_grid = files ? 0u : seg_grid;
+         ZH_LAUNCH(zh_parse_lanes, sg.seg_grid + lane_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, cnt,
+                   (const zh_sbstate_t *)states, best, c->best_stride, cost, hist_part, pass, cnt + ZH_CNT_TASK_TICKET + pass, (const uint2 *)taskinfo, tpw,
+                   files ? 0xFFFFFFFFu : c->num_cus * c->lane_waves, sg);
       }
-      ZH_LAUNCH(zh_parse_lanes, lane_grid, 64, st, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap, (const uint32_t *)cnt,
-                (const zh_sbstate_t *)states, best, c->best_stride, cost, hist_part, pass, cnt + ZH_CNT_TASK_TICKET + pass, (const uint2 *)taskinfo, tpw,
-                files ? 0xFFFFFFFFu : c->num_cus * c->lane_waves);
-      if (!files) ZH_CHECK(c, hipStreamWaitEvent(st, c->seg_ev[k][pass], 0));
       ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
       if (!files) ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));   // (timing marks)
       ZH_LAUNCH_BOTH(zh_sb_build, sb_grid, sb_bound, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, cnt);
@@ -1084,7 +1076,7 @@ static int zh_enqueue_files(zultra_hip_ctx_t *c, uint32_t nblocks, hipStream_t s
          if (c->stagger_ev) ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k - 1][2], 0));
       }
       const uint32_t b0 = zh_files_run_lo(c, nblocks, k), b1 = zh_files_run_lo(c, nblocks, k + 1);
-      if (zh_enqueue_run(c, k, b0, b1 - b0, (uint64_t)(b1 - b0) * c->max_block, b0, b1 - b0, st, c->side_stream[k], NULL, 0) != 0) return -1;
+      if (zh_enqueue_run(c, k, b0, b1 - b0, (uint64_t)(b1 - b0) * c->max_block, c->max_block, b0, b1 - b0, st, c->side_stream[k], 0) != 0) return -1;
       if (k) ZH_CHECK(c, hipEventRecord(c->lane_ev[k][17], st));
    }
    for (int k = 1; k < runs; k++) ZH_CHECK(c, hipStreamWaitEvent(st0, c->lane_ev[k][17], 0));   // join
@@ -1129,7 +1121,7 @@ static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
             for (int part = 1; part <= 2; part++) {
                const int g = 2 * k + part - 1;
                ZH_CHECK(c, hipStreamBeginCapture(sk, hipStreamCaptureModeThreadLocal));
-               const int rc = zh_enqueue_run(c, k, b0, b1 - b0, (uint64_t)(b1 - b0) * c->max_block, b0, b1 - b0, sk, c->side_stream[k], NULL, part);
+               const int rc = zh_enqueue_run(c, k, b0, b1 - b0, (uint64_t)(b1 - b0) * c->max_block, c->max_block, b0, b1 - b0, sk, c->side_stream[k], part);
                const hipError_t e = hipStreamEndCapture(sk, &G->graph[g]);
                if (rc != 0) return -1;
                ZH_CHECK(c, e);
@@ -1294,7 +1286,11 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
          if (c->stagger_ev) ZH_CHECK(c, hipStreamWaitEvent(st, c->lane_ev[k - 1][c->stagger_ev], 0));
       }
       uint64_t total_n = 0;
-      for (uint32_t b = b0; b < b1; b++) total_n += blocks[b].n;
+      uint32_t max_n = 0;
+      for (uint32_t b = b0; b < b1; b++) {
+         total_n += blocks[b].n;
+         max_n = max(max_n, blocks[b].n);
+      }
       if (per_run_stage) {
          // this run's windows: from the first block's history to the last block's end (the 32 KiB in front of the run go up twice,
          // with the run before it: the same bytes)
@@ -1335,7 +1331,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, side, c->cur_data, (const zh_block_t *)(c->d_blocks + b0), (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
       // token bits are ORed into the payload slots: cleared there too, long before stage 3 needs them
       ZH_CHECK(c, hipMemsetAsync(c->d_payload + (uint64_t)b0 * c->slot_stride, 0, (size_t)nb * c->slot_stride, side));
-      if (zh_enqueue_run(c, k, b0, nb, total_n, sg0, nsg, st, side, c->seg_stream[k], 0) != 0) return -1;
+      if (zh_enqueue_run(c, k, b0, nb, total_n, max_n, sg0, nsg, st, side, 0) != 0) return -1;
       ZH_CHECK(c, hipMemcpyAsync(c->h_crc + b0, c->d_crc + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipMemcpyAsync(c->h_adler + 2 * (size_t)b0, c->d_adler + 2 * (size_t)b0, 2 * nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipEventRecord(ev[16], st));

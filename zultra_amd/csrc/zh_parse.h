@@ -573,41 +573,7 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
 
 // Which of the two ways a run's cut tasks are parsed (see "speculative segments" above): many segments are throughput — four to a wave of
 // zh_parse_segments, which also checks them; a few are latency — each one a job of zh_parse_chain (five times faster per position). Decided on
-// the device from the run's counters (zh_list_huge), the same way by both kernels: the host launches both and never reads the counts.
+// the device from the run's counters (zh_list_huge), the same way by both kernels (zh_parse_lanes takes the wide case in the first workgroups of its grid): the host launches both and never reads the counts.
 __device__ __forceinline__ bool zh_segments_are_wide(const uint32_t *cnt, uint32_t seg_wide_min) {
    return cnt[ZH_CNT_SEGTASKS] != 0 && cnt[ZH_CNT_SEGITEMS] >= seg_wide_min;
-}
-
-// The cut tasks (see "speculative segments" above): one wave per entry of segwaves, four segments each; the wave that finishes a task
-// checks it. Launched next to zh_parse_lanes and zh_parse_chain, on a stream of its own. How many entries there are is known on the device only:
-// <false> over a bounded grid (surplus workgroups leave at once — all of them when zh_parse_chain takes the run's segments), <true> a few workgroups
-// that stride over what lies beyond it (see zh_sb_init, zh_encode.h).
-template <bool MORE>
-__global__ void __launch_bounds__(64)
-zh_parse_segments(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
-                  const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
-                  const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *hist_part, int pass, uint4 *segtasks,
-                  const uint2 *__restrict__ segwaves, int16_t *vecs, uint32_t *cnt, uint32_t *demote_list /* the run's fourth chain list */,
-                  uint32_t demote_min /* a task with this many failed cuts in a pass is a whole chain from the next pass on; 0: never */,
-                  uint32_t seg_wide_min /* fewer segments in the run: zh_parse_chain takes them */, uint32_t first) {
-   __shared__ zh_parse_ws_t ws;
-   if (!zh_segments_are_wide(cnt, seg_wide_min)) return;
-   const uint32_t nwaves = cnt[ZH_CNT_SEGWAVES];
-   if (!MORE) {
-      if (blockIdx.x >= nwaves) return;
-      const uint2 sw = segwaves[blockIdx.x];
-      const uint4 stask = segtasks[sw.x];
-      if (stask.y & ZH_CUT_DEMOTED) return;   // (set by the task's checker at the end of an earlier pass: every wave of the task sees it or none)
-      zh_parse_one_task<true>(ws, stask.x, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, stask.y, sw.y,
-                              stask.z, vecs, &segtasks[sw.x].w, cnt, demote_list, demote_min);
-      return;
-   }
-   for (uint32_t w = first + blockIdx.x; w < nwaves; w += gridDim.x) {
-      zh_sync();   // the entry before this one is done with the workspace
-      const uint2 sw = segwaves[w];
-      const uint4 stask = segtasks[sw.x];
-      if (stask.y & ZH_CUT_DEMOTED) continue;
-      zh_parse_one_task<true>(ws, stask.x, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, stask.y, sw.y,
-                              stask.z, vecs, &segtasks[sw.x].w, cnt, demote_list, demote_min);
-   }
 }

@@ -528,7 +528,24 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    ZH_LP_COUNT(5, ZH_LP_CLOCK() - tic2);
 }
 
-// Single-wave workgroups take groups of tasks_per_wave consecutive tasks from *ticket until the run's task list — whose length only the device
+// The cut tasks' segments, when a run has many (zh_parse.h, "speculative segments"; zh_segments_are_wide), are parsed by the FIRST seg_grid workgroups of
+// this kernel's grid — one wave per entry of segwaves, four segments each, the wave that finishes a task checks it — next to the workgroups behind them,
+// which parse the task list on the quads: two kinds of work in one launch. (Rounds 2-4 launched zh_parse_segments as a kernel of its own on a third
+// stream per run. Since the host no longer knows whether a run has such segments — round 5: the counts stay on the device — that launch would be made
+// for every run and pass, and a third active stream per run turned out to be one too many next to other contexts on the device: three jobs in flight fell
+// from 2.7 GB/s to 0.36, the runtime's eight hardware queues stalling on each other's event waits.) A run whose segments go to zh_parse_chain, or that
+// has none, sees those workgroups leave at once; entries beyond the grid are taken in strides.
+struct zh_seg_args_t {
+   uint4 *segtasks;
+   const uint2 *segwaves;
+   int16_t *vecs;
+   uint32_t *demote_list;   // the run's fourth chain list
+   uint32_t demote_min;     // a task with this many failed cuts in a pass is a whole chain from the next pass on; 0: never
+   uint32_t seg_wide_min;   // fewer segments in the run: zh_parse_chain takes them
+   uint32_t seg_grid;       // workgroups of this launch that take segment entries (0: none — files mode)
+};
+
+// Behind them, single-wave workgroups take groups of tasks_per_wave consecutive tasks from *ticket until the run's task list — whose length only the device
 // knows (cnt[ZH_CNT_TASKS]) — is used up. The host gives a wave up to ZH_LP_TASKS tasks — a pool of pieces large enough to keep its sixteen quads
 // busy — but no more than it takes to give every wave slot of the chip a wave: a small batch (one 40 KB input: 20 tasks) is a matter of latency,
 // not of lane utilisation. Next to chains (zh_parse_chain, zh_parse_segments: the run's counters say whether it has any) only the first
@@ -540,14 +557,32 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
 __global__ void __launch_bounds__(64)
 zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const zh_match_t *__restrict__ match, uint64_t match_stride,
                const uint64_t *__restrict__ bars, uint64_t bar_stride, const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap,
-               const uint32_t *__restrict__ cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all,
+               uint32_t *cnt, const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint16_t *cost_all,
                uint32_t *hist_part, int pass, uint32_t *ticket, const uint2 *__restrict__ taskinfo, uint32_t tasks_per_wave /* 1 .. ZH_LP_TASKS */,
-               uint32_t bounded /* workgroups that stay when the run has chains */) {
-   __shared__ zh_lp_ws_t ws;
+               uint32_t bounded /* quad workgroups that stay when the run has chains */, zh_seg_args_t sg) {
+   __shared__ union {
+      zh_lp_ws_t ws;
+      zh_parse_ws_t seg_ws;
+   } sh;
+   if (blockIdx.x < sg.seg_grid) {
+      // ---- a workgroup of segment entries
+      if (!zh_segments_are_wide(cnt, sg.seg_wide_min)) return;
+      const uint32_t nwaves = cnt[ZH_CNT_SEGWAVES];
+      for (uint32_t w = blockIdx.x; w < nwaves; w += sg.seg_grid) {
+         zh_sync();   // the entry before this one is done with the workspace
+         const uint2 sw = sg.segwaves[w];
+         const uint4 stask = sg.segtasks[sw.x];
+         if (stask.y & ZH_CUT_DEMOTED) continue;   // (set by the task's checker at the end of an earlier pass: every wave of the task sees it or none)
+         zh_parse_one_task<true>(sh.seg_ws, stask.x, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, hist_part, pass, stask.y, sw.y,
+                                 stask.z, sg.vecs, &sg.segtasks[sw.x].w, (uint32_t *)cnt, sg.demote_list, sg.demote_min);
+      }
+      return;
+   }
+   zh_lp_ws_t &ws = sh.ws;
    const uint32_t ntasks = cnt[ZH_CNT_TASKS];
-   if (blockIdx.x >= bounded && (cnt[ZH_CNT_VLONG] | cnt[ZH_CNT_LONG] | cnt[ZH_CNT_SHORT] | cnt[ZH_CNT_SEGTASKS]) != 0u) return;
+   if (blockIdx.x - sg.seg_grid >= bounded && (cnt[ZH_CNT_VLONG] | cnt[ZH_CNT_LONG] | cnt[ZH_CNT_SHORT] | cnt[ZH_CNT_SEGTASKS]) != 0u) return;
    for (;;) {
-      uint32_t w = blockIdx.x;
+      uint32_t w = blockIdx.x - sg.seg_grid;
       if (ticket) {
          if (zh_lane() == 0) w = atomicAdd(ticket, 1u);
          w = zh_readfirstlane(w);
