@@ -990,7 +990,9 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
    // room the moment they are launched (the run's counters tell the kernel which); zh_parse_segments takes the cut tasks' segments when there are many.
    const uint32_t tpw = zh_tasks_per_wave(c, est_tasks);
    const uint32_t lane_grid = max(1u, min((est_tasks + tpw - 1) / tpw, c->num_cus * 16u));
-   const uint32_t chain_grid = files ? min(nb, c->files_chain_grid) : (uint32_t)zh_min64(ZH_CHAIN_GRID, total_n / 256u + nb);
+   // (two chain workgroups fit a CU — 169 registers, four waves — and they are persistent: a third per CU would only queue behind them, find the tickets
+   // gone and leave; and in a run without chains every workgroup of this grid has to find a slot among the quad kernel's waves before the pass can end)
+   const uint32_t chain_grid = files ? min(nb, c->files_chain_grid) : (uint32_t)zh_min64(zh_min64(ZH_CHAIN_GRID, 2u * c->num_cus), total_n / 256u + nb);
    const uint32_t seg_grid = (uint32_t)zh_min64(c->num_cus * 8u, zh_max64(1, seg_bound));
    for (int pass = 0; pass <= 3; pass++) {
       ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
