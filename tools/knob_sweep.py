@@ -2,7 +2,7 @@
 """Diagnostics: device pipeline time of one 100 MB batch (first launch to last completion, HIP events) under different settings of the library's
 tuning knobs (environment variables read at context creation). The shipped library has its tuning knobs compiled in: build a probe library first —
 tools/build_variant.sh knobs -DZH_TUNING_KNOBS — and name it in KNOB_LIB=build/libzultra_amd_knobs.so.
-usage: KNOB_LIB=... python tools/knob_sweep.py [bytes] [corpus] -- KEY=VAL,KEY=VAL ... (one group per setting)"""
+usage: KNOB_LIB=... [KNOB_BLOCK=32768] python tools/knob_sweep.py [bytes] [pysrc|text|binary|mixed] -- KEY=VAL,KEY=VAL ... (one group per setting)"""
 import os
 import sys
 
@@ -19,8 +19,24 @@ sep = args.index("--") if "--" in args else len(args)
 size = int(args[0]) if sep > 0 else 100_000_000
 kind = args[1] if sep > 1 else "pysrc"
 settings = args[sep + 1:] or [""]
-d = corpus.real_text(size) if kind == "pysrc" else corpus.text_like_fast(size, 1000) if kind == "text" else corpus.mixed_config4(0, size >> 20)
-size, bs = len(d), 65536
+def _binaries(size):   # configuration 3's stand-in (bench.py: binary_corpus)
+    import glob
+    parts, total = [], 0
+    for f in sorted(glob.glob("/usr/lib/x86_64-linux-gnu/*.so*")) + sorted(glob.glob("/usr/bin/*")):
+        if os.path.isfile(f) and not os.path.islink(f):
+            try:
+                b = np.fromfile(f, dtype=np.uint8)
+            except OSError:
+                continue
+            parts.append(b)
+            total += b.size
+            if total >= size:
+                break
+    return np.concatenate(parts)[:size].copy()
+
+
+d = corpus.real_text(size) if kind == "pysrc" else corpus.text_like_fast(size, 1000) if kind == "text" else _binaries(size) if kind == "binary" else corpus.mixed_config4(0, size >> 20)
+size, bs = len(d), int(os.environ.get("KNOB_BLOCK", "65536"))
 nb = (size + bs - 1) // bs
 blocks = [(b * bs - (32768 if b else 0), 32768 if b else 0, min(bs, size - b * bs)) for b in range(nb)]
 import torch  # noqa: E402
