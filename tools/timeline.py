@@ -4,6 +4,8 @@ rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 # take the last batch: find last zh_stitch and go back to the previous one
 names=[r["Kernel_Name"] for r in rows]
 st=[i for i,n in enumerate(names) if n.replace("void ","").split("(")[0]=="zh_stitch"]   # (not zh_stitch_scan)
+if not st:   # a command that never stitches (tools/step_dev.py): a batch ends with zh_compact_results
+    st=[i for i,n in enumerate(names) if n.replace("void ","").split("(")[0]=="zh_compact_results"]
 a=st[-2]+1 if len(st)>1 else 0; b=st[-1]+1
 last=rows[a:b]
 t0=int(last[0]["Start_Timestamp"])
