@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostics: step and lane utilisation of zh_parse_lanes, from a profiling build of the library (-DZH_LP_PROFILE, built into build/).
 usage: python tools/lp_profile.py --build            (here, no GPU needed)
-       python tools/lp_profile.py [bytes] [corpus]   (on the GPU box)"""
+       python tools/lp_profile.py [bytes] [corpus]   (on the GPU box)
+       python tools/lp_profile.py [inputs] files     (files mode: that many 4 KiB inputs in one batch)"""
 import ctypes as C
 import os
 import subprocess
@@ -25,6 +26,25 @@ from zultra_amd._ffi import Lib  # noqa: E402
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
 kind = sys.argv[2] if len(sys.argv) > 2 else "pysrc"
 L = Lib(SO)
+if kind == "files":   # files mode: `size` inputs of 4096 bytes (configuration 5's JSON-like files), one batch
+    nfiles, fsz = size, 4096
+    d = corpus.json_files(0, nfiles, fsz)
+    ctx = L.files_context(fsz, nfiles)
+    offs = np.arange(nfiles, dtype=np.uint64) * np.uint64(fsz)
+    sizes = np.full(nfiles, fsz, dtype=np.uint32)
+    ctx.compress_files(d, offs, sizes)
+    f = L.L.zultra_hip_lp_profile
+    f.argtypes = [C.c_void_p, C.c_int]
+    f(None, 1)
+    ctx.compress_files(d, offs, sizes)
+    out = np.zeros(12, dtype=np.uint64)
+    f(out.ctypes.data, 0)
+    o = [float(x) for x in out]
+    print("files %d x %d bytes" % (nfiles, fsz))
+    print("   groups %d, pieces per group %.1f, steps per group %.1f" % (o[3], o[6] / max(1, o[3]), o[0] / max(1, o[3])))
+    print("   quads with a position per step %.1f of 16" % (o[1] / max(1, o[0])))
+    print("   cycles per step %.0f; per group: setup %.0f, steps %.0f, histogram %.0f cycles" % (o[2] / max(1, o[0]), o[4] / max(1, o[3]), o[2] / max(1, o[3]), o[5] / max(1, o[3])))
+    sys.exit(0)
 d = corpus.real_text(size) if kind == "pysrc" else corpus.text_like_fast(size, 1000) if kind == "text" else corpus.mixed_config4(0, size >> 20)
 size, bs = len(d), 65536
 nb = (size + bs - 1) // bs
