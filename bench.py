@@ -586,7 +586,7 @@ def prepare_stream_config(args, rank, world):
         flags, bs, size = 2, args.block or 65536, args.size or 100_000_000
         corp, data_note = text_corpus(world, size)
         metric = "input MB/s, gzip 64 KiB max-blocks, enwik8-sized text, bit-exact vs CPU zultra"
-        if args.synthetic_leg:   # (a leg of the default run: round 1's headline corpus in a process of its own)
+        if getattr(args, "synthetic_leg", False):   # (a leg of the default run: round 1's headline corpus in a process of its own)
             corp, data_note = SyntheticText(), "round 1's seeded Zipf word stream (tests/corpus.py: text_like_fast): never splits, never meets the chain parse"
             metric = "input MB/s, gzip 64 KiB max-blocks, synthetic text, bit-exact vs CPU zultra"
     elif cfg == 3:

@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-SO = os.path.join(ROOT, "build", "libzultra_amd_lpprof.so")
+SO = os.environ.get("LP_LIB") or os.path.join(ROOT, "build", "libzultra_amd_lpprof.so")   # (LP_LIB: another profiling build)
 CSRC = os.path.join(ROOT, "zultra_amd", "csrc")
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(SO), exist_ok=True)
@@ -37,13 +37,14 @@ if kind == "files":   # files mode: `size` inputs of 4096 bytes (configuration 5
     f.argtypes = [C.c_void_p, C.c_int]
     f(None, 1)
     ctx.compress_files(d, offs, sizes)
-    out = np.zeros(12, dtype=np.uint64)
+    out = np.zeros(16, dtype=np.uint64)
     f(out.ctypes.data, 0)
     o = [float(x) for x in out]
     print("files %d x %d bytes" % (nfiles, fsz))
     print("   groups %d, pieces per group %.1f, steps per group %.1f" % (o[3], o[6] / max(1, o[3]), o[0] / max(1, o[3])))
     print("   quads with a position per step %.1f of 16" % (o[1] / max(1, o[0])))
     print("   cycles per step %.0f; per group: setup %.0f, steps %.0f, histogram %.0f cycles" % (o[2] / max(1, o[0]), o[4] / max(1, o[3]), o[2] / max(1, o[3]), o[5] / max(1, o[3])))
+    print("   histogram phase per group: waiting for the group's stores + clearing %.0f, the walks %.0f, storing the counters %.0f cycles" % (o[12] / max(1, o[3]), o[13] / max(1, o[3]), (o[5] - o[12] - o[13]) / max(1, o[3])))
     sys.exit(0)
 d = corpus.real_text(size) if kind == "pysrc" else corpus.text_like_fast(size, 1000) if kind == "text" else corpus.mixed_config4(0, size >> 20)
 size, bs = len(d), 65536
@@ -55,7 +56,7 @@ f = L.L.zultra_hip_lp_profile
 f.argtypes = [C.c_void_p, C.c_int]
 f(None, 1)
 ctx.compress_blocks(d, blocks)
-out = np.zeros(12, dtype=np.uint64)
+out = np.zeros(16, dtype=np.uint64)
 f(out.ctypes.data, 0)
 t = ctx.timing()
 o = [float(x) for x in out]
@@ -63,6 +64,7 @@ print("%s %d bytes: parse %.2f ms (all runs, 4 passes)" % (kind, size, t["parse_
 print("   groups %d, pieces per group %.1f, steps per group %.1f" % (o[3], o[6] / max(1, o[3]), o[0] / max(1, o[3])))
 print("   quads with a position per step %.1f of 16, batches with a second plane %.2f" % (o[1] / max(1, o[0]), 4 * o[7] / max(1, o[0])))
 print("   cycles per step %.0f; per group: setup %.0f, steps %.0f, histogram %.0f cycles" % (o[2] / max(1, o[0]), o[4] / max(1, o[3]), o[2] / max(1, o[3]), o[5] / max(1, o[3])))
+print("   histogram phase per group: waiting for the group's stores + clearing %.0f, the walks %.0f, storing the counters %.0f cycles" % (o[12] / max(1, o[3]), o[13] / max(1, o[3]), (o[5] - o[12] - o[13]) / max(1, o[3])))
 lap = max(1.0, o[8] + o[9] + o[10] + o[11])
 print("   step loop by part (s_memtime laps, which drain the LDS queue: shares, not cycles): staging a batch %.0f %%, stage C (decision) %.0f %%, stage B (window, prefix minima) %.0f %%, stage A (slots, prices) %.0f %%"
       % (100 * o[8] / lap, 100 * o[9] / lap, 100 * o[10] / lap, 100 * (o[11]) / lap))

@@ -1571,7 +1571,7 @@ extern "C" int zultra_hip_mfg_profile(unsigned long long *out, int reset) {
 extern "C" int zultra_hip_lp_profile(unsigned long long *out, int reset) {
    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(zh_lp_prof), sizeof(zh_lp_prof)) != hipSuccess) return -1;
    if (reset) {
-      unsigned long long z[12] = {0};
+      unsigned long long z[16] = {0};
       if (hipMemcpyToSymbol(HIP_SYMBOL(zh_lp_prof), z, sizeof(z)) != hipSuccess) return -1;
    }
    return 0;

@@ -60,7 +60,8 @@ static_assert(ZH_LP_TASKS >= 1 && ZH_LP_TASKS <= 64, "the parsed-task mask of a 
 #ifdef ZH_LP_PROFILE
 // probe builds only (tools/lp_profile.py): 0 steps, 1 quad-steps with a position, 2 cycles of the step loops, 3 groups, 4 cycles of the
 // group setup, 5 cycles of the histogram walks, 6 pieces, 7 batches with a second plane
-__device__ unsigned long long zh_lp_prof[12];   // 8..11: cycles of the batch staging, stage C, stage B, stage A of the step loop
+__device__ unsigned long long zh_lp_prof[16];   // 8..11: cycles of the batch staging, stage C, stage B, stage A of the step loop; 12..14: of the histogram phase — waiting for the
+                                                // group's own stores and clearing the counters, the walks, storing the counters
 #define ZH_LP_COUNT(slot_, n_) do { if (zh_lane() == 0) atomicAdd(&zh_lp_prof[slot_], (unsigned long long)(n_)); } while (0)
 #define ZH_LP_CLOCK() zh_clock()
 #else
@@ -511,12 +512,16 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
       zh_wave_sync();
       for (uint32_t k = lane; k < ZH_NSYM; k += 64) ws.hist[k] = 0;
       zh_wave_sync();
+      ZH_LP_COUNT(12, ZH_LP_CLOCK() - tic2);
+      const uint64_t tic3 = ZH_LP_CLOCK();
       for (uint32_t gt = g0; gt < g1; gt++) {
          if (!((parsed >> (gt - g0)) & 1ull)) continue;
          const uint2 ti = taskinfo[gt];
          zh_walk_histogram_wave(ws.hist, win, prev, ti.x, ti.y, best);
       }
       zh_wave_sync();
+      ZH_LP_COUNT(13, ZH_LP_CLOCK() - tic3);
+      (void)tic3;
       bool first = true;
       for (uint32_t gt = g0; gt < g1; gt++) {
          if (!((parsed >> (gt - g0)) & 1ull)) continue;

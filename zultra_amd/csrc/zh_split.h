@@ -25,13 +25,25 @@
 // Follow the chain through a 64-position tile. `len` holds, per lane, the step length of that position
 // (>=3: match, else literal). `carry` = offset of the first token start relative to the tile (may be >= 64).
 // Returns the mask of token starts among the first `limit` positions and updates carry for the next tile.
+// (Round 5: a run of literals is one loop iteration, not one per literal — a ballot gives the tile's match positions; standing on a match the step is what it was
+// (mark, read its length, jump), standing on a literal everything up to the next match is marked at once. Rounds 1-4 took a dependent readlane-compare-add round per
+// token: on inputs that are mostly literals — the first kilobytes of every small file — 64 rounds per tile, 6600 cycles; the forward walks of zh_parse_lanes were
+// 29 % of that kernel on configuration 5, tools/lp_profile.py.)
 __device__ inline uint64_t zh_chain_mask(uint32_t len, uint32_t &carry, uint32_t limit) {
+   const uint64_t below_limit = limit >= 64u ? ~0ull : ((1ull << limit) - 1ull);
+   const uint64_t matches = zh_ballot(len >= ZH_MIN_MATCH) & below_limit;
    uint64_t mask = 0;
    uint32_t p = carry;
-   while (p < limit) {
-      mask |= 1ull << p;
-      uint32_t l = zh_readlane(len, (int)p);
-      p += (l >= ZH_MIN_MATCH) ? l : 1u;
+   while (p < limit) {   // (p < 64)
+      if ((matches >> p) & 1ull) {
+         mask |= 1ull << p;
+         p += zh_readlane(len, (int)p);
+         continue;
+      }
+      const uint64_t ahead = matches & (~0ull << p);
+      const uint32_t q = ahead ? (uint32_t)zh_ctz64(ahead) : limit;   // the next match (or the limit): p .. q - 1 are literals
+      mask |= (q >= 64u ? ~0ull : ((1ull << q) - 1ull)) & (~0ull << p);
+      p = q;
    }
    carry = p - limit;   // only meaningful when limit == 64 (a full tile) or at the very end
    return mask;
