@@ -276,7 +276,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
 
    // what an entry carries from stage A to stage B, and from stage B to stage C
    struct zh_lp_a_t {
-      uint32_t e0, e1, mlen0, mlen1, dp0, dp1, lit, lc0, lc1, rg0, rg1, j;   // (j: entry | batch parity << 2)
+      uint32_t e0, e1, mlen0, mlen1, dp0, dp1, lit, lr0, lr1, j;   // (lr: for a slot stored with length >= 40, the price of its clamped length + the cost behind it; j: entry | batch parity << 2)
       bool act, fresh;
    };
    struct zh_lp_b_t {
@@ -285,7 +285,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    };
    zh_lp_a_t ea;
    zh_lp_b_t eb;
-   ea.e0 = ea.e1 = ea.mlen0 = ea.mlen1 = ea.dp0 = ea.dp1 = ea.lit = ea.lc0 = ea.lc1 = ea.rg0 = ea.rg1 = ea.j = 0;
+   ea.e0 = ea.e1 = ea.mlen0 = ea.mlen1 = ea.dp0 = ea.dp1 = ea.lit = ea.lr0 = ea.lr1 = ea.j = 0;
    ea.act = ea.fresh = false;
    eb.e0 = eb.e1 = eb.mlen0 = eb.mlen1 = eb.lit = eb.j = 0;
    eb.key0 = eb.key1 = ZH_LP_NOKEY;
@@ -431,12 +431,12 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
             const bool short0 = len0 >= ZH_MIN_MATCH && !long0 && ea.mlen0 >= ZH_MIN_MATCH, short1 = len1 >= ZH_MIN_MATCH && !long1 && ea.mlen1 >= ZH_MIN_MATCH;
             const uint32_t r0 = short0 ? ea.mlen0 - ZH_MIN_MATCH : 0u, r1 = short1 ? ea.mlen1 - ZH_MIN_MATCH : 0u;
             const uint32_t pk0 = ws.pmin[r0][ZH_LP_PCOL(r0, piece)];
-            const uint32_t lk0 = long0 ? ((ea.lc0 + ea.rg0 + ea.dp0) << 9) | (q << 6) : ZH_LP_NOKEY;
+            const uint32_t lk0 = long0 ? ((ea.lr0 + ea.dp0) << 9) | (q << 6) : ZH_LP_NOKEY;
             nb.key0 = short0 ? pk0 + ((ea.dp0 << 9) | (q << 6)) : lk0;
             nb.key1 = ZH_LP_NOKEY;
             if (j == 0 ? old_hi : cur_hi) {   // (the entry in this stage is the last one of the batch before when j is 0)
                const uint32_t pk1 = ws.pmin[r1][ZH_LP_PCOL(r1, piece)];
-               const uint32_t lk1 = long1 ? ((ea.lc1 + ea.rg1 + ea.dp1) << 9) | ((4u + q) << 6) : ZH_LP_NOKEY;
+               const uint32_t lk1 = long1 ? ((ea.lr1 + ea.dp1) << 9) | ((4u + q) << 6) : ZH_LP_NOKEY;
                nb.key1 = short1 ? pk1 + ((ea.dp1 << 9) | ((4u + q) << 6)) : lk1;
             }
             nb.e0 = ea.e0;
@@ -455,7 +455,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
          // ======== stage A, second half: the slots' distance prices, the literal's price; for a slot stored with length >= 40 the
          //          price of its clamped length and the cost behind it ========================================================================
          {
-            if (!na.act) na.e0 = na.e1 = 0;
+            // (an entry without a position holds zeros in the stage: its lane fetched nothing, ZH_LP_FETCH / ZH_LP_FETCH_HI)
             const uint32_t len0 = na.e0 & 0xffffu, len1 = na.e1 & 0xffffu;
             na.mlen0 = min(len0, aroom);
             na.mlen1 = min(len1, aroom);
@@ -464,16 +464,14 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
             if (cur_hi) na.dp1 = ws.distprice[len1 >= ZH_MIN_MATCH ? zh_lp_dist_index((na.e1 >> 16) - 1u) : 0u];
             na.lit = ws.litprice[abyte & 0xffu];
             const bool long0 = len0 >= ZH_LEAVE_ALONE;
-            na.lc0 = na.lc1 = na.rg0 = na.rg1 = 0;
+            na.lr0 = na.lr1 = 0;
             if (zh_ballot(long0)) {
                // (rows are longest first: a long slot 4..7 sits behind four long slots 0..3)
                uint32_t enc0 = na.mlen0 - ZH_MIN_MATCH, enc1 = na.mlen1 - ZH_MIN_MATCH;   // wraps below 3, then saturates (:289, :216-219)
                if (enc0 > 255u) enc0 = 255u;
                if (enc1 > 255u) enc1 = 255u;
-               na.lc0 = ws.lencost[enc0];
-               na.lc1 = ws.lencost[enc1];
-               na.rg0 = ws.stagef[piece][j][q];
-               na.rg1 = ws.stagef[piece][j][4u + q];
+               na.lr0 = (uint32_t)ws.lencost[enc0] + (uint32_t)ws.stagef[piece][j][q];
+               na.lr1 = (uint32_t)ws.lencost[enc1] + (uint32_t)ws.stagef[piece][j][4u + q];
             }
          }
          eb = nb;
