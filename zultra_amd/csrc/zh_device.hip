@@ -291,6 +291,14 @@ __global__ void __launch_bounds__(64) zh_selftest_kernel(uint32_t seed, uint32_t
             }
             // the counter held `all` less before this step's lanes arrived; this lane is the (below)-th of them
             if (valid && (got32 != cnt32[d] - all + below || got16 != got32)) errors++;
+            {
+               // zh_peers8: the lanes that hold this lane's digit
+               uint64_t pref = 0;
+               for (uint32_t k = 0; k < 64; k++)
+                  if (v[k] == d) pref |= 1ull << k;
+               const uint64_t peers = zh_peers8(d, valid);
+               if (valid && peers != pref) errors++;
+            }
             zh_sync();
          }
       }

@@ -238,13 +238,17 @@ __device__ __forceinline__ void zh_lockstep_sync() {
 // The lanes (among those with `valid`) that hold the same 8-bit digit as the calling lane, itself included: one ballot per bit, and per lane
 // the OR over the bits of "lanes whose bit differs from mine" (ballot XOR own bit spread over the word).
 __device__ __forceinline__ uint64_t zh_peers8(uint32_t d, bool valid) {
+   // per bit: the lane's bit spread over a word (v_bfe_i32), a ballot of it, and "differs from mine" ORed in with one three-input operation per half
+   // (v_bitop3_b32: a | (b ^ c)) — 32 instructions; written with shifts and plain operators (rounds 1-4) the compiler made 48 of it. zh_selftest_kernel
+   // checks the result against a lane-by-lane comparison on the device.
    uint32_t dlo = 0, dhi = 0;
 #pragma unroll
    for (int bit = 0; bit < 8; bit++) {
-      const uint32_t s = (uint32_t)((int32_t)(d << (31 - bit)) >> 31);   // all ones where this lane's bit is set
-      const uint64_t m = __ballot(s != 0);                               // (lanes without `valid` are masked out at the end)
-      dlo |= (uint32_t)m ^ s;
-      dhi |= (uint32_t)(m >> 32) ^ s;
+      uint32_t s = (uint32_t)__builtin_amdgcn_sbfe((int)d, (uint32_t)bit, 1u);   // all ones where this lane's bit is set
+      asm volatile("" : "+v"(s));                                                // (the compare below takes s, not a shifted copy of d)
+      const uint64_t m = __ballot(s != 0);                                       // (lanes without `valid` are masked out at the end)
+      dlo = __builtin_amdgcn_bitop3_b32(dlo, (uint32_t)m, s, 0xf6);              // dlo | (m ^ s)
+      dhi = __builtin_amdgcn_bitop3_b32(dhi, (uint32_t)(m >> 32), s, 0xf6);
    }
    const uint64_t v = __ballot(valid);
    return v & ~(((uint64_t)dhi << 32) | dlo);
