@@ -46,12 +46,13 @@
                                    // puts the four lanes of a quad on different LDS banks, a stride of 10 puts lanes 0 and 2 on the same)
 #define ZH_LP_QSTRIDE 9u
 #define ZH_LP_NL 37u               // rows of the prefix scratch: lengths 3 .. 39 (ZH_LEAVE_ALONE - 1)
-#define ZH_LP_MAXP (ZH_LP_TASKS * 32u) // pieces per group: a task without a run of more than ZH_COOP_MIN positions has fewer than 32
+#define ZH_LP_PPT ((ZH_TASK + ZH_COOP_MIN + ZH_PIECE - 1) / ZH_PIECE <= 32 ? 32u : 64u)   // pieces a task can have: fewer than 32 with the default piece size, at most ZH_MAXPIECES
+#define ZH_LP_MAXP (ZH_LP_TASKS * ZH_LP_PPT) // pieces per group: a task without a run of more than ZH_COOP_MIN positions has fewer than ZH_LP_PPT
 #define ZH_LP_LONG 192u            // pieces of at least this many positions are handed out first
 #define ZH_LP_NOKEY 0xFFFFFFFFu
 // a task that is parsed here has no barrier-free run of more than ZH_COOP_MIN positions, so it has fewer than 32 pieces of >= ZH_PIECE positions
 // (zh_task_pieces); a group whose pieces outgrew ZH_LP_MAXP would silently lose a task — variant builds (-D...) must keep these
-static_assert((ZH_TASK + ZH_COOP_MIN + ZH_PIECE - 1) / ZH_PIECE <= 32, "pieces per task must stay below 32 (ZH_LP_MAXP = 32 per task)");
+static_assert((ZH_TASK + ZH_COOP_MIN + ZH_PIECE - 1) / ZH_PIECE <= ZH_LP_PPT && ZH_LP_PPT <= ZH_MAXPIECES, "pieces per task must stay within ZH_LP_PPT (ZH_LP_MAXP = ZH_LP_PPT per task)");
 static_assert(ZH_LP_TASKS >= 1 && ZH_LP_TASKS <= 64, "the parsed-task mask of a group is 64 bits");
 // The prefix scratch [row][column]: row L - 3, and piece i in column i ^ 8 for the rows of lanes 2 and 3 — the four lanes of a quad
 // write rows 9 q + k, whose LDS banks (16 per row) would coincide for lanes 0 / 2 and for lanes 1 / 3
