@@ -48,6 +48,7 @@ static std::recursive_mutex g_emu_mutex;
 #endif
 
 #define ZH_MAX_RUNS 8           // staggered runs of a batch (ZULTRA_HIP_STREAMS)
+#define ZH_TOK_SMALL_BATCH 32u  // a batch of at most this many max-blocks follows its token chain in small chunks (zh_split.h)
 #define ZH_NCNT ((uint32_t)ZH_MAX_RUNS * ZH_CNT_STRIDE)   // device counters: one block of ZH_CNT_* words per run
 
 static_assert(sizeof(zultra_hip_block_t) == sizeof(zh_block_t), "ABI");
@@ -729,7 +730,7 @@ static zultra_hip_ctx_t *zh_create(int device, uint32_t max_block, uint32_t max_
    c->run_stride = c->sort_stride + 576;   // start[Q] length[Q] first[256] end[256] count, Q = W/4 + 1
    c->match_stride = (uint64_t)c->max_block * ZH_NMATCH;
    c->tok_stride = ((uint64_t)c->max_block + 63) & ~63ull;
-   c->chunks_per_block = (c->max_block + ZH_TOK_CHUNK - 1) / ZH_TOK_CHUNK;
+   c->chunks_per_block = (c->max_block + ZH_TOK_CHUNK_SMALL - 1) / ZH_TOK_CHUNK_SMALL;   // (what the per-chunk arrays hold: the small chunks of a small batch)
    c->best_stride = c->tok_stride;
    c->slot_stride = (((uint64_t)c->max_block + 64 * c->max_subs + 64) + 63) & ~63ull;
    c->data_cap = (size_t)c->W + (size_t)(max_blocks - 1) * c->max_block;
@@ -787,7 +788,7 @@ extern "C" size_t zultra_hip_context_bytes_on(int device, uint32_t max_block_siz
    const uint64_t seg_W = W <= ZH_SEG_WINDOW ? W : (uint64_t)ZH_SEG_WINDOW;
    const uint64_t S = W <= ZH_SEG_WINDOW ? 1 : (N + ZH_SEG_POSITIONS - 1) / ZH_SEG_POSITIONS;
    const uint64_t sort_stride = (seg_W + 63) & ~63ull, run_stride = sort_stride + 576, tok_stride = (N + 63) & ~63ull;
-   const uint64_t slot_stride = ((N + 64 * ZH_MAX_SPLITS + 64) + 63) & ~63ull, cpb = (N + ZH_TOK_CHUNK - 1) / ZH_TOK_CHUNK;
+   const uint64_t slot_stride = ((N + 64 * ZH_MAX_SPLITS + 64) + 63) & ~63ull, cpb = (N + ZH_TOK_CHUNK_SMALL - 1) / ZH_TOK_CHUNK_SMALL;
    const uint64_t tasks = B * (N / ZH_TASK + ZH_MAX_SPLITS), subs = B * ZH_MAX_SPLITS;
    uint64_t bytes = 0;
    bytes += W + (B - 1) * N + 64;                                    // d_data
@@ -864,18 +865,21 @@ static uint32_t zh_tasks_per_wave(const zultra_hip_ctx_t *c, uint32_t ntasks) {
 
 // barrier bitmap and greedy token chain of `nb` max-blocks starting at batch block b0, in chunks (zh_split.h)
 static int zh_enqueue_tokenize(zultra_hip_ctx_t *c, hipStream_t st, const zh_block_t *blk, uint32_t b0, uint32_t nb) {
-   const uint32_t cpb = c->chunks_per_block;
+   // (chunks of an eighth for a BATCH of a few max-blocks — all its runs alike: they share the per-chunk arrays, which are sized for the small chunks; files mode:
+   // an input is one chunk)
+   const uint32_t chunk = (!c->files_mode && c->nblocks <= ZH_TOK_SMALL_BATCH) ? (uint32_t)ZH_TOK_CHUNK_SMALL : (uint32_t)ZH_TOK_CHUNK;
+   const uint32_t cpb = (c->max_block + chunk - 1) / chunk;
    const uint32_t *match = (const uint32_t *)(c->d_match + (uint64_t)b0 * c->match_stride);   // slot 0 of a position's row = its longest match
    uint64_t *bars = c->d_bars + (uint64_t)b0 * c->bar_stride;
    uint32_t *tp = c->d_tok_pos + (uint64_t)b0 * c->tok_stride;
    uint16_t *ti = c->d_tok_info + (uint64_t)b0 * c->tok_stride;
    uint32_t *cmax = c->d_chunkmax + (uint64_t)b0 * cpb, *sstart = c->d_spanstart + (uint64_t)b0 * cpb, *scnt = c->d_spancnt + (uint64_t)b0 * cpb;
    uint32_t *slot0 = c->d_best + (uint64_t)b0 * c->best_stride;   // (free until the run's first parse pass: zh_split.h)
-   ZH_LAUNCH(zh_barriers, nb * cpb, 64, st, blk, match, c->match_stride, bars, c->bar_stride, cmax, cpb, slot0, c->best_stride);
-   if (cpb > 1) ZH_LAUNCH(zh_barriers_fix, (nb + 63) / 64, 64, st, blk, nb, bars, c->bar_stride, (const uint32_t *)cmax, cpb);
+   ZH_LAUNCH(zh_barriers, nb * cpb, 64, st, blk, match, c->match_stride, bars, c->bar_stride, cmax, cpb, chunk, slot0, c->best_stride);
+   if (cpb > 1) ZH_LAUNCH(zh_barriers_fix, (nb + 63) / 64, 64, st, blk, nb, bars, c->bar_stride, (const uint32_t *)cmax, cpb, chunk);
    ZH_LAUNCH(zh_tokenize_spans, nb * cpb, 64, st, c->cur_data, blk, (const uint32_t *)slot0, c->best_stride, tp, ti, c->tok_stride, (const uint64_t *)bars, c->bar_stride, sstart, scnt,
-             cpb);
-   ZH_LAUNCH(zh_tokens_compact, nb, ZH_COMPACT_THREADS, st, blk, tp, ti, c->tok_stride, (const uint32_t *)sstart, (const uint32_t *)scnt, cpb, c->d_ntok + b0);
+             cpb, chunk);
+   ZH_LAUNCH(zh_tokens_compact, nb, ZH_COMPACT_THREADS, st, blk, tp, ti, c->tok_stride, (const uint32_t *)sstart, (const uint32_t *)scnt, cpb, chunk, c->d_ntok + b0);
    return 0;
 }
 

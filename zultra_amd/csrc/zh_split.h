@@ -76,18 +76,22 @@ __device__ inline uint32_t zh_first_barrier(const uint64_t *bar, uint32_t r, uin
 #ifndef ZH_TOK_CHUNK
 #define ZH_TOK_CHUNK 16384u   // a multiple of 64 (the emulator build uses 1024, so that its small test windows span several chunks)
 #endif
+// A batch of a few max-blocks (one call on one block: what counts is the longest chain of dependent steps, not the number of waves) takes chunks of an eighth of
+// that — `chunk` is a kernel argument, cpb the chunks per max-block that go with it (round 5: one 39 KB block, zh_barriers 0.09 -> 0.03 ms, zh_tokenize_spans 0.18 -> 0.05).
+#define ZH_TOK_CHUNK_SMALL (ZH_TOK_CHUNK / 8u >= 512u ? ZH_TOK_CHUNK / 8u : 512u)
+static_assert(ZH_TOK_CHUNK % 64u == 0 && ZH_TOK_CHUNK_SMALL % 64u == 0, "chunks are whole words of the barrier bitmap");
 
 __global__ void __launch_bounds__(64)
 zh_barriers(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ longest, uint64_t longest_stride, uint64_t *bars, uint64_t bar_stride,
-            uint32_t *chunkmax, uint32_t cpb, uint32_t *slot0, uint64_t slot0_stride /* slot 0 of every row once more, 4 bytes per block position and
+            uint32_t *chunkmax, uint32_t cpb, uint32_t chunk, uint32_t *slot0, uint64_t slot0_stride /* slot 0 of every row once more, 4 bytes per block position and
             dense: this kernel reads the rows in position order — a word out of every 16 bytes — and is the one place where that copy can be
             written coalesced (the frontier owns entries of the order: its stores to such a plane scattered); zh_tokenize_spans and
             zh_list_huge read it instead of the rows. It lives in the parse-entry array, which nothing else touches before the first parse pass */) {
    const uint32_t b = blockIdx.x / cpb, c = blockIdx.x - b * cpb;
    const zh_block_t blk = blocks[b];
-   const uint32_t n = blk.n, lo = c * ZH_TOK_CHUNK;
+   const uint32_t n = blk.n, lo = c * chunk;
    if (lo >= n) return;
-   const uint32_t hi = min(n, lo + ZH_TOK_CHUNK);
+   const uint32_t hi = min(n, lo + chunk);
    const uint32_t *rows = longest + (uint64_t)b * longest_stride;   // per position r its longest match: slot 0 of its row, rows[4 r] (matchfinder.c:221; first plane, zh_common.h)
    uint64_t *bar = bars + (uint64_t)b * bar_stride;
    const uint32_t lane = zh_lane();
@@ -119,15 +123,15 @@ zh_barriers(const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ 
 }
 
 __global__ void zh_barriers_fix(const zh_block_t *__restrict__ blocks, uint32_t nblocks, uint64_t *bars, uint64_t bar_stride, const uint32_t *__restrict__ chunkmax,
-                                uint32_t cpb) {
+                                uint32_t cpb, uint32_t chunk) {
    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
    if (b >= nblocks) return;
    const uint32_t n = blocks[b].n;
    uint64_t *bar = bars + (uint64_t)b * bar_stride;
    uint32_t reach = 0;
-   for (uint32_t c = 1; c * ZH_TOK_CHUNK < n; c++) {
+   for (uint32_t c = 1; c * chunk < n; c++) {
       reach = max(reach, chunkmax[b * cpb + c - 1]);
-      const uint32_t lo = c * ZH_TOK_CHUNK;   // positions lo .. reach-1 have a match crossing them (reach <= lo + 257)
+      const uint32_t lo = c * chunk;   // positions lo .. reach-1 have a match crossing them (reach <= lo + 257)
       for (uint32_t w = lo >> 6; w * 64 < min(reach, n); w++) {
          const uint32_t keep_from = reach - w * 64;   // bits below it are cleared
          bar[w] &= keep_from >= 64 ? 0ull : (~0ull << keep_from);
@@ -138,15 +142,15 @@ __global__ void zh_barriers_fix(const zh_block_t *__restrict__ blocks, uint32_t 
 __global__ void __launch_bounds__(64)
 zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, const uint32_t *__restrict__ longest, uint64_t longest_stride,
                   uint32_t *tok_pos, uint16_t *tok_info, uint64_t tok_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride, uint32_t *spanstart,
-                  uint32_t *spancnt, uint32_t cpb) {
+                  uint32_t *spancnt, uint32_t cpb, uint32_t chunk) {
    const uint32_t b = blockIdx.x / cpb, c = blockIdx.x - b * cpb;
    const zh_block_t blk = blocks[b];
-   const uint32_t n = blk.n, lo = c * ZH_TOK_CHUNK;
+   const uint32_t n = blk.n, lo = c * chunk;
    const uint32_t lane = zh_lane();
    const uint64_t *bar = bars + (uint64_t)b * bar_stride;
    // the span of this chunk: from the first barrier at or after its start to the first barrier at or after its end
    const uint32_t s0 = c == 0 ? 0u : zh_first_barrier(bar, lo, n);
-   const uint32_t s1 = (lo >= n || lo + ZH_TOK_CHUNK >= n) ? n : zh_first_barrier(bar, lo + ZH_TOK_CHUNK, n);
+   const uint32_t s1 = (lo >= n || lo + chunk >= n) ? n : zh_first_barrier(bar, lo + chunk, n);
    if (lo >= n || s0 >= s1) {
       if (lane == 0) {
          spanstart[blockIdx.x] = min(s0, n);
@@ -204,13 +208,13 @@ zh_tokenize_spans(const uint8_t *__restrict__ data, const zh_block_t *__restrict
 #define ZH_COMPACT_THREADS 256
 __global__ void __launch_bounds__(ZH_COMPACT_THREADS)
 zh_tokens_compact(const zh_block_t *__restrict__ blocks, uint32_t *tok_pos, uint16_t *tok_info, uint64_t tok_stride, const uint32_t *__restrict__ spanstart,
-                  const uint32_t *__restrict__ spancnt, uint32_t cpb, uint32_t *ntok_out) {
+                  const uint32_t *__restrict__ spancnt, uint32_t cpb, uint32_t chunk, uint32_t *ntok_out) {
    const uint32_t b = blockIdx.x, tid = threadIdx.x;
    const uint32_t n = blocks[b].n;
    uint32_t *tp = tok_pos + (uint64_t)b * tok_stride;
    uint16_t *ti = tok_info + (uint64_t)b * tok_stride;
    uint32_t total = 0;
-   for (uint32_t c = 0; c * ZH_TOK_CHUNK < n; c++) {
+   for (uint32_t c = 0; c * chunk < n; c++) {
       const uint32_t src = spanstart[b * cpb + c], m = spancnt[b * cpb + c];
       if (m && src != total) {
          // moving down in place: a step writes below what it has just read, and never above what later steps read
