@@ -103,7 +103,7 @@ struct zultra_hip_ctx_s {
    uint32_t *d_hugelist;
    uint4 *d_segtasks;           // tasks cut into speculative segments (zh_parse_chain.h): per max-block seg_tasks_per_block entries
    uint2 *d_segitems;           // their segments, as jobs of zh_parse_chain: per max-block seg_items_per_block entries
-   uint2 *d_segwaves;           // ... or as waves of zh_parse_segments (four segments each), likewise
+   uint2 *d_segwaves;           // ... or as segment waves of zh_parse_lanes' launch (four segments each), likewise
    uint32_t cut_len;            // ... into segments of about this many positions
    uint32_t demote_min;         // a cut task with this many failed cuts in a pass is parsed as one chain in the passes left (ZULTRA_HIP_DEMOTE; 0: never)
    uint32_t coop_tasks;         // ... a run of at most this many tasks counts as small (ZULTRA_HIP_COOP_TASKS, default: the number of CUs)
@@ -119,7 +119,7 @@ struct zultra_hip_ctx_s {
    int stagger_ev;              // event of the previous run that a run's matchfinder waits for (0: none)
    uint32_t last_run_pct;       // share of the last run, likewise
    uint32_t first_run_pct;      // share of the first run of a batch in percent of an equal share
-   uint32_t seg_wide;           // a run with at least this many segments parses them with zh_parse_segments (ZULTRA_HIP_SEG_WIDE)
+   uint32_t seg_wide;           // a run with at least this many segments parses them in the segment workgroups of zh_parse_lanes' launch (ZULTRA_HIP_SEG_WIDE)
    int16_t *d_vecs;             // two cost vectors per segment
    uint64_t seg_tasks_per_block, seg_items_per_block;
    uint64_t *d_chain_trace;     // diagnostics (ZULTRA_HIP_CHAIN_TRACE=1): [run][pass][ticket] {positions, start, end}
@@ -155,7 +155,7 @@ struct zultra_hip_ctx_s {
    int nlanes;
    hipStream_t lane_stream[ZH_MAX_RUNS];
    hipEvent_t lane_ev[ZH_MAX_RUNS][24];
-   hipStream_t side_stream[ZH_MAX_RUNS];     // per run: zh_parse_chain runs next to zh_parse_tasks
+   hipStream_t side_stream[ZH_MAX_RUNS];     // per run: zh_parse_chain runs next to zh_parse_lanes
    hipEvent_t side_ev[ZH_MAX_RUNS][8];       // per pass: fork, join
    hipEvent_t ev_input;
    zh_subblock_t *d_results_compact;
@@ -609,7 +609,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       if (c->coop_small < 64u) c->coop_small = 64u;
       if (c->coop_small > ZH_COOP_MIN) c->coop_small = ZH_COOP_MIN;
       c->seg_whole = (uint32_t)zh_env("ZULTRA_HIP_SEG_WHOLE", 16384);  // cut tasks shorter than this are parsed whole when zh_parse_chain takes the segments
-      c->seg_wide = (uint32_t)zh_env("ZULTRA_HIP_SEG_WIDE", 1024);     // a run with at least this many segments parses them with zh_parse_segments
+      c->seg_wide = (uint32_t)zh_env("ZULTRA_HIP_SEG_WIDE", 1024);     // a run with at least this many segments parses them in the segment workgroups of zh_parse_lanes' launch
       c->mf_lds_cap = (uint32_t)max(0, zh_env("ZULTRA_HIP_MF_CAP", (int)ZH_MFL_CAP_LIMIT));   // elements per chunk of zh_mf_group's refinement in LDS (zh_mf_group_lds.h)
       const int streams = zh_env("ZULTRA_HIP_STREAMS", 0);              // staggered runs per batch; not set: three, four for batches of 256 MiB and more
       c->nlanes = streams ? streams : 4;
@@ -929,7 +929,7 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
    uint2 *taskmap = c->d_taskmap + t0;
    uint2 *taskinfo = c->d_taskinfo + t0;
    uint32_t *hist_part = c->d_hist_part + t0 * ZH_NSYM, *task_bits = c->d_task_bits + t0;
-   uint32_t *hugelist = c->d_hugelist + 4 * t0;   // four lists of `cap` entries each: three by zh_list_huge, the cut tasks given up on by zh_parse_segments
+   uint32_t *hugelist = c->d_hugelist + 4 * t0;   // four lists of `cap` entries each: three by zh_list_huge, the cut tasks given up on by the segment workgroups
    const uint32_t cap = (uint32_t)zh_min64((uint64_t)nb * tasks_per_block, 0xFFFFFFFFull);
    uint4 *segtasks = c->d_segtasks + (uint64_t)b0 * c->seg_tasks_per_block;
    uint2 *segwaves = c->d_segwaves + (uint64_t)b0 * c->seg_items_per_block, *segitems = c->d_segitems + (uint64_t)b0 * c->seg_items_per_block;
@@ -999,7 +999,7 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
    if (!files) ZH_CHECK(c, hipEventRecord(ev[5], st));   // (timing marks)
    // Persistent workgroups of zh_parse_chain take the listed chains from a ticket (none listed: they leave at once); zh_parse_lanes takes the task
    // list in groups, as a grid that fills the chip's wave slots — next to chains only `lane_waves` per CU stay, so that the chain workgroups find
-   // room the moment they are launched (the run's counters tell the kernel which); zh_parse_segments takes the cut tasks' segments when there are many.
+   // room the moment they are launched (the run's counters tell the kernel which); the first workgroups of zh_parse_lanes' grid take the cut tasks' segments when there are many.
    const uint32_t tpw = zh_tasks_per_wave(c, est_tasks);
    const uint32_t lane_grid = max(1u, min((est_tasks + tpw - 1) / tpw, c->num_cus * 16u));
    // (two chain workgroups fit a CU — 169 registers, four waves — and they are persistent: a third per CU would only queue behind them, find the tickets

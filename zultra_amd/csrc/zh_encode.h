@@ -12,7 +12,7 @@
 // per-sub-block coder state (zh_sbstate_t: code lengths, codes, flags) lives in HBM between them:
 //
 //   zh_sb_init      wave per sub-block   greedy histogram -> static / dynamic price -> type; tentative (or fixed) codes
-//   4 x { zh_parse_tasks   wave per task        optimal parse of the task + histogram of its parse   (zh_parse.h)
+//   4 x { zh_parse_lanes   wave per group of tasks, zh_parse_chain next to it: optimal parse + histogram of the parse   (zh_parse_lanes.h, zh_parse_chain.h)
 //         zh_sb_build      wave per sub-block   sum the task histograms, rebuild both codes; after the 4th pass also the
 //                                               RLE-friendly alternative, the 20 code-length masks and the block header }
 //   zh_post_tasks   wave per task        literalisation (blockdeflate.c:410-458) and the bit count of the task's tokens
@@ -263,7 +263,7 @@ struct zh_cl_write_sink {
 };
 
 // ---- zh_sb_build: blockdeflate.c:887-919 for pass 0..3; after pass 3 also :925-992 -----------------------------------
-// One sub-block by one wave (all 64 lanes call; the syncs are the wave's: it may be one of several of a workgroup, zh_parse_own); `ws` is the
+// One sub-block by one wave (all 64 lanes call; the syncs are the wave's: it may be one of several of a workgroup); `ws` is the
 // wave's own workspace in LDS. Returns (in every lane) whether the sub-block has failed.
 __device__ __forceinline__ uint32_t zh_sb_build_one(zh_sb_ws_t &ws, const zh_work_t wk, zh_sbstate_t *st, const uint32_t *__restrict__ hist_part, uint8_t *payload, int pass, uint32_t *cnt /* the run's counters */) {
    if (st->failed) return 1u;

@@ -13,10 +13,11 @@
 // and the parse degrades gracefully to one serial chain per run.
 //
 // Work decomposition (no serial dependency anywhere between the units):
-//   task  = the positions of one sub-block between the barriers nearest to multiples of ZH_TASK; one wave per task,
-//           grid = all tasks of all sub-blocks of the batch (tens of thousands of waves: fills 256 CUs many times over).
-//   piece = a barrier-to-barrier run of >= ZH_PIECE positions inside a task; each 16-lane DPP row of the wave owns
-//           one piece at a time, so a wave advances FOUR independent recurrences per step.
+//   task  = the positions of one sub-block between the barriers nearest to multiples of ZH_TASK;
+//   piece = a barrier-to-barrier run of >= ZH_PIECE positions inside a task.
+// Who parses what (since round 3): zh_parse_lanes (zh_parse_lanes.h) takes the task list, a quad of lanes per piece; zh_parse_chain (zh_parse_chain.h) the tasks
+// with a barrier-free run too long for that, whole; and THIS file's row machinery — round 2's kernel: each 16-lane DPP row of a wave owns one piece, a wave advances
+// four recurrences per step — the speculative SEGMENTS such tasks are cut into when a run has many (below), in the first workgroups of zh_parse_lanes' launch.
 // Every forward walk over the chosen parse (histogram, literalisation, bit counting, emission) is a walk over tasks
 // too, because a task starts on a token boundary.
 //
@@ -42,7 +43,7 @@
 #endif
 #define ZH_MAXPIECES 64
 #ifndef ZH_COOP_MIN
-#define ZH_COOP_MIN 1536     // a task with a piece longer than this goes to zh_parse_huge (zh_parse_huge.h)
+#define ZH_COOP_MIN 1536     // a task with a piece longer than this goes to zh_parse_chain (zh_parse_chain.h), whole or cut into segments
 #endif
 #define ZH_NSYM (ZH_NLIT + ZH_NDIST)
 // Costs are kept modulo 2^16: within the 258 positions a step can look ahead, two costs differ by less than 258 x 15 bits
@@ -65,9 +66,9 @@ __device__ __forceinline__ uint32_t zh_ring_wrap(uint32_t x) { return min(x, x -
 // nothing is ever forgotten). And the choices left of b depend on the costs at b .. b+258 through their differences only (every
 // comparison is between sums that share the constant — the argument that makes barriers restart points, see the top of this
 // file). So a long task [t0, t1) whose longest matches are mostly shorter than 258 is cut at b_k = t1 - (K-1-k) S into K
-// segments, and the segments are PIECES like any other: four of them share a wave of zh_parse_tasks, one per row. Segment k
+// segments, and the segments are PIECES like any other: four of them share a wave (zh_parse_one_task<true>: the segment workgroups of zh_parse_lanes' launch), one per row. Segment k
 // starts at b_k + ZH_CUT_WARM, stores no parse entries at or above b_k, records the relative costs of [b_k, b_k + 258] as it
-// passes (speculated) and those of [b_{k-1}, b_{k-1} + 258] when it is done (its own left end). zh_parse_chain_fix
+// passes (speculated) and those of [b_{k-1}, b_{k-1} + 258] when it is done (its own left end). The wave that finishes a task last (below; zh_chain_check_task when zh_parse_chain takes the segments)
 // (zh_parse_chain.h) then walks each cut task from the right: the last segment is exact by construction; segment k is exact if
 // segment k+1 is and its speculated vector equals segment k+1's left one; otherwise it is parsed again from that (exact)
 // vector, as a chain. The output is the reference's parse bit for bit either way; speculation only decides how much of it was
@@ -79,7 +80,7 @@ __device__ __forceinline__ uint32_t zh_ring_wrap(uint32_t x) { return min(x, x -
 #define ZH_CUT_WARM 1024u         // warm-up positions right of a cut (a multiple of 32, 288 .. ZH_CUT_LEN)
 #endif
 #define ZH_CUT_MIN ZH_CUT_LEN      // tasks shorter than this stay whole (measured on JSON-like records, 50 MB: 8192 -> 45.4 ms, 4096 -> 43.6 ms, 2048 -> 43.3 ms)
-#define ZH_CUT_ROWS 4u            // segments per wave of zh_parse_segments
+#define ZH_CUT_ROWS 4u            // segments per wave (one per 16-lane row)
 // segtasks[].y: number of segments | their length / 32 << 12
 #define ZH_CUT_PACK(K, S) ((K) | (((S) >> 5) << 12))
 #define ZH_CUT_K(y) ((y) & 0xfffu)
@@ -553,7 +554,7 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
    // A failed cut is parsed again by this one wave on one of its rows, cut after cut: a task with several of them holds its pass up
    // for milliseconds. Speculation that failed under one pass's prices mostly fails under the next: such a task goes
    // to zh_parse_chain as ONE chain for the passes left — a workgroup there steps several times faster than a row — by an entry in the
-   // run's fourth chain list; zh_parse_segments skips it from then on.
+   // run's fourth chain list; the segment workgroups skip it from then on.
    if (SEG && demote_min && seg_nfail >= demote_min && pass < 3 && lane == 0) {
       atomicOr(seg_done - 2, ZH_CUT_DEMOTED);   // (segtasks[].y; seg_done points at .w, the counter)
       demote_list[atomicAdd(&cnt[ZH_CNT_DEMOTED], 1u)] = gt;
@@ -572,7 +573,7 @@ __device__ __forceinline__ void zh_parse_one_task(zh_parse_ws_t &ws, uint32_t gt
 }
 
 // Which of the two ways a run's cut tasks are parsed (see "speculative segments" above): many segments are throughput — four to a wave of
-// zh_parse_segments, which also checks them; a few are latency — each one a job of zh_parse_chain (five times faster per position). Decided on
+// the segment workgroups of zh_parse_lanes' launch, which also check them; a few are latency — each one a job of zh_parse_chain (five times faster per position). Decided on
 // the device from the run's counters (zh_list_huge), the same way by both kernels (zh_parse_lanes takes the wide case in the first workgroups of its grid): the host launches both and never reads the counts.
 __device__ __forceinline__ bool zh_segments_are_wide(const uint32_t *cnt, uint32_t seg_wide_min) {
    return cnt[ZH_CNT_SEGTASKS] != 0 && cnt[ZH_CNT_SEGITEMS] >= seg_wide_min;

@@ -41,7 +41,7 @@
 
 // ---- segments of cut tasks (see "speculative segments", zh_parse.h) as chain jobs ---------------------------------------------
 // When a run has few cut tasks their segments are latency, not throughput: a four-wave chain workgroup prices a position in
-// 0.054 us, a row of zh_parse_segments in about 0.3 us. The host then hands the segments to zh_parse_chain (a segment = a job
+// 0.054 us, a 16-lane row of the segment workgroups (zh_parse.h) in about 0.3 us. The host then hands the segments to zh_parse_chain (a segment = a job
 // with a made-up end, a limit for its parse entries and vectors to record); the workgroup that finishes a task's last
 // segment checks the task (zh_chain_check_task).
 #ifndef ZH_TRACE_SLOTS
@@ -337,7 +337,7 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
    }
    __syncthreads();
    // the recurrence is the critical path of the whole batch: its wave outranks the throughput waves it shares a SIMD with
-   // (zh_parse_tasks of the same pass, the other run's kernels); the producers must keep up with it
+   // (zh_parse_lanes of the same pass, the other run's kernels); the producers must keep up with it
    if (wave == 0)
       zh_set_wave_priority_high();
    else
@@ -415,9 +415,9 @@ __device__ inline void zh_chain_parse(zh_chain_ws_t &ws, const uint4 *rows, cons
 #undef ZH_CHAIN_TILE_CNT
 }
 
-// the tasks zh_parse_tasks leaves alone: one wave per task, the same piece computation. cnt = the run's counters (ZH_CNT_*).
+// the tasks zh_parse_lanes leaves alone: one wave per task, the same piece computation. cnt = the run's counters (ZH_CNT_*).
 // Tasks of at least seg_min positions that are not periodic are cut into segments (zh_parse.h): listed in segtasks, with one
-// entry of segitems per segment (for zh_parse_chain) and one entry of segwaves per four segments (for zh_parse_segments): the
+// entry of segitems per segment (for zh_parse_chain) and one entry of segwaves per four segments (for the segment workgroups of zh_parse_lanes' launch): the
 // host picks one of the two ways by the number of segments in the run.
 __device__ __forceinline__ void zh_list_huge_one(uint32_t *bnd /* LDS, ZH_MAXPIECES + 1 */, uint32_t gt, const zh_block_t *__restrict__ blocks, const uint64_t *__restrict__ bars, uint64_t bar_stride,
                                                  const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ longest, uint64_t longest_stride,
@@ -445,13 +445,13 @@ __device__ __forceinline__ void zh_list_huge_one(uint32_t *bnd /* LDS, ZH_MAXPIE
       for (uint32_t p = t0 + lane; p < t1; p += 64) full += (lg[4u * (p - prev)] & 0xffffu) >= ZH_MAX_MATCH ? 1u : 0u;   // (slot 0 of the position's row)
       full = zh_wave_sum(full);
       if (2u * full <= len) {
-         // K segments of S positions, segment 0 the short one: as many as fill whole waves of zh_parse_segments (ZH_CUT_ROWS each)
+         // K segments of S positions, segment 0 the short one: as many as fill whole segment waves (ZH_CUT_ROWS each)
          // with about cut_len (ZH_CUT_LEN) positions per row
          uint32_t K = ZH_CUT_ROWS * ((len + ZH_CUT_ROWS * cut_len - 1u) / (ZH_CUT_ROWS * cut_len));
          if (len / K < ZH_CUT_WARM) K = max(2u, len / ZH_CUT_WARM);   // (a segment is never shorter than the warm-up)
          const uint32_t S = ((len + K - 1u) / K + 31u) & ~31u;
          K = (len + S - 1u) / S;
-         const uint32_t nw = (K + ZH_CUT_ROWS - 1u) / ZH_CUT_ROWS;   // waves of zh_parse_segments
+         const uint32_t nw = (K + ZH_CUT_ROWS - 1u) / ZH_CUT_ROWS;   // segment waves
          uint32_t ti = 0, w0 = 0, it = 0;
          if (lane == 0) {
             ti = atomicAdd(&cnt[ZH_CNT_SEGTASKS], 1u);
@@ -564,7 +564,7 @@ __device__ __forceinline__ void zh_chain_histogram(zh_chain_ws_t &ws, const zh_c
    for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) ws.hist[k] = 0;
    __syncthreads();
    zh_walk_histogram_wave(ws.hist, T.win, T.prev, (tid >> 6) == 0 ? T.t0 : T.t1, T.t1, T.best);   // the other waves walk nothing
-   zh_sync();   // (the walk ends with a sync of its own wave only: zh_parse_own calls it from waves that are not in step)
+   zh_sync();   // (the walk ends with a sync of its own wave only)
    for (uint32_t k = tid; k < ZH_NSYM; k += ZH_CHAIN_THREADS) hp[k] = ws.hist[k];
 }
 
@@ -603,7 +603,7 @@ __device__ inline void zh_chain_check_task(zh_chain_ws_t &ws, uint32_t *s_bad_p,
 }
 
 // Persistent workgroups take the listed items from a ticket: the grid is small and fixed (ZH_CHAIN_GRID), so it is dispatched at
-// once — next to zh_parse_tasks' tens of thousands of waves — and every chain starts at the beginning of the pass. Ticket order:
+// once — next to zh_parse_lanes' thousands of waves — and every chain starts at the beginning of the pass. Ticket order:
 // the whole tasks of the two long classes, the segments of the cut tasks, the short whole tasks.
 #define ZH_CHAIN_GRID 1536
 #ifndef ZH_CHAIN_VGPR_ATTR
@@ -619,7 +619,7 @@ zh_parse_chain(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
    __shared__ zh_chain_ws_t ws;
    __shared__ uint32_t s_item, s_bad;
    const uint32_t tid = threadIdx.x;
-   // the cut tasks that zh_parse_segments gave up on in the passes before this one (zh_parse_one_task: the fourth list, in the order of the
+   // the cut tasks that the segment workgroups gave up on in the passes before this one (zh_parse_one_task: the fourth list, in the order of the
    // passes): whole chains, and the longest of the pass — they get the first tickets
    uint32_t ndem = 0;
    for (int q = 0; q < pass; q++) ndem += cnt[ZH_CNT_DEMOTED_PASS + q];

@@ -1,7 +1,7 @@
 // zh_parse_lanes.h — the backward optimal parse (reference src/blockdeflate.c:254-323, zultra_optimize_matches_lwd) with a
 // QUAD OF LANES PER PIECE: a wave advances 16 independent recurrences per step, and a step is ~140 wave instructions.
 //
-// Why. zh_parse_tasks (zh_parse.h) gives a piece to a 16-lane row, lane s pricing length 3+s: whatever the position offers, a
+// Why. Round 2's kernel (zh_parse_tasks; its row machinery lives on in zh_parse.h for the speculative segments) gave a piece to a 16-lane row, lane s pricing length 3+s: whatever the position offers, a
 // step costs the same ~120 wave instructions for four positions (profiles/r02e_sq_counters.csv: 31.7 vector instructions per
 // position and pass, the vector unit saturated). What a position needs is much less once the work is ordered differently.
 //
@@ -28,9 +28,9 @@
 // p-1-q — two batches ahead of their use, stages them in LDS, and stores the four parse entries of a batch with one instruction.
 //
 // Work: a wave takes ZH_LP_TASKS consecutive tasks of the run's task list (zh_parse.h: a task = ~2048 positions between two
-// barriers), groups them by sub-block (prices differ), cuts each task into the same pieces as zh_parse_tasks did and hands the
+// barriers), groups them by sub-block (prices differ), cuts each task into pieces (zh_task_pieces) and hands the
 // pieces to its quads, the long ones first, a new one whenever a quad runs out. Tasks with a barrier-free run of more than
-// ZH_COOP_MIN positions are left to zh_parse_chain / zh_parse_segments exactly as before (zh_list_huge lists them with the same
+// ZH_COOP_MIN positions are left to zh_parse_chain / the segment workgroups of this launch (zh_list_huge lists them with the same
 // test). The histogram of the chosen parse (blockdeflate.c:371-400) is taken by the 64 lanes, each walking pieces forward (a
 // piece starts on a token boundary), and stored in the slot of the group's first task (zh_sb_build sums a sub-block's slots).
 #pragma once
@@ -107,7 +107,7 @@ struct zh_lp_batch_t {
 };
 
 // Parses the tasks [g0, g1) of one sub-block (all of sub-block tm.x). All 64 lanes of ONE wave call; the workspace is the wave's own, and the
-// syncs are the wave's (zh_wave_sync): the wave may be one of several of a workgroup (zh_parse_own).
+// syncs are the wave's (zh_wave_sync): the wave may be one of several of a workgroup.
 __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_t g1, const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks,
                                             const zh_match_t *__restrict__ match, uint64_t match_stride, const uint64_t *__restrict__ bars, uint64_t bar_stride,
                                             const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const zh_sbstate_t *__restrict__ states,
@@ -162,7 +162,7 @@ __device__ __forceinline__ void zh_lp_group(zh_lp_ws_t &ws, uint32_t g0, uint32_
    uint64_t parsed = 0;   // bit j: task g0 + j is parsed here
    for (uint32_t gt = g0; gt < g1; gt++) {
       // the task's range, and whether it has a barrier-free run of more than ZH_COOP_MIN positions: zh_list_huge has listed such a
-      // task for zh_parse_chain / zh_parse_segments — and left both here
+      // task for zh_parse_chain / the segment workgroups — and left both here
       const uint2 ti = taskinfo[gt];
       if (ti.y >> 31) continue;
       const uint32_t t0 = ti.x, t1 = ti.y;
@@ -552,7 +552,7 @@ struct zh_seg_args_t {
 // Behind them, single-wave workgroups take groups of tasks_per_wave consecutive tasks from *ticket until the run's task list — whose length only the device
 // knows (cnt[ZH_CNT_TASKS]) — is used up. The host gives a wave up to ZH_LP_TASKS tasks — a pool of pieces large enough to keep its sixteen quads
 // busy — but no more than it takes to give every wave slot of the chip a wave: a small batch (one 40 KB input: 20 tasks) is a matter of latency,
-// not of lane utilisation. Next to chains (zh_parse_chain, zh_parse_segments: the run's counters say whether it has any) only the first
+// not of lane utilisation. Next to chains (zh_parse_chain, the segment workgroups: the run's counters say whether it has any) only the first
 // `bounded` workgroups stay: a grid that keeps every wave slot, register and LDS granule of the chip taken would make the four-wave workgroup that
 // carries the longest chain of the batch wait for room until the grid has drained (measured, tools/probes/chain2_probe.hip: a 3.6 ms chain next to
 // such a grid ended after 25 ms).
