@@ -1,6 +1,6 @@
 # GPU box: one step of 100 MB of synthetic text, fresh process, round-4 tree against the current one: timelines
 O=gpurun_out/r05; mkdir -p $O; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-export DEBUG_HIP_DYNAMIC_QUEUES=1 GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=8
 timeout 300 rocprofv3 --kernel-trace -d $O/kt_a -o kt --output-format csv -- python3 tools/step_dev.py zultra_amd/libzultra_amd.so 100000000 text 5 > $O/syn5_r05.txt 2>&1
 python tools/timeline.py $(find $O/kt_a -name "*kernel_trace.csv" | head -1) $O/timeline_text_r05.txt
 rm -rf $O/kt_a
