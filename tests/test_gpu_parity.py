@@ -231,6 +231,18 @@ def test_a_run_needs_no_host_decision(gpu, oracle):
     assert gpu.memory_compress(d, 2, 65536) == want
 
 
+def test_token_chain_chunk_size_follows_the_batch(gpu, oracle):
+    """A batch of at most 32 max-blocks follows its token chain in chunks of 2048 positions, a larger one in chunks of 16 Ki (zh_split.h: the chunk size is a
+    kernel argument since round 5). The same bytes at 32 and at 33 max-blocks — data with barrier-free stretches longer than a small chunk, matches that cross
+    chunk boundaries, and a ragged last block — are the oracle's streams."""
+    base = np.concatenate([corpus.text_like(40000, 5), corpus.duplicated(70000, 6, 700), corpus.constant(9000, 3), corpus.indented(50000, 8),
+                           corpus.periodic(30000, 7, 2), corpus.json_like(60000, 4)])
+    d = np.resize(base, 33 * 32768 - 5000)
+    for nblocks in (32, 33):
+        part = d[: nblocks * 32768 - 5000]
+        assert gpu.memory_compress(part, 1, 32768) == oracle.memory_compress(part, 1, 32768), nblocks
+
+
 def test_streaming_output_cadence(gpu, oracle, monkeypatch):
     """libzultra.c:424-462 publishes output after every max-block; the device build collects max-blocks into batches, but a caller that
     feeds small pieces with ZULTRA_CONTINUE sees output once ZULTRA_HIP_FLUSH_BYTES of full blocks are staged (default 4 MiB), not
