@@ -38,3 +38,14 @@ def ref():
         else:
             pytest.skip("compiled reference (oracle/_ref) not available")
     return zlibs.Ref()
+
+
+@pytest.fixture(scope="session")
+def checker(oracle):
+    """What the GPU suite compares the device with: the COMPILED REFERENCE itself (oracle/_ref/libzultra_ref.so, built from /root/reference by
+    oracle/Makefile; it travels to the GPU box with the snapshot) behind the oracle's interface — stage by stage and on whole streams — and, only
+    where that file is absent, the restatement that tests/test_oracle_vs_ref.py pins to it."""
+    import zlibs
+    if zlibs.have_ref():
+        return zlibs.RefStages()
+    return oracle

@@ -234,3 +234,53 @@ class Ref:
 
     def probe(self, max_block, win, prev, n):
         return Ref.Probe(self, max_block, win, prev, n)
+
+
+class RefStages:
+    """The compiled reference behind the Oracle's interface (find_matches / split / costs / deflate / memory_compress /
+    memory_bound): the GPU suite's checker wherever oracle/_ref travelled (tests/conftest.py `checker`). One probe of the
+    reference's compressor state is kept per window and reused by the stage calls that follow find_matches, which is the
+    order every caller uses (tests/parity_util.py)."""
+
+    def __init__(self):
+        self.ref = Ref()
+        self._probe = None
+        self._key = None
+
+    def _get(self, win, prev, n):
+        win = as_u8(win)
+        key = (win.ctypes.data, len(win), prev, n, int(win[:: max(1, len(win) // 64)].sum()))
+        if self._probe is None or self._key != key:
+            if self._probe is not None:
+                self._probe.close()
+            mb = 32768
+            while mb < n:
+                mb <<= 1
+            self._probe = self.ref.probe(mb, win, prev, n)   # (keeps its own reference to the window)
+            self._key = key
+        return self._probe
+
+    def find_matches(self, win, prev, n):
+        if self._probe is not None:   # a new analysis: never reuse a probe across calls on a buffer that may have been rewritten in place
+            self._probe.close()
+            self._probe = None
+        return self._get(win, prev, n).matches()
+
+    def split(self, win, match, prev, n):
+        return self._get(win, prev, n).split()
+
+    def costs(self, win, match, prev, start, size):
+        p = self._probe
+        assert p is not None and p.prev == prev, "costs() follows find_matches() on the same window"
+        return p.costs(start, size)
+
+    def deflate(self, win, match, prev, start, size, is_dynamic):
+        p = self._probe
+        assert p is not None and p.prev == prev, "deflate() follows find_matches() on the same window"
+        return p.deflate(start, size, is_dynamic)
+
+    def memory_bound(self, n, flags, max_block):
+        return self.ref.memory_bound(n, flags, max_block)
+
+    def memory_compress(self, data, flags, max_block, dictionary=None, cap=None):
+        return self.ref.memory_compress(data, flags, max_block, dictionary=dictionary, cap=cap)

@@ -28,7 +28,9 @@ def key(name):
 
 counters = {}
 for name, cname, n, total in db.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
-    counters.setdefault(key(name), {})[cname] = (n, float(total))
+    # (the <true> and <false> instances of a kernel share a key: their counters ADD — round 5's file held whichever instance came last, zeros for five kernels)
+    n0, t0 = counters.setdefault(key(name), {}).get(cname, (0, 0.0))
+    counters[key(name)][cname] = (n0 + n, t0 + float(total))
 dur = {}
 for name, n, total in db.execute("select name, count(*), sum(duration) from kernels group by name"):
     k = key(name)

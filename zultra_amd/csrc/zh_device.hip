@@ -79,6 +79,8 @@ struct zultra_hip_ctx_s {
    std::vector<uint32_t> seg_base;
    zh_match_t *d_match;
    uint32_t lane_tasks;         // zh_parse_lanes: tasks per wave when forced (0: chosen per run)
+   uint32_t lane_tasks_last;    // ... of the batch's last run, whose passes are the tail of the step (0: like the others)
+   uint32_t run_share[ZH_MAX_RUNS];   // shares of the runs of a batch in per mille of its max-blocks (run_share[0] == 0: equal shares, see first_run_pct / last_run_pct)
    uint32_t mf_lds_cap;         // zh_mf_group: chunk size of the refinement in LDS, 0 = through HBM
    uint32_t *d_pay;             // zh_mf_group: 3 x sort_stride words per persistent workgroup (payload of the refining sort passes)
    uint32_t *d_longest;         // (round 2: a copy of slot 0 of every match row; no longer written — its readers take the rows)
@@ -629,6 +631,22 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       c->split_waves = (uint32_t)zh_knob("ZULTRA_HIP_SPLIT_WAVES", 0);               // waves per splitter workgroup (2, 4, 8, 16; default by max-block size)
       c->lane_waves = (uint32_t)max(1, min(16, zh_knob("ZULTRA_HIP_LANE_WAVES", 12)));
       c->lane_tasks = (uint32_t)max(0, min((int)ZH_LP_TASKS, zh_knob("ZULTRA_HIP_LANE_TASKS", 0)));   // tasks per wave of zh_parse_lanes; 0: by the size of the run
+      c->lane_tasks_last = (uint32_t)max(0, min((int)ZH_LP_TASKS, zh_knob("ZULTRA_HIP_LANE_TASKS_LAST", 0)));
+      memset(c->run_share, 0, sizeof(c->run_share));
+#ifdef ZH_TUNING_KNOBS
+      if (const char *rs = getenv("ZULTRA_HIP_RUN_SHARES")) {   // probe builds: "500,300,150,50" — as many runs, of these shares (per mille)
+         int n = 0;
+         while (*rs && n < ZH_MAX_RUNS) {
+            c->run_share[n++] = (uint32_t)atoi(rs);
+            while (*rs && *rs != ',' && *rs != ':') rs++;
+            if (*rs) rs++;
+         }
+         if (n >= 1 && streams == 0) {
+            c->nlanes = n;
+            c->auto_runs = 0;
+         }
+      }
+#endif
       c->mf_cu_pct = (uint32_t)max(1, min(100, zh_knob("ZULTRA_HIP_MF_CUS", 100)));  // share of the CUs the matchfinder's persistent workgroups take, in percent
       c->stagger_ev = zh_knob("ZULTRA_HIP_STAGGER", 2);   // which stage of the previous run a run's matchfinder waits for: 0 none, 2 zh_mf_group, 3 zh_mf_frontier, 4 the splitter
                                                           // (measured, 2 instead of 3: 100 MB of real text 51.9 -> 49.8 ms, configuration 3 31.6 -> 30.5, configuration 4 972 -> 910)
@@ -857,7 +875,8 @@ static int zh_build_segments(zultra_hip_ctx_t *c, const zultra_hip_block_t *bloc
 }
 
 // tasks a wave of zh_parse_lanes takes (zh_parse_lanes.h): as many as ZH_LP_TASKS, as few as it takes to fill the chip's wave slots
-static uint32_t zh_tasks_per_wave(const zultra_hip_ctx_t *c, uint32_t ntasks) {
+static uint32_t zh_tasks_per_wave(const zultra_hip_ctx_t *c, uint32_t ntasks, bool last_run) {
+   if (last_run && c->lane_tasks_last) return c->lane_tasks_last;
    if (c->lane_tasks) return c->lane_tasks;   // ZULTRA_HIP_LANE_TASKS, read once at context creation
    const uint32_t slots = c->total_cus * 8u;   // (measured: eight tasks per wave at 16 K tasks per run beat four by 2 % of the step)
    return max(1u, min((uint32_t)ZH_LP_TASKS, (ntasks + slots - 1) / slots));
@@ -1000,7 +1019,7 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
    // Persistent workgroups of zh_parse_chain take the listed chains from a ticket (none listed: they leave at once); zh_parse_lanes takes the task
    // list in groups, as a grid that fills the chip's wave slots — next to chains only `lane_waves` per CU stay, so that the chain workgroups find
    // room the moment they are launched (the run's counters tell the kernel which); the first workgroups of zh_parse_lanes' grid take the cut tasks' segments when there are many.
-   const uint32_t tpw = zh_tasks_per_wave(c, est_tasks);
+   const uint32_t tpw = zh_tasks_per_wave(c, est_tasks, !files && c->last_runs > 1 && k == c->last_runs - 1);
    const uint32_t lane_grid = max(1u, min((est_tasks + tpw - 1) / tpw, c->num_cus * 16u));
    // (two chain workgroups fit a CU — 169 registers, four waves — and they are persistent: a third per CU would only queue behind them, find the tickets
    // gone and leave; and in a run without chains every workgroup of this grid has to find a slot among the quad kernel's waves before the pass can end)
@@ -1249,6 +1268,13 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    auto run_lo = [&](int k) -> uint32_t {
       if (k <= 0) return 0u;
       if (k >= lanes) return nblocks;
+      if (c->run_share[0]) {   // explicit shares (set for `lanes` runs); a run is never empty
+         uint64_t acc = 0, tot = 0;
+         for (int j = 0; j < lanes; j++) tot += c->run_share[j] ? c->run_share[j] : 1u;
+         for (int j = 0; j < k; j++) acc += c->run_share[j] ? c->run_share[j] : 1u;
+         const uint64_t lo = (uint64_t)nblocks * acc / tot;
+         return (uint32_t)zh_min64(zh_max64(lo, (uint64_t)k), (uint64_t)nblocks - (uint64_t)(lanes - k));
+      }
       // (a run is never empty: with ZULTRA_HIP_FIRST_RUN / _LAST_RUN below 25 and four max-blocks per run the shares rounded to 0, and a
       // zero-sized grid fails the batch)
       const uint64_t first = zh_max64(1, (uint64_t)nblocks * c->first_run_pct / (100ull * (uint64_t)lanes));
@@ -1586,6 +1612,16 @@ extern "C" int zultra_hip_lp_profile(unsigned long long *out, int reset) {
       unsigned long long z[16] = {0};
       if (hipMemcpyToSymbol(HIP_SYMBOL(zh_lp_prof), z, sizeof(z)) != hipSuccess) return -1;
    }
+   return 0;
+}
+#endif
+
+#ifdef ZH_LP_TRACE
+extern "C" int zultra_hip_lp_trace(unsigned long long *out /* 4 passes x ZH_LP_TRACE_SLOTS x 4 */, unsigned int *slots) {
+   if (slots) *slots = ZH_LP_TRACE_SLOTS;
+   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(zh_lp_trace), sizeof(zh_lp_trace)) != hipSuccess) return -1;
+   static unsigned long long z[4u * ZH_LP_TRACE_SLOTS * 4u];
+   if (out && hipMemcpyToSymbol(HIP_SYMBOL(zh_lp_trace), z, sizeof(z)) != hipSuccess) return -1;
    return 0;
 }
 #endif

@@ -70,6 +70,13 @@ __device__ unsigned long long zh_lp_prof[16];   // 8..11: cycles of the batch st
 #define ZH_LP_CLOCK() 0
 #endif
 
+#ifdef ZH_LP_TRACE
+// probe builds only (tools/lp_trace.py): per pass and ticket of the LAST launch that ran {wall clock when the wave started, when it took the ticket, when it was done with
+// it, blockIdx << 32 | HW_ID}
+#define ZH_LP_TRACE_SLOTS 8192u
+__device__ uint64_t zh_lp_trace[4u * ZH_LP_TRACE_SLOTS * 4u];
+#endif
+
 struct alignas(16) zh_lp_ws_t {
    union {
       struct {
@@ -583,6 +590,9 @@ zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       return;
    }
    zh_lp_ws_t &ws = sh.ws;
+#ifdef ZH_LP_TRACE
+   const uint64_t trace_born = zh_wall_clock();
+#endif
    const uint32_t ntasks = cnt[ZH_CNT_TASKS];
    if (blockIdx.x - sg.seg_grid >= bounded && (cnt[ZH_CNT_VLONG] | cnt[ZH_CNT_LONG] | cnt[ZH_CNT_SHORT] | cnt[ZH_CNT_SEGTASKS]) != 0u) return;
    for (;;) {
@@ -594,6 +604,9 @@ zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       const uint32_t g0 = w * tasks_per_wave;
       if (g0 >= ntasks) return;
       const uint32_t g1 = min(ntasks, g0 + tasks_per_wave);
+#ifdef ZH_LP_TRACE
+      const uint64_t trace_t0 = zh_wall_clock();
+#endif
       // the wave's tasks, sub-block by sub-block
       for (uint32_t g = g0; g < g1;) {
          const uint32_t sb = taskmap[g].x;
@@ -602,6 +615,15 @@ zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
          zh_lp_group(ws, g, ge, data, blocks, match, match_stride, bars, bar_stride, work, taskmap, states, best_all, best_stride, cost_all, hist_part, pass, taskinfo);
          g = ge;
       }
+#ifdef ZH_LP_TRACE
+      if (zh_lane() == 0 && w < ZH_LP_TRACE_SLOTS) {
+         uint64_t *tr = zh_lp_trace + ((uint64_t)pass * ZH_LP_TRACE_SLOTS + w) * 4u;
+         tr[0] = trace_born;
+         tr[1] = trace_t0;
+         tr[2] = zh_wall_clock();
+         tr[3] = ((uint64_t)blockIdx.x << 32) | (uint64_t)__builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | (31 << 11));
+      }
+#endif
       if (!ticket) return;
    }
 }
