@@ -469,6 +469,8 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup, last_rank=None):
 
     def step():
         if ctx is not None:
+            if world == 1 and not group:   # one rank: the stream starts at phase 0 here — the stitch goes out with the batch (zultra_hip_stitch_with_batch)
+                ctx.stitch_with_batch(nblocks - 1, phase=0)
             ctx.compress_blocks(d_data.data_ptr(), blocks, data_on_device=True, data_size=d_data.numel())
             t = ctx.timing()
             extra = np.array([shard_checksum(), n], dtype=np.int64)

@@ -181,12 +181,20 @@ size_t zultra_hip_stitch_finish(zultra_hip_bitstate_t *state, uint8_t *out, size
  */
 int zultra_hip_stitch_device(zultra_hip_ctx_t *ctx, zultra_hip_bitstate_t *state, int final_block, uint64_t *end_bit);
 /*
+ * The next batch of max-blocks (zultra_hip_compress_blocks) is stitched at bit phase `phase` (0..7; final_block as for zultra_hip_stitch_device) right behind
+ * its last kernel, before the host is woken: a caller that knows the phase its batch starts at — every batch of a stream compressed batch by batch
+ * (libzultra.c:327-398 carries the phase from max-block to max-block), the first job of zultra_memory_compress — saves the second synchronisation. The
+ * zultra_hip_stitch_device call that follows with the same phase and final_block returns that stitch's result without launching anything; with other
+ * arguments it stitches again. The setting is consumed by one batch. enable = 0 disarms. Returns 0, -1 for a files context.
+ */
+int zultra_hip_stitch_with_batch(zultra_hip_ctx_t *ctx, int enable, uint32_t phase, int final_block);
+/*
  * Where the last batch would end for each of the eight bit phases it could start at (the same scan, nothing written):
  * end_bits[p] counts from the start of the byte that holds the p pending bits; bit p of *failed_mask is set where the
  * reference would fail with ZULTRA_ERROR_DST from that phase. What a device hands its neighbours when one stream
  * (libzultra.c:601-619) is cut over several of them: a shard's bit length depends on the phase it starts at.
  */
-int zultra_hip_stitch_phase_table(zultra_hip_ctx_t *ctx, uint64_t *end_bits /* 8 */, uint32_t *failed_mask);
+int zultra_hip_stitch_phase_table(zultra_hip_ctx_t *ctx, uint64_t *end_bits /* 8 */, uint32_t *failed_mask);   /* (rewrites the last stitch's items and report: stitch again before reading the stream) */
 const void *zultra_hip_stream_device(const zultra_hip_ctx_t *ctx);
 int zultra_hip_stream_read(zultra_hip_ctx_t *ctx, void *out, size_t offset, size_t nbytes);
 

@@ -186,7 +186,7 @@ def test_multiblock_stream_bit_carry_and_stored_fallback(emu, oracle):
     assert zlib.decompress(got, 31) == d.tobytes()
 
 
-def _scan_vs_planner(lib):
+def _scan_vs_planner(lib, more=True):
     """The device scan of the stitcher (zh_stitch_scan: transfer tables bit phase -> bits added, composed over the batch) against the serial
     host planner (zh_stitch_plan, behind zultra_hip_stitch), at every one of the eight start phases: same bytes, same end bit, same new phase;
     and the eight-entry phase table a rank hands its neighbours (zultra_hip_stitch_phase_table) = the eight end bits."""
@@ -201,6 +201,9 @@ def _scan_vs_planner(lib):
     blocks = [(b * bs - (bs if b else 0), bs if b else 0, min(bs, len(d) - b * bs)) for b in range(nb)]
     ctx = lib.context(bs, nb)
     try:
+        # (round 6) the stitch at phase 0 goes out WITH the batch (zultra_hip_stitch_with_batch): the first stitch_device call of the loop below returns its
+        # result without a launch, the seven others — other phases — stitch again
+        ctx.stitch_with_batch(nb - 1, phase=0)
         ctx.compress_blocks(d, blocks)
         subs, _, cnt = ctx.subblocks()
         assert cnt > nb   # the splitter cut at least one max-block
@@ -223,12 +226,56 @@ def _scan_vs_planner(lib):
             assert int(ends[ph]) == end_bit, (ph, int(ends[ph]), end_bit)
             stored.add(end_bit - ph)
         assert len(stored) > 1   # the shard's bit length does depend on the phase it starts at (stored sub-blocks pad to a byte)
+        # a stitch that goes out WITH its batch (zultra_hip_stitch_with_batch, round 6): armed for one batch, its result returned by the stitch_device call
+        # that follows with the same arguments — the same bytes as a stitch of its own; other arguments stitch again
+        for ph in ((0, 5) if more else ()):   # (the emulator suite stops here: a batch takes it a minute)
+            from zultra_amd._ffi import BitState
+            want, st = ctx.stitch(d, offs, bs, nb - 1, state=BitState(0, ph), finish=False)
+            ctx.stitch_with_batch(nb - 1, phase=ph)
+            ctx.compress_blocks(d, blocks)
+            assert ctx.timing()["stitch_ms"] > 0 or "emu" in lib.path   # (the batch's own timing carries the stitch)
+            end_bit, nacc = ctx.stitch_device(nb - 1, phase=ph)
+            got = ctx.stream_read((end_bit + 7) // 8)
+            assert nacc == st.nacc and got[:len(want)].tobytes() == want, "with the batch, phase %d" % ph
+            other = (ph + 3) & 7
+            want2, st2 = ctx.stitch(d, offs, bs, nb - 1, state=BitState(0, other), finish=False)
+            end2, nacc2 = ctx.stitch_device(nb - 1, phase=other)
+            assert nacc2 == st2.nacc and ctx.stream_read((end2 + 7) // 8)[:len(want2)].tobytes() == want2, "restitched at phase %d" % other
+            ctx.compress_blocks(d, blocks)   # (not armed any more: a stitch of its own)
+            end3, _ = ctx.stitch_device(nb - 1, phase=ph)
+            assert end3 == end_bit and ctx.stream_read((end3 + 7) // 8)[:len(want)].tobytes() == want
     finally:
         ctx.close()
 
 
 def test_device_scan_equals_the_host_planner_at_every_phase(emu):
-    _scan_vs_planner(emu)
+    _scan_vs_planner(emu, more=False)
+
+
+def _overflow_forms(lib, checker, monkeypatch, sizes):
+    """The <true> forms of zh_sb_init / zh_sb_build / zh_list_huge / zh_post_tasks / zh_emit_tasks — a few workgroups that stride over whatever lies beyond
+    the <false> grid — are reached by a run with more sub-blocks than max(4 x max-blocks, 1024) or more tasks than bytes / 2048 + 4 x max-blocks only.
+    ZULTRA_HIP_GRID_CAP caps the <false> grids (here at 1 and at 3 workgroups), so that nearly every sub-block and task of a batch that splits into many
+    sub-blocks goes through the strided forms: stages and streams are the checker's."""
+    from parity_util import check_window
+    stretch, nstretch, caps, streams = sizes
+    parts = []
+    for k in range(nstretch):   # stretches over byte values of their own, neighbours in different bins of the splitter's statistics: many sub-blocks
+        r = corpus.noise(stretch, 500 + k)
+        parts.append(((((k >> 2) & 3) << 6) | ((r & 15) << 2) | (k & 3)).astype(np.uint8))
+    many = np.concatenate(parts)
+    d = np.concatenate([corpus.text_like(32768, 3), many, corpus.text_like(20000, 4), corpus.noise(3000, 1)])
+    for cap in caps:
+        monkeypatch.setenv("ZULTRA_HIP_GRID_CAP", cap)
+        st = {}
+        check_window(lib, checker, many, 0, len(many), max_block=1 << 20, tag="overflow_forms/cap" + cap, stats_out=st)
+        assert st["subblocks"] >= 3 and st["tasks"] > int(cap) + 2, st
+        for flags, bs in streams:
+            assert lib.memory_compress(d, flags, bs) == checker.memory_compress(d, flags, bs), (cap, flags, bs)
+
+
+def test_strided_overflow_forms_of_the_per_item_kernels(emu, oracle, monkeypatch):
+    _overflow_forms(emu, oracle, monkeypatch, (12288, 4, ("1",), ()))   # (48 KB: the emulator takes a minute)
 
 
 def test_dictionary_stream(emu, oracle):

@@ -220,17 +220,37 @@ def test_device_scan_equals_the_host_planner_at_every_phase(gpu):
     _scan_vs_planner(gpu)
 
 
-def test_a_run_needs_no_host_decision(gpu, checker):
+def test_strided_overflow_forms_of_the_per_item_kernels(gpu, checker, monkeypatch):
+    """ZULTRA_HIP_GRID_CAP = 1 / 3: nearly every sub-block and task goes through the <true> forms of the per-sub-block / per-task kernels (the emulator
+    suite's check on the real kernels, with 41 sub-blocks in one max-block)."""
+    from test_emu_parity import _overflow_forms
+    _overflow_forms(gpu, checker, monkeypatch, (32768, 32, ("1", "3"), ((2, 32768), (0, 65536))))
+
+
+@pytest.mark.parametrize("runs", ["1", "2", "3"])
+def test_a_run_needs_no_host_decision(gpu, checker, monkeypatch, runs):
     """Sub-block counts, task counts, chains and cut tasks are summed up on the device (zh_plan_subblocks, zh_list_huge) and every later kernel takes
     its bounds from the run's counters; the host sizes grids from the input bytes alone. A batch whose max-blocks split very unevenly — one max-block of
-    forty short stretches of different statistics next to max-blocks that do not split at all — over one, two and three runs: the bytes are the oracle's."""
+    forty short stretches of different statistics next to max-blocks that do not split at all, then 12 MiB of text — as one, two and three runs
+    (ZULTRA_HIP_STREAMS; the run count is asserted): the bytes are the checker's."""
     parts = [corpus.text_like(65536, 3)]
     rng = np.random.default_rng(5)
     many = np.concatenate([corpus.selftest_data(1600, 100 + k, int(rng.integers(2, 200)), float(rng.uniform(0.0, 0.9))) for k in range(41)])[:65536]
     parts += [many, corpus.constant(65536, 7), corpus.duplicated(65536, 4, 900), corpus.noise(65536, 9), corpus.indented(65536, 2)] * 2
+    parts += [corpus.text_like_fast(12 << 20, 77)]   # (a batch is cut into as many runs as it has multiples of 4 MiB, at most ZULTRA_HIP_STREAMS: 13 MiB for three)
     d = np.concatenate(parts)
+    monkeypatch.setenv("ZULTRA_HIP_STREAMS", runs)
     want = checker.memory_compress(d, 2, 65536)
     assert gpu.memory_compress(d, 2, 65536) == want
+    # ... and the device layer did cut the batch into that many runs (zh_compact_results lays their descriptors end to end)
+    bs = 65536
+    nb = (len(d) + bs - 1) // bs
+    ctx = gpu.context(bs, nb)
+    try:
+        ctx.compress_blocks(d, [(b * bs - (32768 if b else 0), 32768 if b else 0, min(bs, len(d) - b * bs)) for b in range(nb)])
+        assert ctx.stats()["runs"] == int(runs), ctx.stats()
+    finally:
+        ctx.close()
 
 
 def test_token_chain_chunk_size_follows_the_batch(gpu, checker):

@@ -79,7 +79,7 @@ EXPORTS = [
     "zultra_hip_stitch_device", "zultra_hip_stitch_phase_table", "zultra_hip_stream_device", "zultra_hip_stream_read", "zultra_hip_block_crc32", "zultra_crc32_append", "zultra_crc32_append_many",
     "zultra_hip_create_files", "zultra_hip_compress_files", "zultra_hip_stitch_files", "zultra_hip_staging",
     "zultra_hip_block_adler32", "zultra_adler32_append", "zultra_hip_copy_bandwidth", "zultra_hip_last_stats",
-    "zultra_hip_ctx_info", "zultra_hip_context_bytes", "zultra_hip_context_bytes_on", "zultra_release_cached_contexts", "zultra_hip_chain_trace", "zultra_hip_cut_tasks",
+    "zultra_hip_ctx_info", "zultra_hip_context_bytes", "zultra_hip_context_bytes_on", "zultra_release_cached_contexts", "zultra_hip_chain_trace", "zultra_hip_cut_tasks", "zultra_hip_stitch_with_batch",
 ]
 
 
@@ -90,10 +90,11 @@ def _as_u8(data):
 
 
 class Lib:
-    def __init__(self, path):
+    def __init__(self, path, allow_missing=()):
+        """allow_missing: exports an OLDER build of the library may lack (A/B tools under tools/ that load a previous round's build; the product loader passes none)."""
         self.path = path
         L = self.L = C.CDLL(path)
-        missing = [n for n in EXPORTS if not hasattr(L, n)]
+        missing = [n for n in EXPORTS if not hasattr(L, n) and n not in allow_missing]
         if missing:
             raise ZultraError("%s does not export %s" % (path, missing))
         L.zultra_stream_init.argtypes = [C.POINTER(_Stream), C.c_uint, C.c_uint]
@@ -388,6 +389,14 @@ class HipContext:
         if self.lib.L.zultra_hip_get_parse(self.h, block, m.ctypes.data) != 0:
             raise ZultraError("get_parse")
         return m
+
+    def stitch_with_batch(self, final_block, phase=0, enable=True):
+        """Arms the next compress_blocks to stitch at `phase` behind its last kernel (zultra_hip_stitch_with_batch); stitch_device with the same
+        arguments then returns that result without a launch."""
+        L = self.lib.L
+        L.zultra_hip_stitch_with_batch.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int]
+        if L.zultra_hip_stitch_with_batch(self.h, 1 if enable else 0, phase, final_block) != 0:
+            raise ZultraError("zultra_hip_stitch_with_batch")
 
     def stitch_device(self, final_block, phase=0):
         """Device stitcher over the last batch -> (end_bit, new_phase); the stream stays in HBM (stream_ptr)."""

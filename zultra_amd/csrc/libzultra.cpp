@@ -684,6 +684,8 @@ static zultra_status_t compress_staged(zultra_stream_t *s, zultra_compressor_t *
       consumed += n;
    }
    const size_t data_size = (size_t)c->prev + consumed;
+   // the phase this batch starts at is what the batches before it left (libzultra.c:327-398): its stitch goes out with its kernels
+   if (!c->host_stitch) (void)zultra_hip_stitch_with_batch(c->hip, 1, c->bitstate.nacc, final_last ? (int)count - 1 : -1);
    int nsubs = zultra_hip_compress_blocks(c->hip, c->in + base, data_size, 0, c->blocks, count);
    if (nsubs <= 0) return ZULTRA_ERROR_COMPRESSION;
 
@@ -963,6 +965,8 @@ static void mem_lane_body(MemLanes *M, size_t lane) {
             blocks[b].prev = prev;
             blocks[b].n = (uint32_t)(at + M->bs <= M->n_in ? M->bs : M->n_in - at);
          }
+         // the stream's first job starts at phase 0: its stitch goes out with its kernels (the later jobs' phases are known when the jobs before them are stitched)
+         if (j == 0) (void)zultra_hip_stitch_with_batch(c, 1, 0, M->jobs.size() == 1 ? (int)J.nblocks - 1 : -1);
          ok = zultra_hip_compress_blocks(c, stage, hist + (last - first), in_place ? 2 : 0, blocks.data(), (uint32_t)J.nblocks) > 0;
       }
       {

@@ -78,6 +78,10 @@ struct zultra_hip_ctx_s {
    std::vector<zh_seg_t> segs;
    std::vector<uint32_t> seg_base;
    zh_match_t *d_match;
+   // a stitch enqueued with its batch (zultra_hip_stitch_with_batch): armed for the next batch; what the last batch was stitched with, if it was
+   int ab_armed, ab_final, stitched_valid, stitched_final, stitched_rc;
+   uint32_t ab_phase, stitched_phase;
+   uint32_t grid_cap;           // ZULTRA_HIP_GRID_CAP (tests): the <false> grids of the per-sub-block / per-task kernels are capped here, so that the <true> forms behind them get work
    uint32_t lane_tasks;         // zh_parse_lanes: tasks per wave when forced (0: chosen per run)
    uint32_t lane_tasks_last;    // ... of the batch's last run, whose passes are the tail of the step (0: like the others)
    uint32_t run_share[ZH_MAX_RUNS];   // shares of the runs of a batch in per mille of its max-blocks (run_share[0] == 0: equal shares, see first_run_pct / last_run_pct)
@@ -174,6 +178,7 @@ struct zultra_hip_ctx_s {
    uint32_t *d_nsubs, *h_nsubs, *d_blk_start;
    zh_scan_out_t *d_scan_out, *h_scan_out;
    uint64_t *d_file_off;      // files mode: first byte of every input's stream
+   uint32_t *d_task_prefix, *h_task_prefix;   // files mode: exclusive prefix of the inputs' task counts, computed by the host from the sizes it was handed (zh_plan_files); B + 1 entries
    uint32_t *d_stream;        // stitched deflate bits of the last batch
    size_t stream_cap;         // bytes
    uint32_t *d_crc, *d_crc_tables, *d_adler;
@@ -502,6 +507,8 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_blk_start);
    (void)hipFree(c->d_scan_out);
    (void)hipFree(c->d_file_off);
+   (void)hipFree(c->d_task_prefix);
+   if (c->h_task_prefix) (void)hipHostFree(c->h_task_prefix);
    if (c->h_nsubs) (void)hipHostFree(c->h_nsubs);
    if (c->h_scan_out) (void)hipHostFree(c->h_scan_out);
    (void)hipFree(c->d_ntasks);
@@ -567,6 +574,16 @@ static int zh_knob(const char *name, int dflt) {
 #endif
 }
 
+static int zh_enqueue_stitch(zultra_hip_ctx_t *c, hipStream_t st, uint32_t phase, int final_block, int files, bool scan_only, bool clear);
+static int zh_stitch_verdict(zultra_hip_ctx_t *c, bool scan_only);
+
+// streams (and payload areas) a context holds for the staggered runs of a batch: ZULTRA_HIP_STREAMS, 0 or unset = auto = four (zh_create_buffers and
+// zultra_hip_context_bytes_on must agree: the host layer budgets batches with the latter)
+static int zh_env_lanes(void) {
+   const int streams = zh_env("ZULTRA_HIP_STREAMS", 0);
+   return streams > 0 ? min(streams, (int)ZH_MAX_RUNS) : 4;
+}
+
 static int zh_create_buffers(zultra_hip_ctx_t *c) {
    const uint64_t B = c->max_blocks, N = c->max_block;
    ZH_CHECK(c, hipSetDevice(c->device));
@@ -611,11 +628,13 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       if (c->coop_small < 64u) c->coop_small = 64u;
       if (c->coop_small > ZH_COOP_MIN) c->coop_small = ZH_COOP_MIN;
       c->seg_whole = (uint32_t)zh_env("ZULTRA_HIP_SEG_WHOLE", 16384);  // cut tasks shorter than this are parsed whole when zh_parse_chain takes the segments
+      c->grid_cap = (uint32_t)max(0, zh_env("ZULTRA_HIP_GRID_CAP", 0));   // tests: cap of the <false> grids of zh_sb_init / zh_sb_build / zh_list_huge / zh_post_tasks / zh_emit_tasks (0: none) — the
+                                                                          // <true> forms that stride over what lies beyond a grid are otherwise reached by heavily splitting data only
       c->seg_wide = (uint32_t)zh_env("ZULTRA_HIP_SEG_WIDE", 1024);     // a run with at least this many segments parses them in the segment workgroups of zh_parse_lanes' launch
       c->mf_lds_cap = (uint32_t)max(0, zh_env("ZULTRA_HIP_MF_CAP", (int)ZH_MFL_CAP_LIMIT));   // elements per chunk of zh_mf_group's refinement in LDS (zh_mf_group_lds.h)
       const int streams = zh_env("ZULTRA_HIP_STREAMS", 0);              // staggered runs per batch; not set: three, four for batches of 256 MiB and more
-      c->nlanes = streams ? streams : 4;
-      c->auto_runs = streams ? 0 : 1;   // (measured with the stagger below, runs = 2 / 3 / 4 / 6: 100 MB of real text 49.8 / 49.6 / 51.2 / - ms; configuration 3
+      c->nlanes = zh_env_lanes();
+      c->auto_runs = streams > 0 ? 0 : 1;   // (measured with the stagger below, runs = 2 / 3 / 4 / 6: 100 MB of real text 49.8 / 49.6 / 51.2 / - ms; configuration 3
                                         // 31.0 / 29.1 / 29.5 / -; 1 GiB of configuration 4 910 / 883 / 789 / 812)
       if (c->nlanes < 1) c->nlanes = 1;
       if (c->nlanes > ZH_MAX_RUNS) c->nlanes = ZH_MAX_RUNS;
@@ -671,6 +690,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       memset(c->h_nsubs, 0, (1 + ZH_MAX_RUNS) * sizeof(uint32_t));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_crc, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_blocks, B * sizeof(zh_block_t), 0));
+      if (c->files_mode) ZH_CHECK(c, hipHostMalloc((void **)&c->h_task_prefix, (B + 1) * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_segs, B * c->segs_per_block * sizeof(zh_seg_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_ntasks, 2 * ZH_NCNT * sizeof(uint32_t), 0));   // a mirror of d_ntasks + per-run readbacks
       memset(c->h_ntasks, 0, 2 * ZH_NCNT * sizeof(uint32_t));
@@ -683,7 +703,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
    c->seg_tasks_per_block = c->files_mode ? 1 : N / (2u * ZH_CUT_WARM) + 1;
    c->seg_items_per_block = c->files_mode ? 1 : N / ZH_CUT_WARM + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;   // a task of len positions has at most len / ZH_CUT_LEN + ZH_CUT_ROWS segments
    if (zh_alloc(c, &c->d_bars, B * c->bar_stride) || zh_alloc(c, &c->d_states, B * c->max_subs) || zh_alloc(c, &c->d_taskmap, c->max_tasks) || zh_alloc(c, &c->d_taskinfo, c->max_tasks) ||
-       zh_alloc(c, &c->d_nsubs, 1 + ZH_MAX_RUNS) || zh_alloc(c, &c->d_blk_start, B + 1) || zh_alloc(c, &c->d_scan_out, 1) || (c->files_mode && zh_alloc(c, &c->d_file_off, B + 1)) ||
+       zh_alloc(c, &c->d_nsubs, 1 + ZH_MAX_RUNS) || zh_alloc(c, &c->d_blk_start, B + 1) || zh_alloc(c, &c->d_scan_out, 1) || (c->files_mode && (zh_alloc(c, &c->d_file_off, B + 1) || zh_alloc(c, &c->d_task_prefix, B + 1))) ||
        zh_alloc(c, &c->d_prev3, B * c->segs_per_block * c->sort_stride) || zh_alloc(c, &c->d_runs, B * c->segs_per_block * c->run_stride) ||
        zh_alloc(c, &c->d_segs, B * c->segs_per_block) || zh_alloc(c, &c->d_chunk_ctr, 2 * B * c->segs_per_block + 3 * ZH_MAX_RUNS) || zh_alloc(c, &c->d_ntasks, ZH_NCNT) || zh_alloc(c, &c->d_hugelist, 4 * c->max_tasks) ||
        zh_alloc(c, &c->d_segtasks, B * c->seg_tasks_per_block) || zh_alloc(c, &c->d_segwaves, B * c->seg_items_per_block) || zh_alloc(c, &c->d_segitems, B * c->seg_items_per_block) ||
@@ -822,8 +842,7 @@ extern "C" size_t zultra_hip_context_bytes_on(int device, uint32_t max_block_siz
       // payload of the matchfinder's refining passes: per run (ZULTRA_HIP_STREAMS) and persistent workgroup (one per CU)
       int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-      const char *e = getenv("ZULTRA_HIP_STREAMS");
-      const uint64_t lanes = (uint64_t)max(1, min((int)ZH_MAX_RUNS, e ? atoi(e) : 4));
+      const uint64_t lanes = (uint64_t)zh_env_lanes();   // (what zh_create_buffers allocates for: 0 or unset = four)
       bytes += lanes * zh_min64((uint64_t)cus, B * S) * 3 * sort_stride * 4;
       // cut tasks (zh_parse.h): lists and two cost vectors per segment
       const uint64_t seg_tasks = N / (2u * ZH_CUT_WARM) + 1, seg_items = N / ZH_CUT_WARM + ZH_CUT_ROWS * (N / (2u * ZH_CUT_WARM) + 1) + 2;
@@ -961,9 +980,13 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
    const uint32_t mf_grid = min(nsg, max(1u, c->num_cus * c->mf_cu_pct / 100u));   // persistent workgroups, one per CU (zh_matchfinder.h)
    // grids: bounded by what the input bytes allow, sized for what data usually gives; the kernels stride
    const uint32_t est_tasks = (uint32_t)zh_min64(cap, total_n / ZH_TASK + 2ull * nb);                                   // tasks: ~ bytes / 2048 + one per sub-block
-   const uint32_t task_grid = cap <= 2048u ? cap : (uint32_t)zh_min64(cap, total_n / ZH_TASK + 4ull * nb);               // one wave per task (zh_list_huge, zh_post_tasks, zh_emit_tasks)
+   uint32_t task_grid = cap <= 2048u ? cap : (uint32_t)zh_min64(cap, total_n / ZH_TASK + 4ull * nb);               // one wave per task (zh_list_huge, zh_post_tasks, zh_emit_tasks)
    const uint64_t sb_bound = (uint64_t)nb * c->max_subs;
-   const uint32_t sb_grid = (uint32_t)zh_min64(sb_bound, zh_max64(4ull * nb, 1024));   // one wave per sub-block (zh_sb_init, zh_sb_build)
+   uint32_t sb_grid = (uint32_t)zh_min64(sb_bound, zh_max64(4ull * nb, 1024));   // one wave per sub-block (zh_sb_init, zh_sb_build)
+   if (c->grid_cap) {   // (tests: everything beyond the cap goes through the <true> forms)
+      task_grid = max(1u, min(task_grid, c->grid_cap));
+      sb_grid = max(1u, min(sb_grid, c->grid_cap));
+   }
    const uint64_t seg_bound = (uint64_t)nb * c->seg_items_per_block;                     // entries of segwaves (zh_list_huge)
    if (part != 2) {
       ZH_LAUNCH_LDS(zh_mf_group<true>, mf_grid, ZH_MF_THREADS, ZH_MF_GROUP_LDS, st, c->cur_data, sgs, sa, sb, p3, rn, c->sort_stride, c->run_stride, 0, nsg, ctr + (size_t)nsg * 2 + 1, pay,
@@ -1005,7 +1028,10 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
 #define ZH_LAUNCH_PLAN(T_)                                                                                                                                                               \
    ZH_LAUNCH(zh_plan_subblocks<T_>, 1, T_, st, blk, nb, (const uint32_t *)(c->d_tok_pos + (uint64_t)b0 * c->tok_stride), c->tok_stride, (const uint32_t *)(c->d_ntok + b0),              \
              (const uint32_t *)(c->d_split_tok + (uint64_t)b0 * (ZH_MAX_SPLITS + 1)), (const uint32_t *)(c->d_split_cnt + b0), c->d_sub_base + b0, c->slot_stride, work, taskmap, cnt)
-   if (nb > 4096u)
+   if (files)   // one sub-block per input, the task ranges from the sizes the host was handed (zh_plan_files)
+      ZH_LAUNCH(zh_plan_files, (nb + ZH_PLAN_FILES_THREADS - 1) / ZH_PLAN_FILES_THREADS, ZH_PLAN_FILES_THREADS, st, blk, nb, (const uint32_t *)(c->d_ntok + b0), (const uint32_t *)(c->d_task_prefix + b0),
+                c->d_sub_base + b0, c->slot_stride, work, taskmap, cnt);
+   else if (nb > 4096u)
       ZH_LAUNCH_PLAN(1024u);
    else
       ZH_LAUNCH_PLAN(256u);
@@ -1247,6 +1273,9 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       return -1;
    }
    ZH_CHECK(c, hipSetDevice(c->device));
+   const bool stitch_now = c->ab_armed && !c->files_mode;   // (one batch only)
+   c->ab_armed = 0;
+   c->stitched_valid = 0;
    c->nblocks = nblocks;
    c->nsubs = 0;
    c->blocks.assign((const zh_block_t *)blocks, (const zh_block_t *)blocks + nblocks);
@@ -1307,6 +1336,16 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    }
    memcpy(c->h_blocks, blocks, nblocks * sizeof(zh_block_t));
    ZH_CHECK(c, hipMemcpyAsync(c->d_blocks, c->h_blocks, nblocks * sizeof(zh_block_t), hipMemcpyHostToDevice, st0));
+   if (c->files_mode) {
+      // one sub-block per input, ceil(size / ZH_TASK) tasks each: the task ranges of zh_plan_files, from the sizes alone
+      uint32_t acc = 0;
+      for (uint32_t b = 0; b < nblocks; b++) {
+         c->h_task_prefix[b] = acc;
+         acc += (blocks[b].n + ZH_TASK - 1) / ZH_TASK;
+      }
+      c->h_task_prefix[nblocks] = acc;
+      ZH_CHECK(c, hipMemcpyAsync(c->d_task_prefix, c->h_task_prefix, ((size_t)nblocks + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st0));
+   }
    if (zh_build_segments(c, blocks, nblocks, st0) != 0) return -1;
    ZH_CHECK(c, hipEventRecord(c->ev_input, st0));
    if (c->files_mode) return zh_run_files(c, nblocks);
@@ -1371,6 +1410,13 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, side, c->cur_data, (const zh_block_t *)(c->d_blocks + b0), (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
       // token bits are ORed into the payload slots: cleared there too, long before stage 3 needs them
       ZH_CHECK(c, hipMemsetAsync(c->d_payload + (uint64_t)b0 * c->slot_stride, 0, (size_t)nb * c->slot_stride, side));
+      if (stitch_now && k == 0) {
+         // ... and so is the stream buffer of a stitch that goes out with the batch (zh_enqueue_stitch): nobody reads it between two batches' stitches
+         uint64_t bound = 16;
+         for (uint32_t b = 0; b < nblocks; b++) bound += (uint64_t)blocks[b].n + 5ull * (blocks[b].n / 65535u + 1u);
+         bound += 5ull * (uint64_t)nblocks * c->max_subs;
+         ZH_CHECK(c, hipMemsetAsync(c->d_stream, 0, (size_t)zh_min64((uint64_t)c->stream_cap + 16, (bound + 3) & ~3ull), side));
+      }
       if (zh_enqueue_run(c, k, b0, nb, total_n, max_n, sg0, nsg, st, side, 0) != 0) return -1;
       ZH_CHECK(c, hipMemcpyAsync(c->h_crc + b0, c->d_crc + b0, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       ZH_CHECK(c, hipMemcpyAsync(c->h_adler + 2 * (size_t)b0, c->d_adler + 2 * (size_t)b0, 2 * nb * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1382,6 +1428,11 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    // (the host's copy of the descriptors — the getters' — needs the count: a small batch copies what it can hold with the counts, one wait instead of two)
    const bool copy_bound = (uint64_t)nblocks * c->max_subs * sizeof(zh_subblock_t) <= (256u << 10);
    if (copy_bound) ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results_compact, (size_t)nblocks * c->max_subs * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st0));
+   if (stitch_now) {
+      // the stitch behind the batch's last kernel (zultra_hip_stitch_with_batch): scan, bit mover and the scan's report before the host's one wait
+      ZH_CHECK(c, hipEventRecord(c->ev[0], st0));
+      if (zh_enqueue_stitch(c, st0, c->ab_phase, c->ab_final, 0, false, false) != 0) return -1;
+   }
    ZH_CHECK(c, hipStreamSynchronize(st0));
    ZH_CHECK(c, hipGetLastError());
    const uint32_t nsubs = c->h_nsubs[0];
@@ -1424,6 +1475,13 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    }
    c->timing.matchfinder_ms = c->timing.group_ms + c->timing.frontier_ms;
    c->timing.encode_ms = c->timing.init_ms + c->timing.parse_ms + c->timing.build_ms + c->timing.post_ms + c->timing.emit_ms;
+   if (stitch_now) {
+      (void)hipEventElapsedTime(&c->timing.stitch_ms, c->ev[0], c->ev[1]);
+      c->stitched_rc = zh_stitch_verdict(c, false);
+      c->stitched_phase = c->ab_phase;
+      c->stitched_final = c->ab_final;
+      c->stitched_valid = 1;
+   }
    return (int)nsubs;
 }
 
@@ -1458,29 +1516,38 @@ extern "C" int zultra_hip_block_crc32(const zultra_hip_ctx_t *c, uint32_t *out) 
 
 // The stream assembly of the last batch on the device: the scan that decides where every sub-block goes (zh_stitch_scan), then the kernel that puts
 // it there (zh_stitch). files: every max-block a stream of its own. One synchronisation, at the end, for the 80 bytes the scan reports.
-static int zh_stitch_on_device(zultra_hip_ctx_t *c, uint32_t phase, int final_block, int files, bool scan_only = false) {
-   ZH_CHECK(c, hipSetDevice(c->device));
-   hipStream_t st = c->stream;
-   ZH_CHECK(c, hipEventRecord(c->ev[0], st));
-   if (!scan_only) {
+// The stitch of the batch whose descriptors zh_compact_results has laid out (or will have, on `st`): clears what the bits are ORed into — unless the caller
+// has (clear = false) —, the scan, the bit mover, the 80 bytes the scan reports. The grids need no count from the host: the scan is one workgroup, the mover strides
+// over scan->nsubs. Enqueues only.
+static int zh_enqueue_stitch(zultra_hip_ctx_t *c, hipStream_t st, uint32_t phase, int final_block, int files, bool scan_only, bool clear) {
+   if (!scan_only && clear) {
       // the stream buffer must be zero where bits will be ORed in: everything the batch can fill — no sub-block takes more than its stored form,
       // size + 5 bytes per 65535 + the three header bits
       uint64_t bound = 16;
       for (uint32_t b = 0; b < c->nblocks; b++) bound += (uint64_t)c->blocks[b].n + 5ull * (c->blocks[b].n / 65535u + 1u);
-      bound += 5ull * c->nsubs;
-      const size_t clear = (size_t)zh_min64((uint64_t)c->stream_cap + 16, (bound + 3) & ~3ull);
-      ZH_CHECK(c, hipMemsetAsync(c->d_stream, 0, clear, st));
+      bound += 5ull * (uint64_t)c->nblocks * c->max_subs;
+      const size_t clear_bytes = (size_t)zh_min64((uint64_t)c->stream_cap + 16, (bound + 3) & ~3ull);
+      ZH_CHECK(c, hipMemsetAsync(c->d_stream, 0, clear_bytes, st));
+   }
+   // (the scan's chunk tables are 32-bit: a chunk of ceil(nblocks / 1024) max-blocks must stay below 2^32 bits — only HBM capacity has ruled that out so far)
+   if (((uint64_t)c->nblocks + ZH_SCAN_THREADS - 1) / ZH_SCAN_THREADS * zh_stitch_blockbuf_cap(c->max_block < ZH_MIN_BLOCK ? (uint32_t)ZH_MIN_BLOCK : c->max_block) * 8ull >= (1ull << 32)) {
+      snprintf(c->err, sizeof(c->err), "batch too large for the stream assembly's 32-bit chunk tables (%u max-blocks of %u bytes)", c->nblocks, c->max_block);
+      return -1;
    }
    ZH_LAUNCH(zh_stitch_scan, 1, ZH_SCAN_THREADS, st, (const zh_subblock_t *)c->d_results_compact, (const uint32_t *)c->d_nsubs, c->nblocks, phase,
              files ? (c->max_block < ZH_MIN_BLOCK ? (uint32_t)ZH_MIN_BLOCK : c->max_block) : c->max_block, final_block, files, c->d_blk_start, c->d_items, c->d_file_off, c->d_scan_out);
-   if (!scan_only)
-      ZH_LAUNCH(zh_stitch, c->nsubs, ZH_STITCH_THREADS, st, (const zh_subblock_t *)c->d_results_compact, (const zh_stitch_item_t *)c->d_items, (const zh_block_t *)c->d_blocks, c->cur_data,
+   if (!scan_only) {
+      const uint32_t grid = (uint32_t)zh_min64((uint64_t)c->nblocks * c->max_subs, zh_max64(4ull * c->nblocks, 1024));
+      ZH_LAUNCH(zh_stitch, grid, ZH_STITCH_THREADS, st, (const zh_subblock_t *)c->d_results_compact, (const zh_stitch_item_t *)c->d_items, (const zh_block_t *)c->d_blocks, c->cur_data,
                 (const uint8_t *)c->d_payload, c->d_stream, (const zh_scan_out_t *)c->d_scan_out, (uint64_t)c->stream_cap);
+   }
    ZH_CHECK(c, hipEventRecord(c->ev[1], st));
    ZH_CHECK(c, hipMemcpyAsync(c->h_scan_out, c->d_scan_out, sizeof(zh_scan_out_t), hipMemcpyDeviceToHost, st));
-   ZH_CHECK(c, hipStreamSynchronize(st));
-   ZH_CHECK(c, hipGetLastError());
-   if (!scan_only) (void)hipEventElapsedTime(&c->timing.stitch_ms, c->ev[0], c->ev[1]);
+   return 0;
+}
+
+// ... and what the host makes of the scan's report, once the stream has been waited for
+static int zh_stitch_verdict(zultra_hip_ctx_t *c, bool scan_only) {
    if (c->h_scan_out->nsubs != c->nsubs) {
       snprintf(c->err, sizeof(c->err), "stream assembly saw %u sub-blocks, the batch has %u", c->h_scan_out->nsubs, c->nsubs);
       return -1;
@@ -1497,13 +1564,39 @@ static int zh_stitch_on_device(zultra_hip_ctx_t *c, uint32_t phase, int final_bl
    return 0;
 }
 
+static int zh_stitch_on_device(zultra_hip_ctx_t *c, uint32_t phase, int final_block, int files, bool scan_only = false) {
+   ZH_CHECK(c, hipSetDevice(c->device));
+   hipStream_t st = c->stream;
+   c->stitched_valid = 0;   // (the items and the scan's report are rewritten)
+   ZH_CHECK(c, hipEventRecord(c->ev[0], st));
+   if (zh_enqueue_stitch(c, st, phase, final_block, files, scan_only, true) != 0) return -1;
+   ZH_CHECK(c, hipStreamSynchronize(st));
+   ZH_CHECK(c, hipGetLastError());
+   if (!scan_only) (void)hipEventElapsedTime(&c->timing.stitch_ms, c->ev[0], c->ev[1]);
+   return zh_stitch_verdict(c, scan_only);
+}
+
+// The next batch of max-blocks (zultra_hip_compress_blocks) is stitched at bit phase `phase` (final_block as for zultra_hip_stitch_device) BEHIND ITS LAST KERNEL,
+// before the host is woken: a caller who knows the phase its batch starts at — the first batch of a stream, any batch of a stream compressed batch by batch —
+// saves the second synchronisation and what its thread does between the two calls (0.8 ms of a 38 ms step, profiles/r05_timeline_c2.txt). The
+// zultra_hip_stitch_device call that follows, with the same phase and final_block, returns that stitch's result without launching anything; any other call
+// stitches again as before. One batch only: the setting is consumed by the batch. Not for files contexts.
+extern "C" int zultra_hip_stitch_with_batch(zultra_hip_ctx_t *c, int enable, uint32_t phase, int final_block) {
+   if (!c || c->files_mode) return -1;
+   c->ab_armed = enable ? 1 : 0;
+   c->ab_phase = phase & 7u;
+   c->ab_final = final_block;
+   return 0;
+}
+
 // Device stitch of the last batch. state->nacc = pending bits (phase) before the batch; on return state->nacc = pending
 // bits after it and *end_bit = total bits from the start of the byte that held the pending bits. The stream buffer
 // holds ceil(end_bit / 8) bytes; its first byte carries only this batch's bits (OR the caller's pending bits in).
 extern "C" int zultra_hip_stitch_device(zultra_hip_ctx_t *c, zultra_hip_bitstate_t *state, int final_block, uint64_t *end_bit) {
    ZH_EMU_SERIALIZE();
    if (!c || !state || !end_bit || c->nsubs == 0) return -1;
-   const int rc = zh_stitch_on_device(c, state->nacc & 7u, final_block, 0);
+   // (a stitch that went out with the batch, zultra_hip_stitch_with_batch: its result is at hand)
+   const int rc = (c->stitched_valid && c->stitched_phase == (state->nacc & 7u) && c->stitched_final == final_block) ? c->stitched_rc : zh_stitch_on_device(c, state->nacc & 7u, final_block, 0);
    if (rc != 0) return rc;
    const uint64_t eb = c->h_scan_out->end_bit;
    state->nacc = (uint32_t)(eb & 7);

@@ -127,6 +127,40 @@ zh_plan_subblocks(const zh_block_t *__restrict__ blocks, uint32_t nblocks, const
    }
 }
 
+// Files mode: an input below 8192 bytes is never split (blockdeflate.c:646), so a batch of inputs has one sub-block per input by construction and the task ranges
+// follow from the inputs' sizes alone — which the host has (it was handed them): task_prefix = the exclusive prefix of ceil(size / ZH_TASK) over the batch's inputs,
+// uploaded with the block list. A thread per input, any number of workgroups. (Rounds 4-5 ran zh_plan_subblocks<1024> here: ONE workgroup looping over 32 768 inputs
+// with five dependent loads each — 2.9 ms per launch on the 65 536-input batches of configuration 5, 5 ms next to another run's matchfinder, on the path to the run's
+// first parse pass.) task_prefix points at the run's first input; sub-block and task indices are local to the run.
+#define ZH_PLAN_FILES_THREADS 256
+__global__ void __launch_bounds__(ZH_PLAN_FILES_THREADS)
+zh_plan_files(const zh_block_t *__restrict__ blocks, uint32_t nblocks, const uint32_t *__restrict__ ntok, const uint32_t *__restrict__ task_prefix, uint32_t *sub_base,
+              uint64_t slot_stride, zh_work_t *work, uint2 *taskmap, uint32_t *cnt /* the run's counters */) {
+   const uint32_t b = blockIdx.x * ZH_PLAN_FILES_THREADS + threadIdx.x;
+   const uint32_t base = task_prefix[0];
+   if (b == 0) {
+      cnt[ZH_CNT_NSUBS] = nblocks;
+      cnt[ZH_CNT_TASKS] = task_prefix[nblocks] - base;
+   }
+   if (b >= nblocks) return;
+   const zh_block_t blk = blocks[b];
+   zh_work_t w;
+   w.block = b;
+   w.start = blk.prev;          // the first token sits on the input's first byte
+   w.size = blk.n;
+   w.tok0 = 0;
+   w.tok1 = ntok[b];
+   w.out_off = (uint64_t)b * slot_stride;
+   w.out_cap = (blk.n + 8u + 3u) & ~3u;
+   w.index = b;
+   w.ntasks = (blk.n + ZH_TASK - 1) / ZH_TASK;
+   w.task_base = task_prefix[b] - base;
+   w.pad = 0;
+   for (uint32_t j = 0; j < w.ntasks; j++) taskmap[w.task_base + j] = make_uint2(b, j);
+   work[b] = w;
+   sub_base[b] = b;
+}
+
 // ---- LDS workspace of the per-sub-block kernels -----------------------------------------------------------------
 // 8 KB: twenty one-wave workgroups of zh_sb_init / zh_sb_build per CU. The kernels are chains of dependent LDS round trips on one wave (or one
 // lane), their throughput is the number of them a CU holds; with every array laid side by side (15 KB) it held ten. What is never live at the same

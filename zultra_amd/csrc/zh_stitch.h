@@ -109,12 +109,10 @@ __device__ __forceinline__ void zh_or_bits(uint32_t *out, uint64_t bit, uint32_t
 
 // out must be zero-filled. One workgroup per sub-block. Nothing is written when the scan found that the reference would fail, or that the stream
 // would not fit the buffer (the host reports either after the one synchronisation of a stitch).
-__global__ void __launch_bounds__(ZH_STITCH_THREADS)
-zh_stitch(const zh_subblock_t *__restrict__ subs, const zh_stitch_item_t *__restrict__ items, const zh_block_t *__restrict__ blocks,
-          const uint8_t *__restrict__ data, const uint8_t *__restrict__ payload, uint32_t *out, const zh_scan_out_t *__restrict__ scan, uint64_t stream_cap) {
-   if (scan->failed || ((scan->end_bit + 7) >> 3) + 8 > stream_cap) return;
-   const zh_subblock_t sb = subs[blockIdx.x];
-   const zh_stitch_item_t it = items[blockIdx.x];
+__device__ __forceinline__ void zh_stitch_one(uint32_t s, const zh_subblock_t *__restrict__ subs, const zh_stitch_item_t *__restrict__ items, const zh_block_t *__restrict__ blocks,
+                                              const uint8_t *__restrict__ data, const uint8_t *__restrict__ payload, uint32_t *out) {
+   const zh_subblock_t sb = subs[s];
+   const zh_stitch_item_t it = items[s];
    const uint32_t tid = threadIdx.x;
 
    if (!it.stored) {
@@ -178,6 +176,16 @@ zh_stitch(const zh_subblock_t *__restrict__ subs, const zh_stitch_item_t *__rest
          bit = (body + piece) << 3;
       }
    }
+}
+
+// One workgroup per sub-block, striding: the grid may be sized before the host knows the count (a stitch enqueued with its batch, zh_device.hip) —
+// the scan leaves it in scan->nsubs.
+__global__ void __launch_bounds__(ZH_STITCH_THREADS)
+zh_stitch(const zh_subblock_t *__restrict__ subs, const zh_stitch_item_t *__restrict__ items, const zh_block_t *__restrict__ blocks,
+          const uint8_t *__restrict__ data, const uint8_t *__restrict__ payload, uint32_t *out, const zh_scan_out_t *__restrict__ scan, uint64_t stream_cap) {
+   if (scan->failed || ((scan->end_bit + 7) >> 3) + 8 > stream_cap) return;
+   const uint32_t nsubs = scan->nsubs;
+   for (uint32_t s = blockIdx.x; s < nsubs; s += gridDim.x) zh_stitch_one(s, subs, items, blocks, data, payload, out);
 }
 
 // ---- sub-block descriptors of a batch in stream order ---------------------------------------------------------------------------------
