@@ -274,6 +274,32 @@ def _overflow_forms(lib, checker, monkeypatch, sizes):
             assert lib.memory_compress(d, flags, bs) == checker.memory_compress(d, flags, bs), (cap, flags, bs)
 
 
+def _chains_after_none(lib, checker, n, bs, rounds=4):
+    """A context whose last batch listed nothing for zh_parse_chain gives the next batch's runs a chain grid of a few workgroups (round 6: a stream without chains
+    must not wait for 512 workgroups to be scheduled and leave in every pass). When the next batch does have chains — whole tasks and cut ones — those few persistent
+    workgroups take every ticket: the bytes are the checker's, and the batch after it is back on the full grid."""
+    plain = corpus.text_like(n, 31)
+    chains = np.concatenate([corpus.table_like(n // 2, 9), corpus.duplicated(n - n // 2, 4, 900)])
+    nb = (n + bs - 1) // bs
+    blocks = [(b * bs - (32768 if b else 0), 32768 if b else 0, min(bs, n - b * bs)) for b in range(nb)]
+    ctx = lib.context(bs, nb)
+    try:
+        seen = []
+        for d in (plain, chains, chains, plain)[:rounds]:
+            ctx.compress_blocks(d, blocks)
+            seen.append(ctx.stats()["huge_tasks"] + ctx.stats()["cut_tasks"])
+            end_bit, _ = ctx.stitch_device(nb - 1, phase=0)
+            got = ctx.stream_read((end_bit + 7) // 8).tobytes()
+            assert got == checker.memory_compress(d, 0, bs), (len(seen), seen)
+        assert seen[0] == 0 and seen[1] > 0 and (rounds < 4 or (seen[1] == seen[2] and seen[3] == 0)), seen
+    finally:
+        ctx.close()
+
+
+def test_chains_turn_up_after_a_batch_without_any(emu, oracle):
+    _chains_after_none(emu, oracle, 24000, 32768, rounds=2)   # (the emulator takes a minute for the two batches)
+
+
 def test_strided_overflow_forms_of_the_per_item_kernels(emu, oracle, monkeypatch):
     _overflow_forms(emu, oracle, monkeypatch, (12288, 4, ("1",), ()))   # (48 KB: the emulator takes a minute)
 

@@ -227,6 +227,13 @@ def test_strided_overflow_forms_of_the_per_item_kernels(gpu, checker, monkeypatc
     _overflow_forms(gpu, checker, monkeypatch, (32768, 32, ("1", "3"), ((2, 32768), (0, 65536))))
 
 
+def test_chains_turn_up_after_a_batch_without_any(gpu, checker):
+    """The chain grid of a run follows what the context's last batch listed (a few workgroups after a batch without chains): 13 MiB in three runs, without chains, then
+    with, then without — the emulator suite's check on the real kernels."""
+    from test_emu_parity import _chains_after_none
+    _chains_after_none(gpu, checker, 13 << 20, 65536)
+
+
 @pytest.mark.parametrize("runs", ["1", "2", "3"])
 def test_a_run_needs_no_host_decision(gpu, checker, monkeypatch, runs):
     """Sub-block counts, task counts, chains and cut tasks are summed up on the device (zh_plan_subblocks, zh_list_huge) and every later kernel takes

@@ -81,6 +81,13 @@ struct zultra_hip_ctx_s {
    // a stitch enqueued with its batch (zultra_hip_stitch_with_batch): armed for the next batch; what the last batch was stitched with, if it was
    int ab_armed, ab_final, stitched_valid, stitched_final, stitched_rc;
    uint32_t ab_phase, stitched_phase;
+   // what the runs of the LAST batch of max-blocks listed for zh_parse_chain (their counters, read back with the batch's results): a context whose last batch had no chain
+   // at all in run k enqueues run k of the next batch without chain kernels (zh_enqueue_run; zh_parse.h: zh_run_is_void)
+   int chain_seen_runs;                  // runs of that batch (0: no batch yet)
+   uint32_t chain_redone;                // batches run again because a run without chain kernels listed chains
+   uint32_t chain_seen[ZH_MAX_RUNS];     // per run: tasks listed + cut tasks
+   int chain_skip;                       // ZULTRA_HIP_CHAIN_SKIP (default 1): such a run is enqueued without chain kernels (0: always with them)
+   bool run_nochains[ZH_MAX_RUNS];       // this batch: run k was enqueued without
    uint32_t grid_cap;           // ZULTRA_HIP_GRID_CAP (tests): the <false> grids of the per-sub-block / per-task kernels are capped here, so that the <true> forms behind them get work
    uint32_t lane_tasks;         // zh_parse_lanes: tasks per wave when forced (0: chosen per run)
    uint32_t lane_tasks_last;    // ... of the batch's last run, whose passes are the tail of the step (0: like the others)
@@ -628,6 +635,8 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       if (c->coop_small < 64u) c->coop_small = 64u;
       if (c->coop_small > ZH_COOP_MIN) c->coop_small = ZH_COOP_MIN;
       c->seg_whole = (uint32_t)zh_env("ZULTRA_HIP_SEG_WHOLE", 16384);  // cut tasks shorter than this are parsed whole when zh_parse_chain takes the segments
+      c->chain_skip = zh_env("ZULTRA_HIP_CHAIN_SKIP", 1);   // 1: a run whose counterpart in the context's last batch listed no chain is enqueued without chain kernels (0: always with them)
+      c->chain_seen_runs = 0;
       c->grid_cap = (uint32_t)max(0, zh_env("ZULTRA_HIP_GRID_CAP", 0));   // tests: cap of the <false> grids of zh_sb_init / zh_sb_build / zh_list_huge / zh_post_tasks / zh_emit_tasks (0: none) — the
                                                                           // <true> forms that stride over what lies beyond a grid are otherwise reached by heavily splitting data only
       c->seg_wide = (uint32_t)zh_env("ZULTRA_HIP_SEG_WIDE", 1024);     // a run with at least this many segments parses them in the segment workgroups of zh_parse_lanes' launch
@@ -1049,15 +1058,31 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
    const uint32_t lane_grid = max(1u, min((est_tasks + tpw - 1) / tpw, c->num_cus * 16u));
    // (two chain workgroups fit a CU — 169 registers, four waves — and they are persistent: a third per CU would only queue behind them, find the tickets
    // gone and leave; and in a run without chains every workgroup of this grid has to find a slot among the quad kernel's waves before the pass can end)
-   const uint32_t chain_grid = files ? min(nb, c->files_chain_grid) : (uint32_t)zh_min64(zh_min64(ZH_CHAIN_GRID, 2u * c->num_cus), total_n / 256u + nb);
+   uint32_t chain_grid = files ? min(nb, c->files_chain_grid) : (uint32_t)zh_min64(zh_min64(ZH_CHAIN_GRID, 2u * c->num_cus), total_n / 256u + nb);
+   // A stream without chains must not pay for them (round 6; zh_parse.h, zh_run_is_void): a run whose counterpart in the context's last batch listed nothing for
+   // zh_parse_chain gets no chain kernel at all — no fork, no grid to schedule among the quad kernels' waves, no join — and a mark in its counters that says so.
+   const bool chains_idle = !files && c->run_nochains[k];
+   if (chains_idle) ZH_CHECK(c, hipMemsetAsync(cnt + ZH_CNT_NOCHAINS, 1, sizeof(uint32_t), st));   // (non-zero: zh_run_is_void; the run's counters were cleared on this stream before)
    const uint32_t seg_grid = (uint32_t)zh_min64(c->num_cus * 8u, zh_max64(1, seg_bound));
+   if (chains_idle) {
+      // what the side stream was given at the start of the batch (checksums, clearing the payload slots and the stream buffer) is otherwise joined with the chains
+      ZH_CHECK(c, hipEventRecord(c->side_ev[k][1], side));
+      ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][1], 0));
+   }
    for (int pass = 0; pass <= 3; pass++) {
-      ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
-      ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
-      ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, side, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
-                (const uint32_t *)hugelist, cap, segtasks, (const uint2 *)segitems, vecs, c->seg_wide, c->seg_whole, cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
-                cnt + ZH_CNT_CHAIN_TICKET + pass, (c->d_chain_trace && !files) ? c->d_chain_trace + 3 * (uint64_t)ZH_TRACE_SLOTS * (4 * k + pass) : (uint64_t *)NULL);
-      ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
+      // (a lambda: ZH_LAUNCH returns from the function it stands in)
+      auto launch_chain = [&](hipStream_t cs) -> int {
+         ZH_LAUNCH(zh_parse_chain, chain_grid, ZH_CHAIN_THREADS, cs, c->cur_data, blk, match, c->match_stride, bars, c->bar_stride, (const zh_work_t *)work, (const uint2 *)taskmap,
+                   (const uint32_t *)hugelist, cap, segtasks, (const uint2 *)segitems, vecs, c->seg_wide, c->seg_whole, cnt, (const zh_sbstate_t *)states, best, c->best_stride, hist_part, pass,
+                   cnt + ZH_CNT_CHAIN_TICKET + pass, (c->d_chain_trace && !files) ? c->d_chain_trace + 3 * (uint64_t)ZH_TRACE_SLOTS * (4 * k + pass) : (uint64_t *)NULL);
+         return 0;
+      };
+      if (!chains_idle) {
+         ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass], st));
+         ZH_CHECK(c, hipStreamWaitEvent(side, c->side_ev[k][2 * pass], 0));
+         if (launch_chain(side) != 0) return -1;
+         ZH_CHECK(c, hipEventRecord(c->side_ev[k][2 * pass + 1], side));
+      }
       {
          zh_seg_args_t sg;
          sg.segtasks = segtasks;
@@ -1071,7 +1096,7 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
                    (const zh_sbstate_t *)states, best, c->best_stride, cost, hist_part, pass, cnt + ZH_CNT_TASK_TICKET + pass, (const uint2 *)taskinfo, tpw,
                    files ? 0xFFFFFFFFu : c->num_cus * c->lane_waves, sg);
       }
-      ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
+      if (!chains_idle) ZH_CHECK(c, hipStreamWaitEvent(st, c->side_ev[k][2 * pass + 1], 0));
       if (!files) ZH_CHECK(c, hipEventRecord(ev[6 + 2 * pass], st));   // (timing marks)
       ZH_LAUNCH_BOTH(zh_sb_build, sb_grid, sb_bound, st, (const zh_work_t *)work, states, (const uint32_t *)hist_part, payload, pass, cnt);
       if (!files) ZH_CHECK(c, hipEventRecord(ev[7 + 2 * pass], st));   // (timing marks)
@@ -1314,6 +1339,13 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       return (uint32_t)(first + mid * (uint64_t)(k - 1) / (uint64_t)(lanes - 2));
    };
    hipStream_t st0 = c->lane_stream[0];
+   bool any_nochains = false;
+   for (int k = 0; k < ZH_MAX_RUNS; k++) {
+      c->run_nochains[k] = !c->files_mode && c->chain_skip && k < lanes && c->chain_seen_runs == lanes && c->chain_seen[k] == 0;
+      any_nochains = any_nochains || c->run_nochains[k];
+   }
+   // (such a batch may have to be run again, see below: its stitch does not go out with it — the descriptors of a void run are not to be walked)
+   const bool stitch_with = stitch_now && !any_nochains;
 
    ZH_CHECK(c, hipEventRecord(c->lane_ev[0][0], st0));
    // data_on_device == 2: pageable host memory, and the batch runs as staggered runs of max-blocks — every run's bytes are staged
@@ -1410,7 +1442,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, side, c->cur_data, (const zh_block_t *)(c->d_blocks + b0), (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
       // token bits are ORed into the payload slots: cleared there too, long before stage 3 needs them
       ZH_CHECK(c, hipMemsetAsync(c->d_payload + (uint64_t)b0 * c->slot_stride, 0, (size_t)nb * c->slot_stride, side));
-      if (stitch_now && k == 0) {
+      if (stitch_with && k == 0) {
          // ... and so is the stream buffer of a stitch that goes out with the batch (zh_enqueue_stitch): nobody reads it between two batches' stitches
          uint64_t bound = 16;
          for (uint32_t b = 0; b < nblocks; b++) bound += (uint64_t)blocks[b].n + 5ull * (blocks[b].n / 65535u + 1u);
@@ -1428,13 +1460,27 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    // (the host's copy of the descriptors — the getters' — needs the count: a small batch copies what it can hold with the counts, one wait instead of two)
    const bool copy_bound = (uint64_t)nblocks * c->max_subs * sizeof(zh_subblock_t) <= (256u << 10);
    if (copy_bound) ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results_compact, (size_t)nblocks * c->max_subs * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st0));
-   if (stitch_now) {
+   if (stitch_with) {
       // the stitch behind the batch's last kernel (zultra_hip_stitch_with_batch): scan, bit mover and the scan's report before the host's one wait
       ZH_CHECK(c, hipEventRecord(c->ev[0], st0));
       if (zh_enqueue_stitch(c, st0, c->ab_phase, c->ab_final, 0, false, false) != 0) return -1;
    }
    ZH_CHECK(c, hipStreamSynchronize(st0));
    ZH_CHECK(c, hipGetLastError());
+   for (int k = 0; k < lanes; k++) {
+      const uint32_t *cnt = c->h_ntasks + (size_t)k * ZH_CNT_STRIDE;
+      c->chain_seen[k] = cnt[ZH_CNT_VLONG] + cnt[ZH_CNT_LONG] + cnt[ZH_CNT_SHORT] + cnt[ZH_CNT_SEGTASKS];
+   }
+   c->chain_seen_runs = lanes;
+   for (int k = 0; k < lanes; k++) {
+      if (c->run_nochains[k] && c->chain_seen[k] != 0) {
+         // a run enqueued without chain kernels lists chains after all (zh_run_is_void: its kernels left at once): the batch again, every run with its chain
+         // kernels (the counts just taken say so) — one batch's time, once, where the stream's content changes
+         c->chain_redone++;
+         c->ab_armed = stitch_now ? 1 : 0;
+         return zultra_hip_compress_blocks(c, data, data_size, data_on_device, blocks, nblocks);
+      }
+   }
    const uint32_t nsubs = c->h_nsubs[0];
    if (nsubs < nblocks || (uint64_t)nsubs > (uint64_t)nblocks * c->max_subs) {
       snprintf(c->err, sizeof(c->err), "the device reports %u sub-blocks for %u max-blocks", nsubs, nblocks);
@@ -1475,7 +1521,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    }
    c->timing.matchfinder_ms = c->timing.group_ms + c->timing.frontier_ms;
    c->timing.encode_ms = c->timing.init_ms + c->timing.parse_ms + c->timing.build_ms + c->timing.post_ms + c->timing.emit_ms;
-   if (stitch_now) {
+   if (stitch_with) {
       (void)hipEventElapsedTime(&c->timing.stitch_ms, c->ev[0], c->ev[1]);
       c->stitched_rc = zh_stitch_verdict(c, false);
       c->stitched_phase = c->ab_phase;

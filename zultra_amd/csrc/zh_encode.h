@@ -456,6 +456,7 @@ template <bool MORE>
 __global__ void __launch_bounds__(64)
 zh_sb_build(const zh_work_t *__restrict__ work, zh_sbstate_t *states, const uint32_t *__restrict__ hist_part, uint8_t *payload, int pass, uint32_t *cnt, uint32_t first) {
    __shared__ zh_sb_ws_t ws;
+   if (zh_run_is_void(cnt)) return;
    const uint32_t nsubs = cnt[ZH_CNT_NSUBS];
    if (!MORE) {
       if (blockIdx.x < nsubs) (void)zh_sb_build_one(ws, work[blockIdx.x], states + blockIdx.x, hist_part, payload, pass, cnt);
@@ -586,6 +587,7 @@ zh_post_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ b
               const zh_work_t *__restrict__ work, const uint2 *__restrict__ taskmap, const uint32_t *__restrict__ ntasks_total,
               const zh_sbstate_t *__restrict__ states, uint32_t *best_all, uint64_t best_stride, uint32_t *task_bits, const uint2 *__restrict__ taskinfo, uint32_t first) {
    __shared__ zh_task_ws_t ws;
+   if (zh_run_is_void(ntasks_total)) return;   // (ntasks_total = the run's counter block, ZH_CNT_TASKS first)
    const uint32_t ntasks = *ntasks_total;
    if (!MORE) {
       if (blockIdx.x < ntasks) zh_post_task_one(ws, blockIdx.x, data, blocks, bars, bar_stride, work, taskmap, states, best_all, best_stride, task_bits, taskinfo);
@@ -746,6 +748,7 @@ zh_emit_tasks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ b
               const zh_sbstate_t *__restrict__ states, const uint32_t *__restrict__ best_all, uint64_t best_stride,
               const uint32_t *__restrict__ task_bits, uint8_t *payload, zh_subblock_t *results, const uint2 *__restrict__ taskinfo, uint32_t first) {
    __shared__ zh_task_ws_t ws;
+   if (zh_run_is_void(ntasks_total)) return;   // (ntasks_total = the run's counter block, ZH_CNT_TASKS first)
    const uint32_t ntasks = *ntasks_total;
    if (!MORE) {
       if (blockIdx.x < ntasks) zh_emit_task_one(ws, blockIdx.x, data, blocks, bars, bar_stride, work, taskmap, states, best_all, best_stride, task_bits, payload, results, taskinfo);

@@ -99,8 +99,20 @@ enum {
    ZH_CNT_CHAIN_TICKET = 8, ZH_CNT_TASK_TICKET = 12, ZH_CNT_FIX_TICKET = 16, ZH_CNT_SEGWAVES = 20,
    ZH_CNT_SETTLED = 21 /* parse passes not run because the sub-block's prices had stopped moving (zh_sb_build_one) */, ZH_CNT_SETTLED_POS = 22 /* ... in KiB of input */,
    ZH_CNT_DEMOTED = 23 /* cut tasks handed to zh_parse_chain as whole chains for the passes left (zh_parse_one_task) */, ZH_CNT_DEMOTED_PASS = 24 /* .. 27: listed in pass p */,
-   ZH_CNT_NSUBS = 28 /* sub-blocks of the run (zh_plan_subblocks: the host never sees the splitter's counts) */, ZH_CNT_STRIDE = 32
+   ZH_CNT_NSUBS = 28 /* sub-blocks of the run (zh_plan_subblocks: the host never sees the splitter's counts) */,
+   ZH_CNT_NOCHAINS = 29 /* set by the HOST when it enqueues the run: no chain kernels were launched for it (zh_run_is_void) */, ZH_CNT_STRIDE = 32
 };
+static_assert(ZH_CNT_TASKS == 0, "zh_post_tasks / zh_emit_tasks take the run's counter block as the pointer to its task count");
+
+// A stream without chains must not pay for them (round 6). Whether a run lists anything for zh_parse_chain is known on the device only, and an empty chain grid still
+// costs its pass 0.4-2 ms: its four-wave workgroups (169 registers, 24 KB of LDS) have to be scheduled among the quad kernels' waves, which hold every LDS granule of
+// a CU, before they can find the lists empty and leave. So the host goes by what the context's LAST batch listed, run by run: where that was nothing it launches no
+// chain kernel at all and says so in cnt[ZH_CNT_NOCHAINS]. If the run lists chains after all, its parse is incomplete: every kernel behind zh_list_huge then leaves at
+// once (nothing walks a parse that was never written), the host sees both facts in the counters it reads back anyway, and runs the batch again with the chain
+// kernels — the price of one batch, once, where a stream's content changes.
+__device__ __forceinline__ bool zh_run_is_void(const uint32_t *cnt) {
+   return cnt[ZH_CNT_NOCHAINS] != 0 && (cnt[ZH_CNT_VLONG] | cnt[ZH_CNT_LONG] | cnt[ZH_CNT_SHORT] | cnt[ZH_CNT_SEGTASKS]) != 0u;
+}
 
 // sub-block work item produced by zh_plan_subblocks
 struct zh_work_t {

@@ -575,6 +575,7 @@ zh_parse_lanes(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ 
       zh_lp_ws_t ws;
       zh_parse_ws_t seg_ws;
    } sh;
+   if (zh_run_is_void(cnt)) return;   // (no chain kernels were launched, and the run has chains: the host runs the batch again)
    if (blockIdx.x < sg.seg_grid) {
       // ---- a workgroup of segment entries
       if (!zh_segments_are_wide(cnt, sg.seg_wide_min)) return;
