@@ -625,7 +625,38 @@ def prepare_stream_config(args, rank, world):
                 ref_out=ref_out, last_rank=last_rank, check=check)
 
 
+def run_projection(args, env, prep):
+    """Strong-scaling PROJECTION from one GPU — NOT a scaling measurement: the configuration's one stream is cut over N = 1, 2, 4, 8 ranks by
+    sharded.shard_range, and every one of the N shards is put through this GPU's whole step — kernels, phase table, stitch, the collectives of N > 1 over a 1-rank RCCL
+    group, read-back — one after the other. A rank of an N-GPU job would do exactly that with its shard, next to the others; what the projection leaves out is the
+    transfer of the other ranks' bytes to rank 0 (~2.5 MB per rank over xGMI at N = 8) and any interference between the ranks' collectives. Per N: every shard's ms per
+    step, and the stream's size over the SLOWEST shard's step."""
+    from zultra_amd.sharded import shard_range
+    flags, bs, size, corp = (prep[k] for k in ("flags", "bs", "size", "corp"))
+    nb_total = (size + bs - 1) // bs
+    proj = {"note": "projection from ONE GPU, not a scaling measurement: each of the N shards of the one %d-byte stream timed on this GPU in turn (1-rank RCCL group for the collectives); "
+                    "value_if_ranks_ran_side_by_side = stream bytes / slowest shard's step" % size, "by_ranks": {}}
+    for n in (1, 2, 4, 8):
+        ms, heads, tails = [], [], []
+        for r in range(n):
+            lo, hi = shard_range(nb_total, r, n)
+            lead, shard = corp.range(lo * bs, min(size, hi * bs) - lo * bs)
+            leg = run_stream_leg(env, lead, shard, flags, bs, args.steps, args.warmup, last_rank=0 if r == n - 1 else 1)   # (only the stream's last shard carries BFINAL)
+            c = leg.pop("ctx")
+            if c is not None:
+                c.close()
+            leg.pop("d_data")
+            ms.append(round(leg["ms_per_step"], 3))
+            heads.append(leg["per_rank"]["head_ms"][0])
+            tails.append(leg["per_rank"]["tail_ms"][0])
+        proj["by_ranks"][str(n)] = {"shard_bytes": int(min(size, shard_range(nb_total, 0, n)[1] * bs)), "ms_per_step_by_shard": ms, "slowest_shard_ms": max(ms), "head_ms": heads, "tail_ms": tails,
+                                    "value_if_ranks_ran_side_by_side_MBps": round(size / (max(ms) * 1e-3) / 1e6, 1)}
+    return {"strong_scaling_projection": proj}, False
+
+
 def run_stream_config(args, env, prep):
+    if getattr(args, "projection", False):
+        return run_projection(args, env, prep)
     L, rank, world = env["L"], env["rank"], env["world"]
     cfg, flags, bs, size, corp, data_note, metric = (prep[k] for k in ("cfg", "flags", "bs", "size", "corp", "data_note", "metric"))
     lead, shard, sample, cb, ref_out = (prep[k] for k in ("lead", "shard", "sample", "cb", "ref_out"))
@@ -952,10 +983,12 @@ def run_other_configs(args):
         # round 1's headline corpus, for continuity — in a process of its own since round 5: behind other contexts in ONE process the runtime puts two runs of a
         # batch on one hardware queue (28.5 ms per step there, 23.5 in a fresh process)
         legs["synthetic_text"] = ["--synthetic-leg", "--cpu-sample", str(8 << 20), "--cpu-check", str(32 << 20)]
+    legs["strong_scaling_projection"] = ["--scaling", "strong", "--projection", "--no-cpu-baseline"]
     out = {}
     for cfg, extra in legs.items():
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", "2" if cfg == "synthetic_text" else str(cfg), "--gpus", "1", "--steps", "10" if cfg == "synthetic_text" else "2",
-               "--warmup", "3" if cfg == "synthetic_text" else "1", "--leg"] + extra
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", "2" if cfg in ("synthetic_text", "strong_scaling_projection") else str(cfg), "--gpus", "1",
+               "--steps", "10" if cfg == "synthetic_text" else "5" if cfg == "strong_scaling_projection" else "2",
+               "--warmup", "3" if cfg in ("synthetic_text", "strong_scaling_projection") else "1", "--leg"] + extra
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
@@ -966,6 +999,9 @@ def run_other_configs(args):
             d, rc = None, "%s" % type(e).__name__
         if d is None:
             out[str(cfg)] = {"error": "no line (rc %s)" % rc, "wall_s": round(time.perf_counter() - t0, 1)}
+            continue
+        if cfg == "strong_scaling_projection":
+            out[cfg] = dict(d.get("strong_scaling_projection", {"error": "no projection in the leg's line"}), rc=rc, wall_s=round(time.perf_counter() - t0, 1))
             continue
         keep = ("metric", "value", "unit", "ms_per_step", "kernel_stream_interval_sums_ms", "issue", "graph_ms_per_batch", "input_MBps", "ratio", "size_vs_zlib9", "size_vs_zlib9_sample_bytes",
                 "inflate_roundtrip_ok", "gzip_roundtrip_ok_first_files", "bit_exact_vs_reference_full", "bit_exact_checked_input_bytes", "bit_exact_checked_files", "bit_exact_checker",
@@ -1007,6 +1043,8 @@ def main():
     ap.add_argument("--synthetic-leg", action="store_true", help="(internal) configuration 2's settings on round 1's synthetic text: a leg of the default run")
     ap.add_argument("--no-other-configs", action="store_true", help="default run (config 2, one GPU): skip the legs of configurations 3, 4 and 5")
     ap.add_argument("--leg", action="store_true", help="(internal) this process is one of those legs: bounded extras")
+    ap.add_argument("--projection", action="store_true", help="(internal; --config 2 --gpus 1 --scaling strong) strong-scaling PROJECTION from one GPU: every shard of the configuration's "
+                                                               "one stream cut over N = 2, 4, 8 ranks, timed on this GPU one after the other (a leg of the default run)")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3 passes: only the steps (no round-trip / ratio / CPU extras that would add dispatches), then the PMC calibration probe")
     args = ap.parse_args()
@@ -1074,6 +1112,8 @@ def main():
             if "synthetic_text" in other:   # (under the name it has had since round 2)
                 line["synthetic_text"] = dict(other.pop("synthetic_text"), note="a child process of its own since round 5")
                 line["synthetic_text"]["MBps"] = line["synthetic_text"].get("value")
+            if "strong_scaling_projection" in other:
+                line["strong_scaling_projection"] = other.pop("strong_scaling_projection")
             line["other_configs"] = other
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()

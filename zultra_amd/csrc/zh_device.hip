@@ -185,6 +185,8 @@ struct zultra_hip_ctx_s {
    uint32_t *d_nsubs, *h_nsubs, *d_blk_start;
    zh_scan_out_t *d_scan_out, *h_scan_out;
    uint64_t *d_file_off;      // files mode: first byte of every input's stream
+   uint64_t *h_file_off;      // ... read back with the batch (the stitch of a files batch goes out with it, zh_enqueue_files_tail)
+   int files_stitched, files_stitch_rc;   // the last files batch was stitched with its kernels; zh_stitch_verdict of that
    uint32_t *d_task_prefix, *h_task_prefix;   // files mode: exclusive prefix of the inputs' task counts, computed by the host from the sizes it was handed (zh_plan_files); B + 1 entries
    uint32_t *d_stream;        // stitched deflate bits of the last batch
    size_t stream_cap;         // bytes
@@ -516,6 +518,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_file_off);
    (void)hipFree(c->d_task_prefix);
    if (c->h_task_prefix) (void)hipHostFree(c->h_task_prefix);
+   if (c->h_file_off) (void)hipHostFree(c->h_file_off);
    if (c->h_nsubs) (void)hipHostFree(c->h_nsubs);
    if (c->h_scan_out) (void)hipHostFree(c->h_scan_out);
    (void)hipFree(c->d_ntasks);
@@ -700,6 +703,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_crc, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_blocks, B * sizeof(zh_block_t), 0));
       if (c->files_mode) ZH_CHECK(c, hipHostMalloc((void **)&c->h_task_prefix, (B + 1) * sizeof(uint32_t), 0));
+      if (c->files_mode) ZH_CHECK(c, hipHostMalloc((void **)&c->h_file_off, (B + 1) * sizeof(uint64_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_segs, B * c->segs_per_block * sizeof(zh_seg_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_ntasks, 2 * ZH_NCNT * sizeof(uint32_t), 0));   // a mirror of d_ntasks + per-run readbacks
       memset(c->h_ntasks, 0, 2 * ZH_NCNT * sizeof(uint32_t));
@@ -1108,7 +1112,15 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
              (const uint32_t *)best, c->best_stride, (const uint32_t *)task_bits, payload, c->d_results + s0, (const uint2 *)taskinfo);
    if (!files) ZH_CHECK(c, hipEventRecord(ev[15], st));   // (timing marks)
    // per-max-block CRC-32 (linear part) and Adler-32 for the framing's footer (a batch of max-blocks computes them next to its matchfinder: zultra_hip_compress_blocks)
-   if (files) ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
+   if (files) {
+      // (several inputs to a workgroup: zh_crc32_small)
+      uint32_t spg = 1;
+      while (spg < (c->max_block + ZH_CRC_SLICE - 1) / ZH_CRC_SLICE) spg <<= 1;
+      if (spg <= ZH_CRC_THREADS / 2)
+         ZH_LAUNCH(zh_crc32_small, (nb + ZH_CRC_THREADS / spg - 1) / (ZH_CRC_THREADS / spg), ZH_CRC_THREADS, st, c->cur_data, blk, nb, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0, spg);
+      else
+         ZH_LAUNCH(zh_crc32_blocks, nb, ZH_CRC_THREADS, st, c->cur_data, blk, (const uint32_t *)c->d_crc_tables, c->d_crc + b0, c->d_adler + 2 * (size_t)b0);
+   }
    return 0;
 }
 
@@ -1143,6 +1155,13 @@ static int zh_enqueue_files_tail(zultra_hip_ctx_t *c, uint32_t nblocks, hipStrea
    ZH_CHECK(c, hipMemcpyAsync(c->h_adler, c->d_adler, 2 * (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));
    ZH_CHECK(c, hipMemcpyAsync(c->h_results, c->d_results_compact, (size_t)nblocks * sizeof(zh_subblock_t), hipMemcpyDeviceToHost, st0));   // (one sub-block per input)
    ZH_CHECK(c, hipMemcpyAsync(c->h_crc, c->d_crc, (size_t)nblocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st0));
+   // The assembly of the inputs' streams (zh_stitch_scan in files form, zh_stitch) goes out with the batch (round 6; part of the captured graph where there is one): every
+   // input starts on a byte boundary, nothing depends on what the caller does between the batch and zultra_hip_stitch_files — which then only hands out the offsets read
+   // back here. (Before: a second call, a second synchronisation, 0.4 ms between the two on 65 536-input batches.) The clearing covers the worst case of the batch's
+   // input COUNT — a replayed graph sees other sizes.
+   ZH_CHECK(c, hipMemsetAsync(c->d_stream, 0, (size_t)zh_min64((uint64_t)c->stream_cap + 16, ((uint64_t)nblocks * ((uint64_t)c->max_block + 16) + 16 + 3) & ~3ull), st0));
+   if (zh_enqueue_stitch(c, st0, 0, -1, 1, false, false) != 0) return -1;
+   ZH_CHECK(c, hipMemcpyAsync(c->h_file_off, c->d_file_off, ((size_t)nblocks + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st0));
    return 0;
 }
 
@@ -1273,6 +1292,8 @@ static int zh_run_files(zultra_hip_ctx_t *c, uint32_t nblocks) {
    memcpy(c->crc.data(), c->h_crc, nblocks * sizeof(uint32_t));
    c->adler.assign(c->h_adler, c->h_adler + 2 * (size_t)nblocks);
    c->nsubs = nblocks;
+   c->files_stitch_rc = zh_stitch_verdict(c, false);
+   c->files_stitched = 1;   // (no stitch_ms of its own: inside a captured graph an event is a node, not a time stamp; the batch's encode_ms covers the assembly)
    (void)hipEventElapsedTime(&c->timing.h2d_ms, c->lane_ev[0][0], c->ev_input);
    (void)hipEventElapsedTime(&c->timing.encode_ms, c->lane_ev[0][1], c->lane_ev[0][16]);   // the whole graph
    (void)hipEventElapsedTime(&c->timing.total_ms, c->lane_ev[0][0], c->lane_ev[0][16]);
@@ -1301,6 +1322,7 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    const bool stitch_now = c->ab_armed && !c->files_mode;   // (one batch only)
    c->ab_armed = 0;
    c->stitched_valid = 0;
+   c->files_stitched = 0;
    c->nblocks = nblocks;
    c->nsubs = 0;
    c->blocks.assign((const zh_block_t *)blocks, (const zh_block_t *)blocks + nblocks);
@@ -1614,6 +1636,7 @@ static int zh_stitch_on_device(zultra_hip_ctx_t *c, uint32_t phase, int final_bl
    ZH_CHECK(c, hipSetDevice(c->device));
    hipStream_t st = c->stream;
    c->stitched_valid = 0;   // (the items and the scan's report are rewritten)
+   c->files_stitched = 0;
    ZH_CHECK(c, hipEventRecord(c->ev[0], st));
    if (zh_enqueue_stitch(c, st, phase, final_block, files, scan_only, true) != 0) return -1;
    ZH_CHECK(c, hipStreamSynchronize(st));
@@ -1673,6 +1696,11 @@ extern "C" int zultra_hip_stitch_files(zultra_hip_ctx_t *c, uint64_t *file_off /
    if (!c->d_file_off) {   // (a context of max-blocks: allocated on first use)
       ZH_CHECK(c, hipSetDevice(c->device));
       if (zh_alloc(c, &c->d_file_off, (size_t)c->max_blocks + 1)) return -1;
+   }
+   if (c->files_mode && c->files_stitched) {   // (the batch brought its assembly with it, zh_enqueue_files_tail)
+      if (c->files_stitch_rc != 0) return c->files_stitch_rc;
+      memcpy(file_off, c->h_file_off, ((size_t)c->nblocks + 1) * sizeof(uint64_t));
+      return 0;
    }
    const int rc = zh_stitch_on_device(c, 0, -1, 1);
    if (rc != 0) return rc;

@@ -438,4 +438,55 @@ zh_crc32_blocks(const uint8_t *__restrict__ data, const zh_block_t *__restrict__
    // (initial 0xFFFFFFFF, final XOR) are applied by the host combine.
    if (tid == 0) crc_out[blockIdx.x] = total;
 }
+
+// The same for SMALL inputs (files mode: a few KiB each), several to a workgroup: the 5 KB of tables are staged once for 256 / spg inputs instead of once per input
+// (a 4 KiB input gave sixteen of the 256 threads a slice, and the table load was most of the kernel: 0.8 ms per 32 768 inputs at the tail of every files batch), and
+// every thread has a slice. spg = slices per input, a power of two >= ceil(largest input / ZH_CRC_SLICE), at most ZH_CRC_THREADS; thread t works on input
+// blockIdx.x * (ZH_CRC_THREADS / spg) + t / spg, slice t % spg.
+__global__ void __launch_bounds__(ZH_CRC_THREADS)
+zh_crc32_small(const uint8_t *__restrict__ data, const zh_block_t *__restrict__ blocks, uint32_t nblocks, const uint32_t *__restrict__ tables,
+               uint32_t *crc_out, uint32_t *adler_out /* 2 per block */, uint32_t spg) {
+   __shared__ uint32_t T[256 + 1024];
+   __shared__ uint32_t part[ZH_CRC_THREADS];
+   __shared__ uint32_t asum[ZH_CRC_THREADS][2];   // (per input of the workgroup: the first ZH_CRC_THREADS / spg rows)
+   const uint32_t tid = threadIdx.x, per = ZH_CRC_THREADS / spg, g = tid / spg, sl = tid % spg;
+   const uint32_t b = blockIdx.x * per + g;
+   for (uint32_t k = tid; k < 256 + 1024; k += ZH_CRC_THREADS) T[k] = tables[k];
+   if (tid < per) asum[tid][0] = asum[tid][1] = 0;
+   __syncthreads();
+   uint32_t n = 0, nslices = 0, c = 0;
+   if (b < nblocks) {
+      const zh_block_t blk = blocks[b];
+      const uint8_t *p = data + blk.win_off + blk.prev;
+      n = blk.n;
+      nslices = (n + ZH_CRC_SLICE - 1) / ZH_CRC_SLICE;   // <= spg
+      if (sl < nslices) {
+         const uint32_t first = n - (nslices - 1) * ZH_CRC_SLICE;
+         const uint32_t beg = sl == 0 ? 0 : first + (sl - 1) * ZH_CRC_SLICE;
+         const uint32_t len = sl == 0 ? first : ZH_CRC_SLICE;
+         uint32_t s1 = 0, s2 = 0;
+         for (uint32_t k = 0; k < len; k++) {
+            const uint32_t d = p[beg + k];
+            c = (c >> 8) ^ T[(c ^ d) & 0xff];
+            s1 += d;
+            s2 += (len - k) * d;
+         }
+         const uint64_t after = (uint64_t)(n - beg - len) % ZH_ADLER_MOD;
+         atomicAdd(&asum[g][0], s1 % ZH_ADLER_MOD);   // (at most 256 addends below 65521: no overflow)
+         atomicAdd(&asum[g][1], (uint32_t)((after * (s1 % ZH_ADLER_MOD) + s2) % ZH_ADLER_MOD));
+      }
+   }
+   part[tid] = c;
+   __syncthreads();
+   if (b < nblocks && sl == 0) {
+      uint32_t total = 0;
+      for (uint32_t k = 0; k < nslices; k++) {
+         if (k > 0) total = T[256 + (total & 0xff)] ^ T[512 + ((total >> 8) & 0xff)] ^ T[768 + ((total >> 16) & 0xff)] ^ T[1024 + (total >> 24)];
+         total ^= part[g * spg + k];
+      }
+      crc_out[b] = total;
+      adler_out[2 * b] = asum[g][0] % ZH_ADLER_MOD;
+      adler_out[2 * b + 1] = asum[g][1] % ZH_ADLER_MOD;
+   }
+}
 #endif
