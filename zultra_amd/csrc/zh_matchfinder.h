@@ -810,6 +810,55 @@ __device__ __forceinline__ uint32_t zh_mf_extend_lane(const uint32_t *lwin32, ui
    return min(l, maxlen);
 }
 
+// ... and FOUR lanes at a time (round 6): the wave as four groups of sixteen lanes, group g serving the g-th lane in need — lane k of a group compares the SIXTEEN bytes at
+// offset BASE + 16 k of its group's two strings (five aligned words each, as everywhere in the walk), so one round covers BASE .. BASE + 255: every length up to 258
+// for BASE >= 18. A wave instruction of the whole-wave form above compares 4 bytes per lane for ONE match; here it compares 16 bytes per lane for four: ~75
+// instructions per round of four against ~30 per match, and the per-lane loop over bytes 32..79 that ran in front of the whole-wave form — three rounds of ~35
+// instructions for the two or three lanes of a step that get past 32 bytes, the other sixty idle — is gone. (tools/mf_profile.py, Python sources: 2.15 whole-wave rounds
+// per walk step, a third of the walk's cycles.) All lanes call; returns l, or the lane's match length (clamped to maxlen) where it had `need`.
+template <uint32_t BASE>
+__device__ __forceinline__ uint32_t zh_mf_extend_groups(const uint32_t *lwin32, bool need, uint32_t q, uint32_t i, uint32_t maxlen, uint32_t l) {
+   static_assert(BASE + 240u >= ZH_MAX_MATCH, "a group's last lane lies beyond every match: there is always a lane that stops");
+   uint64_t todo = zh_ballot(need);
+   const uint32_t lane = zh_lane(), grp = lane >> 4, sub = lane & 15u;
+   const uint32_t off = BASE + 16u * sub;
+   while (todo) {
+      // the next four lanes in need (fewer left: the last one again — the same answer twice)
+      const int s0 = zh_ctz64(todo);
+      todo &= todo - 1;
+      const int s1 = todo ? zh_ctz64(todo) : s0;
+      todo &= todo - 1;
+      const int s2 = todo ? zh_ctz64(todo) : s1;
+      todo &= todo - 1;
+      const int s3 = todo ? zh_ctz64(todo) : s2;
+      todo &= todo - 1;
+      const int src = grp == 0 ? s0 : (grp == 1 ? s1 : (grp == 2 ? s2 : s3));
+      const uint32_t qq = zh_shfl(q, src), ii = zh_shfl(i, src), ml = zh_shfl(maxlen, src);
+      const bool beyond = off >= ml;   // (also keeps every read within sixteen bytes of the window's end: inside this kernel's LDS)
+      uint32_t m = 0;                  // how many of the lane's sixteen bytes agree
+      if (!beyond) {
+         uint32_t a[4], b[4];
+         zh_load128_at(lwin32, qq + off, a);
+         zh_load128_at(lwin32, ii + off, b);
+         m = zh_mf_len16(a, b);
+      }
+      const uint64_t stop = zh_ballot(beyond || m < 16u);
+      const uint32_t g16 = (uint32_t)(stop >> (16u * grp)) & 0xffffu;   // the group's lanes that stop: never empty (its last lane is beyond)
+      const uint32_t fl = (uint32_t)__builtin_ctz(g16 | 0x8000u);
+      const uint32_t mf = zh_shfl(m, (int)((grp << 4) + fl));            // (0 where that lane is beyond: the length is clamped to ml below)
+      const uint32_t len = min(BASE + 16u * fl + mf, ml);
+      // a lane in need takes the answer of the group that served it
+      const uint32_t mine = (int)lane == s0 ? 0u : ((int)lane == s1 ? 1u : ((int)lane == s2 ? 2u : 3u));
+      const uint32_t got = zh_shfl(len, (int)(mine << 4));
+      if ((int)lane == s0 || (int)lane == s1 || (int)lane == s2 || (int)lane == s3) l = got;
+   }
+   return l;
+}
+
+#ifndef ZH_MF_EXT_GROUPS
+#define ZH_MF_EXT_GROUPS 1   // 0 (A/B builds): rounds 4-5's form — the lanes extend their own matches up to ZH_MF_EXT_TO, the whole wave beyond, one lane at a time
+#endif
+
 // The length of a match that agrees on its first 16 bytes (lanes with `need`; all lanes call): bytes 16..31 are compared by the lane itself
 // against its own bytes 16..31 in registers — every lane that needs it at once, and half of the long matches of source code end there —
 // and only what still agrees at 32 goes to the whole wave, one lane at a time.
@@ -820,6 +869,9 @@ __device__ __forceinline__ uint32_t zh_mf_length_past16(const uint32_t *lwin32, 
    const uint32_t m = zh_mf_len16(g, own32);
    if (need) l = 16u + m;
    bool more = need && m == 16u && maxlen > 32u;
+#if ZH_MF_EXT_GROUPS
+   return zh_mf_extend_groups<32u>(lwin32, more, q, i, maxlen, l);
+#endif
    // Bytes 32..79 by the lanes themselves, sixteen at a time and all that need it at once (round 4): on source code two lanes of a step
    // go past 32 on average and most of them end before 80 — handing each of them to the whole wave in turn (zh_mf_extend_wave: ~350 cycles
    // per lane) was a fifth of this kernel there. What still agrees at 80 goes to the whole wave.
