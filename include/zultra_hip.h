@@ -126,6 +126,8 @@ typedef struct zultra_hip_stats_s {
                                           blockdeflate.c:874-901, every further pass would have reproduced the parse it has */
    uint32_t settled_kib;               /* ... the input they cover, in KiB (of 4 x positions / 1024 for the four passes of everything) */
    uint32_t cut_demoted;               /* cut tasks that had several failed cuts in one pass and were parsed as one chain in the passes left */
+   uint32_t runs_without_chain_kernels;   /* runs of the last batch enqueued without zh_parse_chain: their counterparts in the context's batch before it listed no chains (round 6) */
+   uint32_t batches_rerun;                /* batches of this context run a second time because such a run listed chains after all (since the context was created) */
 } zultra_hip_stats_t;
 void zultra_hip_last_stats(const zultra_hip_ctx_t *ctx, zultra_hip_stats_t *out);
 

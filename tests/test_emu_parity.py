@@ -274,30 +274,42 @@ def _overflow_forms(lib, checker, monkeypatch, sizes):
             assert lib.memory_compress(d, flags, bs) == checker.memory_compress(d, flags, bs), (cap, flags, bs)
 
 
-def _chains_after_none(lib, checker, n, bs, rounds=4):
-    """A context whose last batch listed nothing for zh_parse_chain gives the next batch's runs a chain grid of a few workgroups (round 6: a stream without chains
-    must not wait for 512 workgroups to be scheduled and leave in every pass). When the next batch does have chains — whole tasks and cut ones — those few persistent
-    workgroups take every ticket: the bytes are the checker's, and the batch after it is back on the full grid."""
+def _chains_after_none(lib, checker, n, bs, order="pc"):
+    """A run whose counterpart in the context's last batch listed nothing for zh_parse_chain is enqueued without chain kernels (round 6: a stream without chains must not
+    wait, in every pass, for a grid of four-wave workgroups to be scheduled and leave). When such a run lists chains after all its kernels leave at once and the host runs
+    the batch again, with them (zh_run_is_void). `order`: the batches of one context, p = text without chains, c = tables and near-copies with whole and cut chain tasks.
+    Every batch's bytes are the checker's; the stats say which batches ran without chain kernels and which were run again."""
     plain = corpus.text_like(n, 31)
     chains = np.concatenate([corpus.table_like(n // 2, 9), corpus.duplicated(n - n // 2, 4, 900)])
     nb = (n + bs - 1) // bs
     blocks = [(b * bs - (32768 if b else 0), 32768 if b else 0, min(bs, n - b * bs)) for b in range(nb)]
     ctx = lib.context(bs, nb)
     try:
-        seen = []
-        for d in (plain, chains, chains, plain)[:rounds]:
+        prev_kind, reruns = None, 0
+        for k, kind in enumerate(order):
+            d = plain if kind == "p" else chains
             ctx.compress_blocks(d, blocks)
-            seen.append(ctx.stats()["huge_tasks"] + ctx.stats()["cut_tasks"])
+            st = ctx.stats()
             end_bit, _ = ctx.stitch_device(nb - 1, phase=0)
             got = ctx.stream_read((end_bit + 7) // 8).tobytes()
-            assert got == checker.memory_compress(d, 0, bs), (len(seen), seen)
-        assert seen[0] == 0 and seen[1] > 0 and (rounds < 4 or (seen[1] == seen[2] and seen[3] == 0)), seen
+            assert got == checker.memory_compress(d, 0, bs), (k, order)
+            listed = st["huge_tasks"] + st["cut_tasks"]
+            assert (listed == 0) == (kind == "p"), (k, order, st)
+            # behind a batch without chains: no chain kernels — unless this batch has chains, then it was run again with them; behind one with chains (and for the
+            # first batch of a context): always with them
+            if prev_kind == "p" and kind == "c":
+                reruns += 1
+            assert st["batches_rerun"] == reruns, (k, order, st)
+            # (run by run: a batch with chains may hold a run without any — that run goes without its chain kernels next time, and in a rerun)
+            assert (st["runs_without_chain_kernels"] == st["runs"]) == (prev_kind == "p" and kind == "p"), (k, order, st)
+            assert k > 0 or st["runs_without_chain_kernels"] == 0, (k, order, st)
+            prev_kind = kind
     finally:
         ctx.close()
 
 
 def test_chains_turn_up_after_a_batch_without_any(emu, oracle):
-    _chains_after_none(emu, oracle, 24000, 32768, rounds=2)   # (the emulator takes a minute for the two batches)
+    _chains_after_none(emu, oracle, 24000, 32768, "pc")   # (the emulator takes a minute for the two batches)
 
 
 def test_strided_overflow_forms_of_the_per_item_kernels(emu, oracle, monkeypatch):

@@ -229,9 +229,9 @@ def test_strided_overflow_forms_of_the_per_item_kernels(gpu, checker, monkeypatc
 
 def test_chains_turn_up_after_a_batch_without_any(gpu, checker):
     """The chain grid of a run follows what the context's last batch listed (a few workgroups after a batch without chains): 13 MiB in three runs, without chains, then
-    with, then without — the emulator suite's check on the real kernels."""
+    with, then without, in several orders — the emulator suite's check on the real kernels, with what the stats say about chain kernels and reruns."""
     from test_emu_parity import _chains_after_none
-    _chains_after_none(gpu, checker, 13 << 20, 65536)
+    _chains_after_none(gpu, checker, 13 << 20, 65536, "ppccpcpp")
 
 
 @pytest.mark.parametrize("runs", ["1", "2", "3"])

@@ -57,7 +57,8 @@ class Timing(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("positions", C.c_uint64), ("huge_positions", C.c_uint64), ("blocks", C.c_uint32), ("subblocks", C.c_uint32),
                 ("tasks", C.c_uint32), ("huge_tasks", C.c_uint32), ("cut_tasks", C.c_uint32), ("cut_segments", C.c_uint32),
-                ("cut_redone", C.c_uint32), ("runs", C.c_uint32), ("settled_passes", C.c_uint32), ("settled_kib", C.c_uint32), ("cut_demoted", C.c_uint32)]
+                ("cut_redone", C.c_uint32), ("runs", C.c_uint32), ("settled_passes", C.c_uint32), ("settled_kib", C.c_uint32), ("cut_demoted", C.c_uint32),
+                ("runs_without_chain_kernels", C.c_uint32), ("batches_rerun", C.c_uint32)]
 
 
 class BitState(C.Structure):

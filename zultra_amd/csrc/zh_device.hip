@@ -1798,6 +1798,7 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
    memset(out, 0, sizeof(*out));
    out->blocks = c->nblocks;
    out->subblocks = c->nsubs;
+   out->batches_rerun = c->chain_redone;
    for (int k = 0; k < c->last_runs && k < ZH_MAX_RUNS; k++) {   // (a run's counters are cleared when it is launched: only the last batch's runs count)
       const uint32_t *cnt = c->h_ntasks + (size_t)k * ZH_CNT_STRIDE;
       out->tasks += cnt[ZH_CNT_TASKS];
@@ -1807,6 +1808,7 @@ extern "C" void zultra_hip_last_stats(const zultra_hip_ctx_t *c, zultra_hip_stat
       out->cut_segments += cnt[ZH_CNT_SEGITEMS];
       out->cut_redone += cnt[ZH_CNT_SEG_FAILED];   // over the four passes
       out->cut_demoted += cnt[ZH_CNT_DEMOTED];
+      out->runs_without_chain_kernels += cnt[ZH_CNT_NOCHAINS] ? 1u : 0u;
       out->settled_passes += cnt[ZH_CNT_SETTLED];
       out->settled_kib += cnt[ZH_CNT_SETTLED_POS];
    }

@@ -871,7 +871,7 @@ __device__ __forceinline__ uint32_t zh_mf_length_past16(const uint32_t *lwin32, 
    bool more = need && m == 16u && maxlen > 32u;
 #if ZH_MF_EXT_GROUPS
    return zh_mf_extend_groups<32u>(lwin32, more, q, i, maxlen, l);
-#endif
+#else
    // Bytes 32..79 by the lanes themselves, sixteen at a time and all that need it at once (round 4): on source code two lanes of a step
    // go past 32 on average and most of them end before 80 — handing each of them to the whole wave in turn (zh_mf_extend_wave: ~350 cycles
    // per lane) was a fifth of this kernel there. What still agrees at 80 goes to the whole wave.
@@ -888,6 +888,7 @@ __device__ __forceinline__ uint32_t zh_mf_length_past16(const uint32_t *lwin32, 
       }
    }
    return zh_mf_extend_wave<ZH_MF_EXT_TO>(lwin32, more, q, i, maxlen, l);
+#endif
 }
 
 template <bool LDS_WIN>
