@@ -381,6 +381,8 @@ def test_files_mode_each_input_is_its_own_stream(emu, oracle):
             assert zlib.decompress(got, -15) == f.tobytes()
         for k, lin in enumerate(ctx.block_crc32()):
             assert emu.crc32_append(0, lin, len(files[k])) == zlib.crc32(files[k].tobytes())
+        for k, (a, bw) in enumerate(ctx.block_adler32()):   # (the same kernel takes the Adler-32 sums: zh_crc32_small, several inputs to a workgroup)
+            assert emu.adler32_append(1, a, bw, len(files[k])) == zlib.adler32(files[k].tobytes()), k
     finally:
         ctx.close()
 

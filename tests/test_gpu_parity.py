@@ -356,6 +356,8 @@ def test_files_mode_graph_replay_vs_oracle(gpu, checker, monkeypatch, runs):
                 if k % 5 == 0:
                     assert got == checker.memory_compress(files[k], 0, 32768), (batch, k)
                 assert gpu.crc32_append(0, crcs[k], sizes[k]) == zlib.crc32(files[k].tobytes())
+            for k, (a, bw) in enumerate(ctx.block_adler32()):
+                assert gpu.adler32_append(1, a, bw, sizes[k]) == zlib.adler32(files[k].tobytes()), (batch, k)
     finally:
         ctx.close()
 

@@ -194,6 +194,11 @@ class Lib:
         self.L.zultra_crc32_append.restype = C.c_uint32
         return self.L.zultra_crc32_append(crc, int(block_linear_crc), block_len)
 
+    def adler32_append(self, adler, a, bw, block_len):
+        self.L.zultra_adler32_append.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_size_t]
+        self.L.zultra_adler32_append.restype = C.c_uint32
+        return self.L.zultra_adler32_append(adler, int(a), int(bw), block_len)
+
     def crc32_append_many(self, crc, block_linear_crcs, block_lens):
         a = np.ascontiguousarray(block_linear_crcs, dtype=np.uint32)
         n = np.ascontiguousarray(block_lens, dtype=np.uint32)
@@ -426,6 +431,14 @@ class HipContext:
         self.lib.L.zultra_hip_stream_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         if self.lib.L.zultra_hip_stream_read(self.h, out.ctypes.data, offset, nbytes) != 0:
             raise ZultraError("stream_read")
+        return out
+
+    def block_adler32(self):
+        """-> uint32 array [n, 2]: per max-block / input the two Adler-32 sums (A, Bw) the device took next to the compression (zultra_adler32_append folds them)."""
+        n = len(self._block_n)
+        out = np.zeros((n, 2), dtype=np.uint32)
+        self.lib.L.zultra_hip_block_adler32.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.L.zultra_hip_block_adler32(self.h, out.ctypes.data)
         return out
 
     def block_crc32(self):
