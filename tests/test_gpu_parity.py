@@ -699,6 +699,38 @@ def test_memory_compress_over_device_lanes(gpu, checker, monkeypatch, how):
     assert zlib.decompress(got, 15) == d.tobytes()
 
 
+def test_streams_get_hardware_queues_of_their_own(tmp_path):
+    """A process that initialised HIP with few hardware queues (GPU_MAX_HW_QUEUES=2 here; the runtime's default of four when an application touches HIP before the
+    library is loaded) puts several of a context's streams on one queue, where they run one after the other. The context finds out at creation — its streams spin
+    side by side for 0.2 ms and it looks at who ran when (zh_spread_streams) — and replaces the ones that shared; the bytes are the checker's either way."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    worker = r'''
+import os, sys
+import numpy as np
+import torch
+torch.zeros(1).cuda()                      # HIP is up before the library is loaded: its GPU_MAX_HW_QUEUES hint comes too late
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+import corpus, zlibs, zultra_amd
+d = np.concatenate([corpus.text_like_fast(9 << 20, 3), corpus.indented(4 << 20, 5)])
+got = zultra_amd.lib().memory_compress(d, 2, 65536)
+want = (zlibs.RefStages() if zlibs.have_ref() else zlibs.Oracle()).memory_compress(d, 2, 65536)
+assert got == want
+print("bytes equal")
+''' % {"root": root, "here": here}
+    script = tmp_path / "queues.py"
+    script.write_text(worker)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="2", ZULTRA_HIP_SPREAD_STREAMS="2")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bytes equal" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    import re
+    m = re.findall(r"zultra_amd: (\d+) of (\d+) streams replaced", r.stderr)
+    assert m and any(int(a) > 0 for a, _ in m), r.stderr[-1500:]   # with two queues for eight streams some must have shared
+
+
 def test_sharded_assembly_at_world_two_with_the_real_kernels(tmp_path):
     """zultra_amd.sharded.assemble — the N > 1 path of bench.py — with the REAL kernels: two rank processes, both on GPU 0, the
     collectives over gloo (RCCL refuses two ranks on one device). A stored sub-block sits right behind the cut; rank 0's stream

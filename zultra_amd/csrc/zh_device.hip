@@ -88,6 +88,7 @@ struct zultra_hip_ctx_s {
    uint32_t chain_seen[ZH_MAX_RUNS];     // per run: tasks listed + cut tasks
    int chain_skip;                       // ZULTRA_HIP_CHAIN_SKIP (default 1): such a run is enqueued without chain kernels (0: always with them)
    bool run_nochains[ZH_MAX_RUNS];       // this batch: run k was enqueued without
+   uint32_t streams_respread;   // streams replaced at creation because they shared a hardware queue with a more important one (zh_spread_streams)
    uint32_t grid_cap;           // ZULTRA_HIP_GRID_CAP (tests): the <false> grids of the per-sub-block / per-task kernels are capped here, so that the <true> forms behind them get work
    uint32_t lane_tasks;         // zh_parse_lanes: tasks per wave when forced (0: chosen per run)
    uint32_t lane_tasks_last;    // ... of the batch's last run, whose passes are the tail of the step (0: like the others)
@@ -584,6 +585,68 @@ static int zh_knob(const char *name, int dflt) {
 #endif
 }
 
+#ifndef ZH_EMU
+// ---- every run's stream on a hardware queue of its own -----------------------------------------------------------------------------------------------------
+// The HIP runtime hands a stream one of a few hardware queues when it is created and keeps it there; two streams on one queue run strictly one after the
+// other. With eight queues and a fresh process the library's streams land on queues of their own (zh_runtime_hints); behind other contexts, or in a process that
+// initialised HIP with the runtime's default of four before the library was loaded, two runs of a batch can share a queue — the 100 MB step then takes 49 ms
+// instead of 39 (profiles/r05_timeline_second_context_static_queues.txt; round 6: tools/ab_step.py under torch without the variable). The runtime does not say
+// which queue a stream has, but it shows: a context lets all its run and chain streams spin for 0.2 ms at once and looks at who ran WHEN. A stream that did not
+// overlap one ahead of it in the order of importance (the runs' streams, then their chain streams) is replaced by a fresh one — created before the old one is
+// destroyed, so the runtime's least-used-queue rule puts it elsewhere — and the test repeated, a few times at most. ~0.3 ms of context creation when all is well.
+__global__ void zh_queue_probe(uint64_t *out, uint64_t ticks) {
+   const uint64_t t0 = zh_wall_clock();
+   uint64_t t = t0;
+   for (uint32_t guard = 0; t - t0 < ticks && guard < (1u << 20); guard++) {
+      __builtin_amdgcn_s_sleep(64);
+      t = zh_wall_clock();
+   }
+   out[0] = t0;
+   out[1] = t;
+}
+
+static int zh_spread_streams(zultra_hip_ctx_t *c) {
+   if (!zh_env("ZULTRA_HIP_SPREAD_STREAMS", 1)) return 0;
+   const int n = c->nlanes;
+   hipStream_t *order[2 * ZH_MAX_RUNS];
+   bool high[2 * ZH_MAX_RUNS];
+   int m = 0;
+   // (the first three runs, their chain streams, then the rest: what a batch of less than 256 MiB uses comes first)
+   for (int k = 0; k < n && k < 3; k++) { order[m] = &c->lane_stream[k]; high[m++] = false; }
+   for (int k = 0; k < n && k < 3; k++) { order[m] = &c->side_stream[k]; high[m++] = true; }
+   for (int k = 3; k < n; k++) { order[m] = &c->lane_stream[k]; high[m++] = false; }
+   for (int k = 3; k < n; k++) { order[m] = &c->side_stream[k]; high[m++] = true; }
+   uint64_t *d_t = NULL, *h_t = NULL;
+   ZH_CHECK(c, hipMalloc((void **)&d_t, (size_t)m * 2 * sizeof(uint64_t)));
+   ZH_CHECK(c, hipHostMalloc((void **)&h_t, (size_t)m * 2 * sizeof(uint64_t), 0));
+   int lo_prio = 0, hi_prio = 0;
+   (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+   int rc = 0;
+   c->streams_respread = 0;
+   for (int attempt = 0; attempt < 12; attempt++) {
+      for (int i = 0; i < m; i++) hipLaunchKernelGGL(zh_queue_probe, dim3(1), dim3(1), 0, *order[i], d_t + 2 * i, (uint64_t)20000);   // 0.2 ms of the 100 MHz clock
+      for (int i = 0; i < m; i++) if (hipStreamSynchronize(*order[i]) != hipSuccess) rc = -1;
+      if (rc != 0 || hipMemcpy(h_t, d_t, (size_t)m * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = -1; break; }
+      int bad = -1;
+      for (int i = 1; i < m && bad < 0; i++)
+         for (int j = 0; j < i; j++)
+            if (!(h_t[2 * i] < h_t[2 * j + 1] && h_t[2 * j] < h_t[2 * i + 1])) { bad = i; break; }   // i ran before or after j, not next to it
+      if (bad < 0) break;
+      hipStream_t fresh = NULL;
+      const hipError_t e = high[bad] ? hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, hi_prio) : hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking);
+      if (e != hipSuccess) { rc = -1; break; }
+      (void)hipStreamDestroy(*order[bad]);
+      *order[bad] = fresh;
+      c->streams_respread++;
+   }
+   (void)hipFree(d_t);
+   (void)hipHostFree(h_t);
+   if (zh_env("ZULTRA_HIP_SPREAD_STREAMS", 1) == 2) fprintf(stderr, "zultra_amd: %u of %d streams replaced for a hardware queue of their own\n", c->streams_respread, m);
+   if (rc != 0) snprintf(c->err, sizeof(c->err), "stream placement probe failed");
+   return rc;
+}
+#endif
+
 static int zh_enqueue_stitch(zultra_hip_ctx_t *c, hipStream_t st, uint32_t phase, int final_block, int files, bool scan_only, bool clear);
 static int zh_stitch_verdict(zultra_hip_ctx_t *c, bool scan_only);
 
@@ -696,6 +759,9 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
          for (int i = 0; i < 8; i++) ZH_CHECK(c, hipEventCreate(&c->side_ev[k][i]));
       }
       ZH_CHECK(c, hipEventCreate(&c->ev_input));
+#ifndef ZH_EMU
+      if (zh_spread_streams(c) != 0) return -1;
+#endif
       if (zh_alloc(c, &c->d_results_compact, B * c->max_subs)) return -1;
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_nsubs, (1 + ZH_MAX_RUNS) * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_scan_out, sizeof(zh_scan_out_t), 0));
