@@ -312,6 +312,36 @@ def test_chains_turn_up_after_a_batch_without_any(emu, oracle):
     _chains_after_none(emu, oracle, 24000, 32768, "pc")   # (the emulator takes a minute for the two batches)
 
 
+def _outgrown_grids(lib, checker, monkeypatch, cap, small, big, bs):
+    """The <true> overflow forms of the per-sub-block / per-task kernels are not launched for a run whose counterpart in the context's last batch stayed inside the
+    <false> grids (round 6); the grids go into the run's counters, and a run that outgrows them is void: every later kernel leaves, the stitch writes nothing, the host
+    runs the batch again with the forms (zh_run_is_void). With ZULTRA_HIP_GRID_CAP the grids are small enough to outgrow: a batch inside them, then one beyond, then the
+    first again — every batch's bytes are the checker's, and exactly the second is run twice."""
+    monkeypatch.setenv("ZULTRA_HIP_GRID_CAP", str(cap))
+    nb = (len(big) + bs - 1) // bs
+    ctx = lib.context(bs, nb)
+    try:
+        reruns = []
+        for d in (small, big, small):
+            n = len(d)
+            k = (n + bs - 1) // bs
+            blocks = [(b * bs - (32768 if b else 0), 32768 if b else 0, min(bs, n - b * bs)) for b in range(k)]
+            ctx.stitch_with_batch(k - 1, phase=0)   # (the stitch goes out with the batch: it must write nothing for a void one)
+            ctx.compress_blocks(d, blocks)
+            end_bit, _ = ctx.stitch_device(k - 1, phase=0)
+            assert ctx.stream_read((end_bit + 7) // 8).tobytes() == checker.memory_compress(d, 0, bs), len(reruns)
+            st = ctx.stats()
+            reruns.append(st["batches_rerun"])
+            assert (st["tasks"] > cap) == (d is big), st
+        assert reruns == [0, 1, 1], reruns
+    finally:
+        ctx.close()
+
+
+def test_a_run_that_outgrows_its_grids_is_run_again(emu, oracle, monkeypatch):
+    _outgrown_grids(emu, oracle, monkeypatch, 6, corpus.text_like(8000, 5), corpus.text_like(20000, 6), 65536)   # (the emulator takes 40 s)
+
+
 def test_strided_overflow_forms_of_the_per_item_kernels(emu, oracle, monkeypatch):
     _overflow_forms(emu, oracle, monkeypatch, (12288, 4, ("1",), ()))   # (48 KB: the emulator takes a minute)
 

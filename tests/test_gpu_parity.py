@@ -227,6 +227,13 @@ def test_strided_overflow_forms_of_the_per_item_kernels(gpu, checker, monkeypatc
     _overflow_forms(gpu, checker, monkeypatch, (32768, 32, ("1", "3"), ((2, 32768), (0, 65536))))
 
 
+def test_a_run_that_outgrows_its_grids_is_run_again(gpu, checker, monkeypatch):
+    """No <true> overflow forms for a run whose counterpart in the last batch stayed inside the grids; a run that outgrows them is void and the batch is run again (the
+    emulator suite's check on the real kernels, with grids capped at 64)."""
+    from test_emu_parity import _outgrown_grids
+    _outgrown_grids(gpu, checker, monkeypatch, 64, corpus.text_like(100000, 5), np.concatenate([corpus.text_like(400000, 6), corpus.table_like(100000, 3)]), 65536)
+
+
 def test_chains_turn_up_after_a_batch_without_any(gpu, checker):
     """The chain grid of a run follows what the context's last batch listed (a few workgroups after a batch without chains): 13 MiB in three runs, without chains, then
     with, then without, in several orders — the emulator suite's check on the real kernels, with what the stats say about chain kernels and reruns."""

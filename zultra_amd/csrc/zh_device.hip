@@ -87,6 +87,10 @@ struct zultra_hip_ctx_s {
    uint32_t chain_redone;                // batches run again because a run without chain kernels listed chains
    uint32_t chain_seen[ZH_MAX_RUNS];     // per run: tasks listed + cut tasks
    int chain_skip;                       // ZULTRA_HIP_CHAIN_SKIP (default 1): such a run is enqueued without chain kernels (0: always with them)
+   uint32_t seen_nsubs[ZH_MAX_RUNS], seen_ntasks[ZH_MAX_RUNS];   // ... and how many sub-blocks and tasks they had: a run that stayed inside the <false> grids last time gets no <true> forms
+   bool run_nomore[ZH_MAX_RUNS];         // this batch: run k was enqueued without them (its grids are in its counters, zh_run_is_void)
+   uint32_t run_grids[ZH_MAX_RUNS][2];   // ... the grids (sub-blocks, tasks) of its <false> forms, as enqueued
+   uint32_t *h_grids;                    // pinned: what goes into the counters (ZH_CNT_SBGRID, ZH_CNT_TASKGRID) of such runs
    bool run_nochains[ZH_MAX_RUNS];       // this batch: run k was enqueued without
    uint32_t streams_respread;   // streams replaced at creation because they shared a hardware queue with a more important one (zh_spread_streams)
    uint32_t grid_cap;           // ZULTRA_HIP_GRID_CAP (tests): the <false> grids of the per-sub-block / per-task kernels are capped here, so that the <true> forms behind them get work
@@ -519,6 +523,7 @@ extern "C" void zultra_hip_destroy(zultra_hip_ctx_t *c) {
    (void)hipFree(c->d_file_off);
    (void)hipFree(c->d_task_prefix);
    if (c->h_task_prefix) (void)hipHostFree(c->h_task_prefix);
+   if (c->h_grids) (void)hipHostFree(c->h_grids);
    if (c->h_file_off) (void)hipHostFree(c->h_file_off);
    if (c->h_nsubs) (void)hipHostFree(c->h_nsubs);
    if (c->h_scan_out) (void)hipHostFree(c->h_scan_out);
@@ -765,6 +770,7 @@ static int zh_create_buffers(zultra_hip_ctx_t *c) {
       if (zh_alloc(c, &c->d_results_compact, B * c->max_subs)) return -1;
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_nsubs, (1 + ZH_MAX_RUNS) * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_scan_out, sizeof(zh_scan_out_t), 0));
+      ZH_CHECK(c, hipHostMalloc((void **)&c->h_grids, 2 * ZH_MAX_RUNS * sizeof(uint32_t), 0));
       memset(c->h_nsubs, 0, (1 + ZH_MAX_RUNS) * sizeof(uint32_t));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_crc, B * sizeof(uint32_t), 0));
       ZH_CHECK(c, hipHostMalloc((void **)&c->h_blocks, B * sizeof(zh_block_t), 0));
@@ -1025,7 +1031,7 @@ __global__ void zh_nosplit(uint32_t nblocks, const uint32_t *__restrict__ ntok, 
 #define ZH_LAUNCH_BOTH(kernel_, grid_, bound_, stream_, ...)                                                                  \
    do {                                                                                                                       \
       ZH_LAUNCH(kernel_<false>, (grid_), 64, stream_, __VA_ARGS__, 0u);                                                       \
-      if ((uint64_t)(grid_) < (uint64_t)(bound_)) ZH_LAUNCH(kernel_<true>, ZH_MORE_GRID, 64, stream_, __VA_ARGS__, (uint32_t)(grid_)); \
+      if ((uint64_t)(grid_) < (uint64_t)(bound_) && !no_more) ZH_LAUNCH(kernel_<true>, ZH_MORE_GRID, 64, stream_, __VA_ARGS__, (uint32_t)(grid_)); \
    } while (0)
 
 static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, uint64_t total_n, uint32_t max_n, uint32_t sg0, uint32_t nsg, hipStream_t st, hipStream_t side, int part) {
@@ -1065,6 +1071,18 @@ static int zh_enqueue_run(zultra_hip_ctx_t *c, int k, uint32_t b0, uint32_t nb, 
    if (c->grid_cap) {   // (tests: everything beyond the cap goes through the <true> forms)
       task_grid = max(1u, min(task_grid, c->grid_cap));
       sb_grid = max(1u, min(sb_grid, c->grid_cap));
+   }
+   // no <true> overflow forms where the context's last batch stayed inside these grids (zh_parse.h, zh_run_is_void): the grids go into the run's counters, a run that
+   // outgrows them is void and the batch is run again with the forms
+   const bool no_more = !files && c->chain_skip && c->chain_seen_runs == c->last_runs && c->seen_nsubs[k] <= sb_grid && c->seen_ntasks[k] <= task_grid &&
+                        ((uint64_t)sb_grid < sb_bound || (uint64_t)task_grid < (uint64_t)cap);
+   c->run_nomore[k] = no_more;
+   c->run_grids[k][0] = sb_grid;
+   c->run_grids[k][1] = task_grid;
+   if (no_more) {
+      c->h_grids[2 * k] = sb_grid;
+      c->h_grids[2 * k + 1] = task_grid;
+      ZH_CHECK(c, hipMemcpyAsync(cnt + ZH_CNT_SBGRID, c->h_grids + 2 * k, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, st));   // (behind the clearing of the run's counters, on this stream)
    }
    const uint64_t seg_bound = (uint64_t)nb * c->seg_items_per_block;                     // entries of segwaves (zh_list_huge)
    if (part != 2) {
@@ -1432,8 +1450,9 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
       c->run_nochains[k] = !c->files_mode && c->chain_skip && k < lanes && c->chain_seen_runs == lanes && c->chain_seen[k] == 0;
       any_nochains = any_nochains || c->run_nochains[k];
    }
-   // (such a batch may have to be run again, see below: its stitch does not go out with it — the descriptors of a void run are not to be walked)
-   const bool stitch_with = stitch_now && !any_nochains;
+   // (such a batch may have to be run again, see below — as may one with a run enqueued without its <true> overflow forms)
+   (void)any_nochains;
+   const bool stitch_with = stitch_now;   // (safe with void runs: zh_compact_results marks the batch, zh_stitch_scan and zh_stitch then write nothing)
 
    ZH_CHECK(c, hipEventRecord(c->lane_ev[0][0], st0));
    // data_on_device == 2: pageable host memory, and the batch runs as staggered runs of max-blocks — every run's bytes are staged
@@ -1561,7 +1580,13 @@ extern "C" int zultra_hip_compress_blocks(zultra_hip_ctx_t *c, const void *data,
    }
    c->chain_seen_runs = lanes;
    for (int k = 0; k < lanes; k++) {
-      if (c->run_nochains[k] && c->chain_seen[k] != 0) {
+      const uint32_t *cnt = c->h_ntasks + (size_t)k * ZH_CNT_STRIDE;
+      c->seen_nsubs[k] = cnt[ZH_CNT_NSUBS];
+      c->seen_ntasks[k] = cnt[ZH_CNT_TASKS];
+   }
+   for (int k = 0; k < lanes; k++) {
+      const bool outgrown = c->run_nomore[k] && (c->seen_nsubs[k] > c->run_grids[k][0] || c->seen_ntasks[k] > c->run_grids[k][1]);
+      if ((c->run_nochains[k] && c->chain_seen[k] != 0) || outgrown) {
          // a run enqueued without chain kernels lists chains after all (zh_run_is_void: its kernels left at once): the batch again, every run with its chain
          // kernels (the counts just taken say so) — one batch's time, once, where the stream's content changes
          c->chain_redone++;

@@ -100,7 +100,8 @@ enum {
    ZH_CNT_SETTLED = 21 /* parse passes not run because the sub-block's prices had stopped moving (zh_sb_build_one) */, ZH_CNT_SETTLED_POS = 22 /* ... in KiB of input */,
    ZH_CNT_DEMOTED = 23 /* cut tasks handed to zh_parse_chain as whole chains for the passes left (zh_parse_one_task) */, ZH_CNT_DEMOTED_PASS = 24 /* .. 27: listed in pass p */,
    ZH_CNT_NSUBS = 28 /* sub-blocks of the run (zh_plan_subblocks: the host never sees the splitter's counts) */,
-   ZH_CNT_NOCHAINS = 29 /* set by the HOST when it enqueues the run: no chain kernels were launched for it (zh_run_is_void) */, ZH_CNT_STRIDE = 32
+   ZH_CNT_NOCHAINS = 29 /* set by the HOST when it enqueues the run: no chain kernels were launched for it (zh_run_is_void) */,
+   ZH_CNT_SBGRID = 30, ZH_CNT_TASKGRID = 31 /* set by the HOST (non-zero) when it launches no <true> overflow forms for the run: the grids of its <false> forms */, ZH_CNT_STRIDE = 32
 };
 static_assert(ZH_CNT_TASKS == 0, "zh_post_tasks / zh_emit_tasks take the run's counter block as the pointer to its task count");
 
@@ -110,8 +111,14 @@ static_assert(ZH_CNT_TASKS == 0, "zh_post_tasks / zh_emit_tasks take the run's c
 // chain kernel at all and says so in cnt[ZH_CNT_NOCHAINS]. If the run lists chains after all, its parse is incomplete: every kernel behind zh_list_huge then leaves at
 // once (nothing walks a parse that was never written), the host sees both facts in the counters it reads back anyway, and runs the batch again with the chain
 // kernels — the price of one batch, once, where a stream's content changes.
+// The same bargain for the <true> overflow forms of the per-sub-block / per-task kernels (zh_device.hip, ZH_LAUNCH_BOTH): nearly always they find nothing beyond the <false>
+// grid, yet each is a launch whose workgroups must find room on a full chip before they can leave — zh_sb_init<true> (99 registers, 8 KB of LDS) 0.4 ms on average and up to
+// 1.7 ms, on every run's path to its first parse pass (profiles/r06_timeline_c2.txt). Where the context's last batch stayed inside this batch's grids the host does not launch
+// them and leaves the grids in the counters; a run that outgrows them is void like one that lists chains without chain kernels.
 __device__ __forceinline__ bool zh_run_is_void(const uint32_t *cnt) {
-   return cnt[ZH_CNT_NOCHAINS] != 0 && (cnt[ZH_CNT_VLONG] | cnt[ZH_CNT_LONG] | cnt[ZH_CNT_SHORT] | cnt[ZH_CNT_SEGTASKS]) != 0u;
+   const bool chains = cnt[ZH_CNT_NOCHAINS] != 0 && (cnt[ZH_CNT_VLONG] | cnt[ZH_CNT_LONG] | cnt[ZH_CNT_SHORT] | cnt[ZH_CNT_SEGTASKS]) != 0u;
+   const bool outgrown = cnt[ZH_CNT_SBGRID] != 0 && (cnt[ZH_CNT_NSUBS] > cnt[ZH_CNT_SBGRID] || cnt[ZH_CNT_TASKS] > cnt[ZH_CNT_TASKGRID]);
+   return chains || outgrown;
 }
 
 // sub-block work item produced by zh_plan_subblocks

@@ -13,6 +13,7 @@
 //                    "shift by one slice" operator; the host combines the per-block values (GF(2) operator for a whole
 //                    max-block, applied once per block).
 #pragma once
+#include "zh_parse.h"   // (zh_run_is_void)
 #include <stdint.h>
 
 #include "zh_common.h"
@@ -203,6 +204,14 @@ struct zh_runs_t {
 #define ZH_COMPACT_RESULTS_THREADS 256
 __global__ void __launch_bounds__(ZH_COMPACT_RESULTS_THREADS)
 zh_compact_results(zh_runs_t R, const zh_subblock_t *__restrict__ results, const uint32_t *__restrict__ counters, zh_subblock_t *out, uint32_t *nsubs_out /* [0] total, [1 + k] of run k */) {
+   // a void run (zh_parse.h, zh_run_is_void: enqueued without chain kernels or overflow forms it turned out to need) left no descriptors: the total says so — a stitch that
+   // went out with the batch then writes nothing (zh_stitch_scan), and the host, which reads the same counters, runs the batch again
+   for (uint32_t k = 0; k < R.nruns; k++) {
+      if (zh_run_is_void(counters + (size_t)k * R.cnt_stride)) {
+         if (blockIdx.x == 0 && threadIdx.x == 0) nsubs_out[0] = 0xFFFFFFFFu;
+         return;
+      }
+   }
    uint32_t base = 0;
    for (uint32_t k = 0; k < R.nruns; k++) {
       const uint32_t ns = counters[(size_t)k * R.cnt_stride + R.nsubs_field];
@@ -246,6 +255,15 @@ zh_stitch_scan(const zh_subblock_t *__restrict__ subs, const uint32_t *__restric
    __shared__ uint32_t s_failed, s_table_failed;
    const uint32_t tid = threadIdx.x;
    const uint32_t nsubs = *nsubs_p;
+   if (nsubs == 0xFFFFFFFFu) {   // (a void run in the batch, zh_compact_results: nothing to assemble — zh_stitch leaves at `failed`)
+      if (tid == 0) {
+         out->end_bit = 0;
+         out->failed = 1;
+         out->nsubs = nsubs;
+         out->table_failed = 0xffu;
+      }
+      return;
+   }
    const uint64_t cap = zh_stitch_blockbuf_cap(max_block_size);
    if (tid == 0) s_failed = s_table_failed = 0;
    if (tid < ZH_SCAN_THREADS / 64) Wfail[tid] = 0;
