@@ -473,7 +473,8 @@ def run_stream_leg(env, lead, shard, flags, bs, steps, warmup, last_rank=None):
                 ctx.stitch_with_batch(nblocks - 1, phase=0)
             ctx.compress_blocks(d_data.data_ptr(), blocks, data_on_device=True, data_size=d_data.numel())
             t = ctx.timing()
-            extra = np.array([shard_checksum(), n], dtype=np.int64)
+            # (one rank: the fold of the per-block checksums runs while the stitched bytes come back — sharded.assemble calls it behind the start of the copy)
+            extra = (lambda: np.array([shard_checksum(), n], dtype=np.int64)) if (world == 1 and not group) else np.array([shard_checksum(), n], dtype=np.int64)
         else:
             t = None
             extra = np.array([0, 0], dtype=np.int64)   # (no bytes: a zero state stays zero, for both checksums)

@@ -599,6 +599,7 @@ static int zh_knob(const char *name, int dflt) {
 // which queue a stream has, but it shows: a context lets all its run and chain streams spin for 0.2 ms at once and looks at who ran WHEN. A stream that did not
 // overlap one ahead of it in the order of importance (the runs' streams, then their chain streams) is replaced by a fresh one — created before the old one is
 // destroyed, so the runtime's least-used-queue rule puts it elsewhere — and the test repeated, a few times at most. ~0.3 ms of context creation when all is well.
+// Opt-in (see zh_spread_streams): an application that cannot export GPU_MAX_HW_QUEUES before it initialises HIP, and runs one context at a time, sets ZULTRA_HIP_SPREAD_STREAMS=1.
 __global__ void zh_queue_probe(uint64_t *out, uint64_t ticks) {
    const uint64_t t0 = zh_wall_clock();
    uint64_t t = t0;
@@ -610,17 +611,24 @@ __global__ void zh_queue_probe(uint64_t *out, uint64_t ticks) {
    out[1] = t;
 }
 
+static std::mutex g_probe_mutex;   // one context probes at a time: two probes on a shared queue would read each other as a collision
+
 static int zh_spread_streams(zultra_hip_ctx_t *c) {
-   if (!zh_env("ZULTRA_HIP_SPREAD_STREAMS", 1)) return 0;
+   // OFF unless asked for (ZULTRA_HIP_SPREAD_STREAMS=1, 2 = and say what was done): it repairs a context that is alone on the device in a process with too few queues
+   // (49 -> 40 ms per 100 MB step), but where several contexts run side by side each one's streams on queues of their own means the contexts share every queue with
+   // each other — measured: three jobs in flight 2.64-2.71 GB/s without it, 2.45-2.64 with (tools/r06_3jobs*.sh) — and a probe taken on a busy device can misread.
+   if (zh_env("ZULTRA_HIP_SPREAD_STREAMS", 0) <= 0) return 0;
+   std::lock_guard<std::mutex> probe_lock(g_probe_mutex);
    const int n = c->nlanes;
    hipStream_t *order[2 * ZH_MAX_RUNS];
    bool high[2 * ZH_MAX_RUNS];
    int m = 0;
    // (the first three runs, their chain streams, then the rest: what a batch of less than 256 MiB uses comes first)
+   const int scope = zh_env("ZULTRA_HIP_SPREAD_SCOPE", 0);   // 0: the runs' streams only; 1: their chain streams too
    for (int k = 0; k < n && k < 3; k++) { order[m] = &c->lane_stream[k]; high[m++] = false; }
-   for (int k = 0; k < n && k < 3; k++) { order[m] = &c->side_stream[k]; high[m++] = true; }
+   if (scope >= 1) for (int k = 0; k < n && k < 3; k++) { order[m] = &c->side_stream[k]; high[m++] = true; }
    for (int k = 3; k < n; k++) { order[m] = &c->lane_stream[k]; high[m++] = false; }
-   for (int k = 3; k < n; k++) { order[m] = &c->side_stream[k]; high[m++] = true; }
+   if (scope >= 1) for (int k = 3; k < n; k++) { order[m] = &c->side_stream[k]; high[m++] = true; }
    uint64_t *d_t = NULL, *h_t = NULL;
    ZH_CHECK(c, hipMalloc((void **)&d_t, (size_t)m * 2 * sizeof(uint64_t)));
    ZH_CHECK(c, hipHostMalloc((void **)&h_t, (size_t)m * 2 * sizeof(uint64_t), 0));
@@ -635,7 +643,13 @@ static int zh_spread_streams(zultra_hip_ctx_t *c) {
       int bad = -1;
       for (int i = 1; i < m && bad < 0; i++)
          for (int j = 0; j < i; j++)
-            if (!(h_t[2 * i] < h_t[2 * j + 1] && h_t[2 * j] < h_t[2 * i + 1])) { bad = i; break; }   // i ran before or after j, not next to it
+            // i ran right BEHIND j (or j right behind i), not next to it: the signature of one queue. (A probe that merely started late — the device busy with another
+            // context's kernels — starts when THEY end, not when j does: no reason to move it. Measured with three contexts created and run side by side: replacing on
+            // mere non-overlap cost the three-jobs-in-flight leg 6 %.)
+            if (!(h_t[2 * i] < h_t[2 * j + 1] && h_t[2 * j] < h_t[2 * i + 1])) {
+               const uint64_t gap_ij = h_t[2 * i] >= h_t[2 * j + 1] ? h_t[2 * i] - h_t[2 * j + 1] : ~0ull, gap_ji = h_t[2 * j] >= h_t[2 * i + 1] ? h_t[2 * j] - h_t[2 * i + 1] : ~0ull;
+               if (gap_ij <= 3000u || gap_ji <= 3000u) { bad = i; break; }   // (30 us of the 100 MHz clock)
+            }
       if (bad < 0) break;
       hipStream_t fresh = NULL;
       const hipError_t e = high[bad] ? hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, hi_prio) : hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking);
@@ -646,7 +660,7 @@ static int zh_spread_streams(zultra_hip_ctx_t *c) {
    }
    (void)hipFree(d_t);
    (void)hipHostFree(h_t);
-   if (zh_env("ZULTRA_HIP_SPREAD_STREAMS", 1) == 2) fprintf(stderr, "zultra_amd: %u of %d streams replaced for a hardware queue of their own\n", c->streams_respread, m);
+   if (zh_env("ZULTRA_HIP_SPREAD_STREAMS", 0) == 2) fprintf(stderr, "zultra_amd: %u of %d streams replaced for a hardware queue of their own\n", c->streams_respread, m);
    if (rc != 0) snprintf(c->err, sizeof(c->err), "stream placement probe failed");
    return rc;
 }

@@ -87,6 +87,20 @@ def _to_host(torch, t):
     return buf[:n].numpy()
 
 
+def _to_host_async(torch, t):
+    """Starts the copy of a device tensor into the reused pinned buffer and returns (numpy view, wait): the caller does other host work, then calls wait()."""
+    if t.device.type != "cuda":
+        return t.numpy(), (lambda: None)
+    n = t.numel()
+    buf = _pinned.get("buf")
+    if buf is None or buf.numel() < n:
+        buf = _pinned["buf"] = torch.empty(max(n, 1 << 20) * 5 // 4, dtype=torch.uint8, pin_memory=True)
+    buf[:n].copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return buf[:n].numpy(), ev.synchronize
+
+
 def assemble(lib, ctx, max_block, dist, torch, device, final_block_local, extra=None, force_collectives=False):
     """Stitch this rank's last batch on its GPU at its true bit offset and gather the stream on rank 0.
     ctx = None for a rank whose shard is empty (it still takes part in the collectives).
@@ -100,12 +114,20 @@ def assemble(lib, ctx, max_block, dist, torch, device, final_block_local, extra=
     Returns (stream bytes as a uint8 numpy array on rank 0 / None elsewhere, info dict)."""
     import time
     rank, world = dist.get_rank(), dist.get_world_size()
-    extra = np.zeros(0, dtype=np.int64) if extra is None else np.ascontiguousarray(extra, dtype=np.int64)
 
     if world == 1 and not force_collectives:
+        # (`extra` may be a callable here: what the caller folds on the host — the shard's checksums — goes on while the stitched bytes come back)
         end_bit, _ = ctx.stitch_device(final_block_local, phase=0)
         nbytes = (end_bit + 7) // 8
-        return _to_host(torch, _stream_tensor(ctx, torch, device, nbytes)), {"shard_bytes": nbytes, "start_phase": 0, "sent_bytes": 0, "extras": [extra], "collective_ms": 0.0}
+        body, wait = _to_host_async(torch, _stream_tensor(ctx, torch, device, nbytes))
+        if callable(extra):
+            extra = extra()
+        extra = np.zeros(0, dtype=np.int64) if extra is None else np.ascontiguousarray(extra, dtype=np.int64)
+        wait()
+        return body, {"shard_bytes": nbytes, "start_phase": 0, "sent_bytes": 0, "extras": [extra], "collective_ms": 0.0}
+    if callable(extra):
+        extra = extra()
+    extra = np.zeros(0, dtype=np.int64) if extra is None else np.ascontiguousarray(extra, dtype=np.int64)
 
     # (1) phase tables of every rank -> start phase and byte offset of every shard
     t_coll = time.perf_counter()
