@@ -166,6 +166,15 @@ struct zh_async_row_t {
 template <int N>
 inline void zh_async_wait() {}
 inline void zh_async_landed(zh_async_row_t &) {}
+struct zh_async_tile_t {
+   uint32_t b, y;
+};
+#define ZH_ASYNC_TILE_LOADS 2
+inline void zh_async_load_tile(zh_async_tile_t &t, const uint32_t *pb, const uint8_t *py) {
+   t.b = *pb;
+   t.y = *py;
+}
+inline void zh_async_landed(zh_async_tile_t &) {}
 inline void zh_wave_sync() {
    zh_emu::collect(0, [] { return (uint64_t)0; });
 }

@@ -183,6 +183,7 @@ struct zh_sb_ws_t {
       zh_cl_t cl_work[20];                                  // the header candidates (:947-992)
    };
 };
+static_assert(ZH_OBUF_WORDS * 4 >= 256, "zh_post_tasks stages 256 bytes of the task in the emission window");
 static_assert(sizeof(zh_sb_ws_t) <= 8192, "twenty workgroups of zh_sb_build per CU (160 KB of LDS)");
 
 __device__ inline void zh_store_codes_wave(zh_sbstate_t *st, const zh_sb_ws_t *ws) {
@@ -516,13 +517,24 @@ __device__ __forceinline__ void zh_post_task_one(zh_task_ws_t &ws, uint32_t gt, 
       // (a task can be tens of thousands of positions — a whole chain — and a tile's work hangs on one global load: the next tile's is
       // issued before this tile is worked on. A tile's literalisations may reach into the tiles loaded ahead, but only at positions the
       // chain jumps over: what the walk reads of a position that is a token start is never changed under it.)
+      // (round 6) the bytes a match is priced against as literals come from LDS: the task's bytes are staged tile by tile, two tiles ahead, in a 256-byte ring (the
+      // emission window of zh_emit_tasks, idle here) — a match is literalised or kept within its first few bytes (its price is a few dozen bits at most), and every
+      // one of those was a dependent load from global memory in a loop that a whole tile waits for: ~2800 cycles per tile, and one wave walks a whole task (a chain
+      // task: tens of thousands of positions — this kernel lasted as long as its longest task, 1.0 ms for one run alone). Bytes beyond the staged tiles: from memory.
+      uint8_t *stage = (uint8_t *)ws.obuf;
       uint32_t carry = 0;
       uint32_t b_next = (t0 + lane < t1) ? best[t0 + lane - prev] : 0;
+      uint32_t y_next = (t0 + 64 + lane < t1) ? (uint32_t)win[t0 + 64 + lane] : 0u;   // the bytes of the tile after the next one loaded
+      if (t0 + lane < t1) stage[lane] = win[t0 + lane];
       for (uint32_t base = t0; base < t1; base += 64) {
          const uint32_t limit = min(64u, t1 - base);
          const uint32_t pos = base + lane;
          const uint32_t b = b_next;
          b_next = (pos + 64 < t1) ? best[pos + 64 - prev] : 0;
+         stage[(pos + 64 - t0) & 255u] = (uint8_t)y_next;   // tile base + 64 .. base + 127 (the ring holds base - 64 .. base + 191)
+         y_next = (pos + 128 < t1) ? (uint32_t)win[pos + 128] : 0u;
+         zh_sync();
+         const uint32_t staged_end = min(t1, base + 128u);
          const uint32_t len = b & 0xffffu;
          const uint64_t mask = zh_chain_mask(len, carry, limit);
          if (((mask >> lane) & 1ull) && len >= ZH_MIN_MATCH) {
@@ -532,7 +544,8 @@ __device__ __forceinline__ void zh_post_task_one(zh_task_ws_t &ws, uint32_t gt, 
                uint32_t lcost = 0, j = 0;
                bool usable = true;
                for (; j < len && lcost < mcost; j++) {
-                  const uint32_t l = ws.pre_lit_len[win[pos + j]];
+                  const uint32_t pj = pos + j;
+                  const uint32_t l = ws.pre_lit_len[pj < staged_end ? (uint32_t)stage[(pj - t0) & 255u] : (uint32_t)win[pj]];
                   if (l == 0) {
                      usable = false;   // a byte without a code keeps the match (:436-440)
                      break;
@@ -543,6 +556,7 @@ __device__ __forceinline__ void zh_post_task_one(zh_task_ws_t &ws, uint32_t gt, 
                   for (j = 0; j < len; j++) best[pos - prev + j] &= 0xffff0000u;   // length := 0 (:449-451)
             }
          }
+         zh_sync();   // (the next tile's bytes go over the ring's oldest)
       }
       __threadfence_block();
       zh_sync();
@@ -550,20 +564,7 @@ __device__ __forceinline__ void zh_post_task_one(zh_task_ws_t &ws, uint32_t gt, 
 
    // bits of the task's tokens under the final codes
    uint32_t bits = 0, carry = 0;
-   uint32_t b_next = 0, byte_next = 0;
-   if (t0 + lane < t1) {
-      b_next = best[t0 + lane - prev];
-      byte_next = win[t0 + lane];
-   }
-   for (uint32_t base = t0; base < t1; base += 64) {
-      const uint32_t limit = min(64u, t1 - base);
-      const uint32_t pos = base + lane;
-      const uint32_t b = b_next, byte = byte_next;
-      b_next = 0;
-      if (pos + 64 < t1) {   // the next tile's loads, under this tile's work
-         b_next = best[pos + 64 - prev];
-         byte_next = win[pos + 64];
-      }
+   if (t0 < t1) ZH_WALK_BEGIN(best, win, prev, t0, t1)   // (tiles in flight tracked by hand, zh_parse.h: this walk issues no vector-memory operation of its own)
       const uint32_t len = b & 0xffffu;
       const uint64_t mask = zh_chain_mask(len, carry, limit);
       if ((mask >> lane) & 1ull) {
@@ -574,7 +575,7 @@ __device__ __forceinline__ void zh_post_task_one(zh_task_ws_t &ws, uint32_t gt, 
          else
             bits += ws.lit_len[byte];
       }
-   }
+   ZH_WALK_END
    bits = zh_wave_sum(bits);
    if (lane == 0) task_bits[gt] = bits;
 }

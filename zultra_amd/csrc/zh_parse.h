@@ -173,24 +173,48 @@ __device__ inline bool zh_task_is_huge(const uint32_t *bnd, uint32_t np, uint32_
 }
 
 // ---- forward walk over the chosen parse of [t0, t1): histogram into LDS counters (blockdeflate.c:371-400) ----------
+// Forward walks over a parse that issue NO vector-memory operation of their own (this one; the bit count of zh_post_tasks) go tile by tile with ZH_WALK_AHEAD tiles in
+// flight, tracked by hand (zh_async_load_tile / zh_async_wait, zh_platform.h). A tile's work — a ballot, a few scalar hops, a handful of LDS updates — is a few hundred
+// cycles, the round trip of its loads a microsecond, and ONE wave walks a whole task (a chain task: tens of thousands of positions). Rounds 2-5 requested "the next tile
+// under this tile's work" with plain loads; the work contains a loop (zh_chain_mask), and around a loop the compiler waits for every load in flight, the youngest
+// included, so the read-ahead was none (four tiles ahead with plain loads measured the same: profiles/r06_ab_results.txt). Measured, one 32 MiB run alone on the chip:
+// zh_parse_chain 7.98 -> 7.42 ms over the four passes, zh_parse_lanes 9.76 -> 9.43, zh_post_tasks (with its byte ring) 1.02 -> 0.93; the step of the bench is within
+// noise of where it was — the two parse kernels overlap. A lane whose position lies behind the range loads the range's last position and is masked.
+#define ZH_WALK_AHEAD 4
+#define ZH_WALK_BEGIN(best_, win_, prev_, t0_, t1_)                                                                                    \
+   {                                                                                                                                   \
+      zh_async_tile_t wq_[ZH_WALK_AHEAD];                                                                                              \
+      zh_async_wait<0>();   /* (whatever the caller had in flight: the counts below are this walk's alone) */                         \
+      _Pragma("unroll") for (uint32_t wu_ = 0; wu_ < ZH_WALK_AHEAD; wu_++) {                                                            \
+         const uint32_t wp_ = min((t0_) + 64u * wu_ + zh_lane(), (t1_) - 1u);                                                          \
+         zh_async_load_tile(wq_[wu_], (best_) + (wp_ - (prev_)), (win_) + wp_);                                                        \
+      }                                                                                                                                \
+      for (uint32_t wbase_ = (t0_); wbase_ < (t1_); wbase_ += 64u * ZH_WALK_AHEAD) {                                                   \
+         _Pragma("unroll") for (uint32_t wu_ = 0; wu_ < ZH_WALK_AHEAD; wu_++) {                                                         \
+            const uint32_t base = wbase_ + 64u * wu_;                                                                                  \
+            if (base < (t1_)) {                                                                                                        \
+               const uint32_t limit = min(64u, (t1_) - base);                                                                          \
+               const uint32_t pos = base + zh_lane();                                                                                  \
+               zh_async_wait<(ZH_WALK_AHEAD - 1) * ZH_ASYNC_TILE_LOADS>();   /* this tile's loads have landed: vector-memory operations complete in order */ \
+               zh_async_landed(wq_[wu_]);                                                                                              \
+               const uint32_t b = pos < (t1_) ? wq_[wu_].b : 0u, byte = pos < (t1_) ? (wq_[wu_].y & 0xffu) : 0u;                       \
+               {                                                                                                                       \
+                  const uint32_t wn_ = min(pos + 64u * ZH_WALK_AHEAD, (t1_) - 1u);                                                     \
+                  zh_async_load_tile(wq_[wu_], (best_) + (wn_ - (prev_)), (win_) + wn_);                                               \
+               }                                                                                                                       \
+               (void)limit; (void)byte;
+#define ZH_WALK_END            \
+            }                  \
+         }                     \
+      }                        \
+      zh_async_wait<0>();      \
+   }
+
 __device__ inline void zh_walk_histogram_wave(uint32_t *hist /* ZH_NSYM, zeroed */, const uint8_t *win, uint32_t prev, uint32_t t0, uint32_t t1,
                                               const uint32_t *best) {
    const uint32_t lane = zh_lane();
    uint32_t carry = 0;
-   uint32_t b_next = 0, byte_next = 0;
-   if (t0 + lane < t1) {
-      b_next = best[t0 + lane - prev];
-      byte_next = win[t0 + lane];
-   }
-   for (uint32_t base = t0; base < t1; base += 64) {
-      const uint32_t limit = min(64u, t1 - base);
-      const uint32_t pos = base + lane;
-      const uint32_t b = b_next, byte = byte_next;
-      b_next = 0;
-      if (pos + 64 < t1) {   // the next tile's loads, under this tile's work (the walk of a chain task is thousands of tiles long)
-         b_next = best[pos + 64 - prev];
-         byte_next = win[pos + 64];
-      }
+   if (t0 < t1) ZH_WALK_BEGIN(best, win, prev, t0, t1)
       const uint32_t len = b & 0xffffu;
       const uint64_t mask = zh_chain_mask(len, carry, limit);
       if ((mask >> lane) & 1ull) {
@@ -201,7 +225,7 @@ __device__ inline void zh_walk_histogram_wave(uint32_t *hist /* ZH_NSYM, zeroed 
          else
             atomicAdd(&hist[byte], 1u);
       }
-   }
+   ZH_WALK_END
    zh_wave_sync();
 }
 

@@ -219,6 +219,16 @@ __device__ __forceinline__ void zh_async_wait() { asm volatile("s_waitcnt vmcnt(
 // after the wait: the registers now hold the loaded values (keeps the compiler from having moved their use above the wait)
 __device__ __forceinline__ void zh_async_landed(zh_async_row_t &r) { asm volatile("" : "+v"(r.a), "+v"(r.b), "+v"(r.byte)::"memory"); }
 
+// ... and one tile of a forward walk over a parse (zh_parse.h, ZH_WALK_*): a parse entry and a byte per lane
+struct zh_async_tile_t {
+   uint32_t b, y;
+};
+__device__ __forceinline__ void zh_async_load_tile(zh_async_tile_t &t, const uint32_t *pb, const uint8_t *py) {
+   asm volatile("global_load_dword %0, %2, off\n\tglobal_load_ubyte %1, %3, off" : "=&v"(t.b), "=&v"(t.y) : "v"(pb), "v"(py) : "memory");
+}
+#define ZH_ASYNC_TILE_LOADS 2   // vector-memory operations per zh_async_load_tile
+__device__ __forceinline__ void zh_async_landed(zh_async_tile_t &t) { asm volatile("" : "+v"(t.b), "+v"(t.y)::"memory"); }
+
 // LDS visibility between the lanes of ONE wave (wave-private data inside a multi-wave workgroup): LDS operations of a
 // wave execute in order, so draining them and stopping the compiler from moving accesses across is all it takes.
 __device__ __forceinline__ void zh_wave_sync() {
