@@ -186,12 +186,11 @@ def test_multiblock_stream_bit_carry_and_stored_fallback(emu, oracle):
     assert zlib.decompress(got, 31) == d.tobytes()
 
 
-def _scan_vs_planner(lib, more=True):
+def _scan_vs_planner(lib, more=True, bs=32768):
     """The device scan of the stitcher (zh_stitch_scan: transfer tables bit phase -> bits added, composed over the batch) against the serial
     host planner (zh_stitch_plan, behind zultra_hip_stitch), at every one of the eight start phases: same bytes, same end bit, same new phase;
     and the eight-entry phase table a rank hands its neighbours (zultra_hip_stitch_phase_table) = the eight end bits."""
     import ctypes as C
-    bs = 32768
     t = corpus.text_like(3 * bs, 11)
     d = t.copy()
     d[bs + 100: bs + 9000] = corpus.noise(8900, 1)        # a stored sub-block inside the second max-block
@@ -249,7 +248,7 @@ def _scan_vs_planner(lib, more=True):
 
 
 def test_device_scan_equals_the_host_planner_at_every_phase(emu):
-    _scan_vs_planner(emu, more=False)
+    _scan_vs_planner(emu, more=False, bs=16384)   # (half the bytes of the GPU form: a third of the emulator suite's longest test)
 
 
 def _overflow_forms(lib, checker, monkeypatch, sizes):
